@@ -1,0 +1,93 @@
+/* marlin_hip.h -- C ABI of libmarlin_hip.so: the MI355X (gfx950) implementation of the
+ * Marlin prover hot path (MSM + NTT inside Marlin::prove and the KZG10 commit/open
+ * calls underneath it).
+ *
+ * The reference (arkworks-rs/marlin 0.3.0, /root/reference) has no FFI seam
+ * (#![forbid(unsafe_code)], src/lib.rs:16).  The entry points below are what a
+ * Rust shim binds in order to drop this library in behind the reference's two
+ * replaceable seams:
+ *   B1  the `PC: PolynomialCommitment` type parameter of Marlin<F, PC, FS>
+ *       (src/lib.rs:64,70): PC::commit (src/lib.rs:125,172,193,213) and
+ *       PC::open_combinations (src/lib.rs:292) reduce to
+ *       VariableBaseMSM::multi_scalar_mul  ->  mh_msm / mh_msm_dev
+ *   B2  the hard-wired GeneralEvaluationDomain<F> (src/ahp/prover.rs:49-55,280-287):
+ *       Radix2EvaluationDomain::{fft_in_place, ifft_in_place}  ->  mh_ntt / mh_ntt_dev
+ * INTEGRATION.md shows the Rust side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MH_E* code on failure; it never
+ *     throws and never aborts.  mh_last_error() returns a thread-local message.
+ *   - host pointers are caller-owned.  Field elements are little-endian u64 limbs in
+ *     arkworks' in-memory order and (unless stated) Montgomery form: Fr = 4 limbs,
+ *     Fq = 6 limbs.  A G1 affine point is x||y (12 limbs, no infinity flag); a G1
+ *     Jacobian point is X||Y||Z (18 limbs), Z = 0 meaning the identity.
+ *   - one process drives one GPU (mh_init(device)); calls are serialised on one HIP
+ *     stream per process (mh_set_stream lets the caller supply it).
+ *   - "_dev" variants take device pointers (hipMalloc / mh_alloc / torch data_ptr).
+ */
+#ifndef MARLIN_HIP_H
+#define MARLIN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_OK 0
+#define MH_EINVAL (-1)   /* bad argument */
+#define MH_ENOMEM (-2)   /* device or host allocation failed */
+#define MH_EHIP (-3)     /* HIP runtime error (see mh_last_error) */
+#define MH_ENOINIT (-4)  /* mh_init not called */
+#define MH_ENODEV (-5)   /* no usable gfx950 device */
+
+#define MH_FIELD_BLS12_381_FR 0
+#define MH_CURVE_BLS12_381_G1 0
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+int mh_init(int device_id);               /* idempotent for the same device */
+int mh_shutdown(void);
+const char* mh_last_error(void);
+int mh_set_stream(void* hip_stream);      /* NULL -> library-owned stream */
+int mh_synchronize(void);
+int mh_device_info(char* name_out, size_t name_cap, int* cu_count, size_t* hbm_bytes);
+
+/* ---- device memory (plain hipMalloc/hipFree/hipMemcpy on the library stream) ---- */
+int mh_alloc(size_t bytes, void** dptr_out);
+int mh_free(void* dptr);
+int mh_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int mh_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int mh_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes);
+int mh_memset(void* dst_dev, int byte, size_t bytes);
+
+/* ---- NTT over Fr: replaces ark_poly Radix2EvaluationDomain::{fft,ifft}_in_place ------
+ * data: n = 2^log_n Montgomery Fr elements, natural order in and out; inverse != 0
+ * also multiplies by n^-1.  log_n in [0, 32] (bounded by device memory). */
+int mh_ntt(int field, uint64_t* data_mont, uint32_t log_n, int inverse);
+int mh_ntt_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse);
+
+/* ---- MSM over G1: replaces ark_ec VariableBaseMSM::multi_scalar_mul ------------------
+ * Bases are uploaded once (the SRS: KZG10 powers_of_g / powers_of_gamma_g) and
+ * addressed by handle + offset, because ark-poly-commit slices one SRS array
+ * (powers[num_leading_zeros..], shifted_powers[..]).  Output: Jacobian X||Y||Z. */
+int mh_bases_upload(int curve, const uint64_t* xy_mont, size_t n, uint64_t* handle_out);
+int mh_bases_from_dev(int curve, const void* d_xy_mont, size_t n, uint64_t* handle_out); /* adopts a copy */
+int mh_bases_free(uint64_t handle);
+int mh_bases_len(uint64_t handle, size_t* n_out);
+int mh_msm(uint64_t bases_handle, size_t base_offset, const uint64_t* scalars, int scalars_are_montgomery,
+           size_t n, uint64_t* out_xyz_mont);
+int mh_msm_dev(uint64_t bases_handle, size_t base_offset, const void* d_scalars, int scalars_are_montgomery,
+               size_t n, uint64_t* out_xyz_mont);
+/* Jacobian -> affine x||y (Montgomery) + infinity flag, on the host (GroupProjective::into_affine) */
+int mh_g1_to_affine(const uint64_t* xyz_mont, uint64_t* xy_mont_out, int* is_infinity_out);
+
+/* ---- profiling: accumulated HIP-event time per kernel family on the library stream ----
+ * family: 0 = ntt passes, 1 = msm (all stages), 2 = msm accum only, 3 = glue.  */
+int mh_prof_enable(int on);
+int mh_prof_reset(void);
+int mh_prof_get(int family, double* total_ms_out, uint64_t* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARLIN_HIP_H */

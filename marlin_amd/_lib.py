@@ -1,0 +1,70 @@
+"""ctypes binding of libmarlin_hip.so (the C ABI declared in include/marlin_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a GPU call fails,
+the error propagates.  The oracle under /oracle is never imported from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmarlin_hip.so")
+
+# every symbol include/marlin_hip.h declares: (restype, argtypes)
+_u64p = C.POINTER(C.c_uint64)
+SYMBOLS = {
+    "mh_init": (C.c_int, [C.c_int]),
+    "mh_shutdown": (C.c_int, []),
+    "mh_last_error": (C.c_char_p, []),
+    "mh_set_stream": (C.c_int, [C.c_void_p]),
+    "mh_synchronize": (C.c_int, []),
+    "mh_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "mh_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mh_free": (C.c_int, [C.c_void_p]),
+    "mh_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mh_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mh_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mh_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
+    "mh_ntt": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_int]),
+    "mh_ntt_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
+    "mh_bases_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
+    "mh_bases_from_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
+    "mh_bases_free": (C.c_int, [C.c_uint64]),
+    "mh_bases_len": (C.c_int, [C.c_uint64, C.POINTER(C.c_size_t)]),
+    "mh_msm": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "mh_msm_dev": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "mh_g1_to_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "mh_prof_enable": (C.c_int, [C.c_int]),
+    "mh_prof_reset": (C.c_int, []),
+    "mh_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), _u64p]),
+}
+
+
+class MarlinHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libmarlin_hip.so and bind every declared symbol; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MarlinHipError(
+            "libmarlin_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C marlin_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mh_last_error()
+        raise MarlinHipError("%s failed (code %d): %s" % (what or "marlin_hip call", rc, (msg or b"").decode()))

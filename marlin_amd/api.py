@@ -1,0 +1,166 @@
+"""Thin, typed wrappers over the C ABI (no arithmetic happens in Python)."""
+import ctypes as C
+import numpy as np
+from . import _lib
+
+FIELD_FR = 0
+CURVE_G1 = 0
+
+
+def _L():
+    return _lib.load()
+
+
+def init(device=0):
+    _lib.check(_L().mh_init(int(device)), "mh_init")
+
+
+def shutdown():
+    _lib.check(_L().mh_shutdown(), "mh_shutdown")
+
+
+def synchronize():
+    _lib.check(_L().mh_synchronize(), "mh_synchronize")
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cu = C.c_int()
+    mem = C.c_size_t()
+    _lib.check(_L().mh_device_info(name, 256, C.byref(cu), C.byref(mem)), "mh_device_info")
+    return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+
+def _as_u64(a, limbs):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim != 2 or a.shape[1] != limbs:
+        raise ValueError("expected uint64 array of shape (n, %d), got %r" % (limbs, a.shape))
+    return a
+
+
+class DeviceBuffer:
+    """hipMalloc'd buffer owned by the library's device (mh_alloc / mh_free)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _lib.check(_L().mh_alloc(self.nbytes, C.byref(p)), "mh_alloc")
+        self.ptr = p.value or 0
+
+    @classmethod
+    def from_numpy(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes)
+        b.upload(arr)
+        return b
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _lib.check(_L().mh_memcpy_h2d(self.ptr, arr.ctypes.data, arr.nbytes), "mh_memcpy_h2d")
+
+    def download(self, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _lib.check(_L().mh_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes), "mh_memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.check(_L().mh_free(self.ptr), "mh_free")
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _log2_exact(n):
+    l = int(n).bit_length() - 1
+    if n <= 0 or (1 << l) != n:
+        raise ValueError("length must be a power of two, got %d" % n)
+    return l
+
+
+def ntt(evals_or_coeffs, inverse=False):
+    """Host-buffer NTT (GeneralEvaluationDomain::fft / ifft): (n,4) uint64 Montgomery Fr."""
+    a = _as_u64(evals_or_coeffs, 4).copy()
+    log_n = _log2_exact(a.shape[0])
+    _lib.check(_L().mh_ntt(FIELD_FR, a.ctypes.data, log_n, 1 if inverse else 0), "mh_ntt")
+    return a
+
+
+def intt(evals):
+    return ntt(evals, inverse=True)
+
+
+def ntt_dev(d_in, d_out, log_n, inverse=False):
+    """Device-resident NTT; d_in / d_out are DeviceBuffer or raw device pointers."""
+    pi = d_in.ptr if isinstance(d_in, DeviceBuffer) else int(d_in)
+    po = d_out.ptr if isinstance(d_out, DeviceBuffer) else int(d_out)
+    _lib.check(_L().mh_ntt_dev(FIELD_FR, pi, po, int(log_n), 1 if inverse else 0), "mh_ntt_dev")
+
+
+class Bases:
+    """An SRS slice resident on the device (KZG10 powers_of_g): mh_bases_upload."""
+
+    def __init__(self, xy_mont):
+        a = _as_u64(xy_mont, 12)
+        h = C.c_uint64()
+        _lib.check(_L().mh_bases_upload(CURVE_G1, a.ctypes.data, a.shape[0], C.byref(h)), "mh_bases_upload")
+        self.handle = h.value
+        self.n = a.shape[0]
+
+    def free(self):
+        if self.handle:
+            _lib.check(_L().mh_bases_free(self.handle), "mh_bases_free")
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm(bases, scalars, base_offset=0, montgomery=True):
+    """VariableBaseMSM::multi_scalar_mul: returns Jacobian X||Y||Z as (18,) uint64 (Montgomery)."""
+    s = _as_u64(scalars, 4)
+    out = np.zeros(18, dtype=np.uint64)
+    _lib.check(_L().mh_msm(bases.handle, int(base_offset), s.ctypes.data, 1 if montgomery else 0, s.shape[0],
+                           out.ctypes.data), "mh_msm")
+    return out
+
+
+def msm_dev(bases, d_scalars, n, base_offset=0, montgomery=True):
+    p = d_scalars.ptr if isinstance(d_scalars, DeviceBuffer) else int(d_scalars)
+    out = np.zeros(18, dtype=np.uint64)
+    _lib.check(_L().mh_msm_dev(bases.handle, int(base_offset), p, 1 if montgomery else 0, int(n), out.ctypes.data),
+               "mh_msm_dev")
+    return out
+
+
+def g1_to_affine(xyz):
+    """GroupProjective::into_affine on the host: returns ((12,) uint64 x||y Montgomery, is_infinity)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.uint64)
+    out = np.zeros(12, dtype=np.uint64)
+    inf = C.c_int()
+    _lib.check(_L().mh_g1_to_affine(xyz.ctypes.data, out.ctypes.data, C.byref(inf)), "mh_g1_to_affine")
+    return out, bool(inf.value)
+
+
+def prof_enable(on=True):
+    _lib.check(_L().mh_prof_enable(1 if on else 0), "mh_prof_enable")
+
+
+def prof_reset():
+    _lib.check(_L().mh_prof_reset(), "mh_prof_reset")
+
+
+def prof_get(family):
+    ms = C.c_double()
+    n = C.c_uint64()
+    _lib.check(_L().mh_prof_get(int(family), C.byref(ms), C.byref(n)), "mh_prof_get")
+    return ms.value, n.value

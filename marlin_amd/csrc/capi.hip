@@ -1,0 +1,467 @@
+// libmarlin_hip.so -- C ABI entry points (include/marlin_hip.h) and the host-side
+// drivers that sequence the gfx950 kernels.
+#include "context.h"
+#include "ff.cuh"
+#include "g1.cuh"
+#include "msm.cuh"
+#include "ntt.cuh"
+#include "host_ff.h"
+
+using namespace mh;
+using hostff::HFq;
+using hostff::HFr;
+using hostff::HG1;
+using hostff::HG1Affine;
+
+namespace mh {
+thread_local std::string g_err;
+Context& ctx() {
+  static Context c;
+  return c;
+}
+
+static Fr to_dev_fr(const HFr& h) {
+  Fr r;
+  memcpy(r.v, h.v, 32);
+  return r;
+}
+
+// --------------------------------------------------------------------------------
+// NTT driver
+// --------------------------------------------------------------------------------
+static int ensure_twiddles(Context& c, uint32_t log_n) {
+  if (c.tw && c.tw_log >= log_n) return MH_OK;
+  uint32_t want = log_n < 16 ? 16 : log_n;
+  if (c.tw) { MH_HIP(hipStreamSynchronize(c.stream)); (void)hipFree(c.tw); c.tw = nullptr; c.tw_log = 0; }
+  MH_HIP(hipMalloc(&c.tw, (size_t)32 << want));
+  uint64_t n = 1ull << want;
+  Fr root = to_dev_fr(hostff::fr_two_adic_root());
+  hipLaunchKernelGGL(ntt::build_twiddles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, (Fr*)c.tw, want, root);
+  MH_HIP(hipGetLastError());
+  c.tw_log = want;
+  return MH_OK;
+}
+
+static void plan_passes(uint32_t log_n, uint32_t* bits, int* npass) {
+  int np = (int)((log_n + ntt::MAX_B - 1) / ntt::MAX_B);
+  if (np == 0) np = 1;
+  uint32_t base = log_n / np, rem = log_n % np;
+  for (int i = 0; i < np; i++) bits[i] = base + ((uint32_t)i < rem ? 1 : 0);
+  *npass = np;
+}
+
+static int launch_pass(Context& c, const Fr* x, Fr* y, uint32_t log_n, uint32_t B, uint32_t logP, uint32_t flags,
+                       const Fr& ninv) {
+  uint32_t logc = log_n - B;
+  if (logc > (uint32_t)ntt::MAX_LOGC) logc = ntt::MAX_LOGC;
+  uint64_t blocks = (1ull << (log_n - B)) >> logc;
+  size_t lds = ntt::pass_lds_bytes(B, (int)logc);
+  dim3 grid((unsigned)blocks), block(ntt::THREADS);
+  switch (logc) {
+    case 0: hipLaunchKernelGGL(ntt::pass_kernel<0>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv); break;
+    case 1: hipLaunchKernelGGL(ntt::pass_kernel<1>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv); break;
+    case 2: hipLaunchKernelGGL(ntt::pass_kernel<2>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv); break;
+    default: hipLaunchKernelGGL(ntt::pass_kernel<3>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv); break;
+  }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+static bool g_ntt_attr_done = false;
+static int ntt_set_attrs() {
+  if (g_ntt_attr_done) return MH_OK;
+  int lds = (int)ntt::pass_lds_bytes(ntt::MAX_B, ntt::MAX_LOGC);
+  MH_HIP(hipFuncSetAttribute((const void*)ntt::pass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  MH_HIP(hipFuncSetAttribute((const void*)ntt::pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  MH_HIP(hipFuncSetAttribute((const void*)ntt::pass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  MH_HIP(hipFuncSetAttribute((const void*)ntt::pass_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  g_ntt_attr_done = true;
+  return MH_OK;
+}
+
+// d_in may equal d_out.
+int ntt_device(Context& c, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
+  if (log_n > 32) return fail(MH_EINVAL, "log_n > two-adicity (32)");
+  size_t bytes = (size_t)32 << log_n;
+  if (log_n == 0) {
+    if (d_in != d_out) MH_HIP(hipMemcpyAsync(d_out, d_in, 32, hipMemcpyDeviceToDevice, c.stream));
+    return MH_OK;
+  }
+  MH_TRY(ensure_twiddles(c, log_n));
+  MH_TRY(ntt_set_attrs());
+  uint32_t bits[8];
+  int np;
+  plan_passes(log_n, bits, &np);
+  // n^-1 in Montgomery form
+  HFr ninv_h = HFr::from_u64(1ull << (log_n < 63 ? log_n : 0)).inv();
+  Fr ninv = to_dev_fr(ninv_h);
+  // buffer chain: in -> ... -> out, intermediates in scratch (never writes d_in unless d_in == d_out)
+  const Fr* src = (const Fr*)d_in;
+  MH_TRY(c.ntt_tmp[0].ensure(np > 1 ? bytes : 0));
+  MH_TRY(c.ntt_tmp[1].ensure(np > 2 ? bytes : 0));
+  uint32_t logP = 0;
+  ProfScope ps(c, PF_NTT);
+  for (int p = 0; p < np; p++) {
+    Fr* dst;
+    if (p == np - 1) dst = (Fr*)d_out;
+    else dst = (Fr*)c.ntt_tmp[p & 1].ptr;
+    // last pass writes d_out; if d_out == src of this pass (only when np == 1 and in-place) bounce via scratch
+    if (p == np - 1 && (const void*)dst == (const void*)src) {
+      MH_TRY(c.ntt_tmp[0].ensure(bytes));
+      dst = (Fr*)c.ntt_tmp[0].ptr;
+      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, (inverse && p == np - 1) ? 1u : 0u, ninv));
+      MH_HIP(hipMemcpyAsync(d_out, dst, bytes, hipMemcpyDeviceToDevice, c.stream));
+    } else {
+      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, (inverse && p == np - 1) ? 1u : 0u, ninv));
+    }
+    src = dst;
+    logP += bits[p];
+  }
+  return MH_OK;
+}
+
+// --------------------------------------------------------------------------------
+// MSM driver
+// --------------------------------------------------------------------------------
+static bool g_msm_attr_done = false;
+static int msm_set_attrs() {
+  if (g_msm_attr_done) return MH_OK;
+  int lds = 32768 * 4;
+  MH_HIP(hipFuncSetAttribute((const void*)msm::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  g_msm_attr_done = true;
+  return MH_OK;
+}
+
+// window sums (device XYZZ) -> one Jacobian point on the host
+static HG1 combine_windows(const std::vector<uint64_t>& win, uint32_t W, uint32_t c) {
+  HG1 acc = HG1::identity();
+  for (int w = (int)W - 1; w >= 0; w--) {
+    for (uint32_t k = 0; k < c; k++) acc = acc.dbl();
+    const uint64_t* p = win.data() + (size_t)w * 24;
+    HFq X, Y, ZZ, ZZZ;
+    memcpy(X.v, p, 48); memcpy(Y.v, p + 6, 48); memcpy(ZZ.v, p + 12, 48); memcpy(ZZZ.v, p + 18, 48);
+    acc = acc.add(HG1::from_xyzz(X, Y, ZZ, ZZZ));
+  }
+  return acc;
+}
+
+int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mont, size_t n, uint64_t* out_xyz) {
+  if (n == 0) {
+    HG1 id = HG1::identity();
+    memcpy(out_xyz, id.X.v, 48); memcpy(out_xyz + 6, id.Y.v, 48); memcpy(out_xyz + 12, id.Z.v, 48);
+    return MH_OK;
+  }
+  if (n >= (1ull << 31)) return fail(MH_EINVAL, "msm: n must be < 2^31");
+  MH_TRY(msm_set_attrs());
+  msm::Plan p = msm::make_plan(n);
+  const size_t WN = (size_t)p.W * n;
+  const size_t WB = (size_t)p.W * p.nb;
+  MH_TRY(c.msm_dig.ensure(WN * 4));
+  MH_TRY(c.msm_sorted.ensure(WN * 4));
+  MH_TRY(c.msm_bh.ensure((size_t)p.W * p.ntiles * p.nb * 4));
+  MH_TRY(c.msm_tot.ensure(WB * 4));
+  MH_TRY(c.msm_base.ensure(WB * 4));
+  MH_TRY(c.msm_buckets.ensure(WB * sizeof(G1Xyzz)));
+  MH_TRY(c.msm_seg.ensure((size_t)p.W * p.nseg * sizeof(G1Xyzz)));
+  MH_TRY(c.msm_win.ensure((size_t)p.W * sizeof(G1Xyzz)));
+  hipStream_t s = c.stream;
+  {
+    ProfScope ps(c, PF_MSM);
+    hipLaunchKernelGGL(msm::digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const Fr*)d_scalars,
+                       (u32*)c.msm_dig.ptr, (u64)n, p.c, p.W, is_mont);
+    size_t lds = (size_t)p.nb * 4;
+    hipLaunchKernelGGL(msm::hist_kernel, dim3(p.ntiles, p.W), dim3(msm::HIST_THREADS), lds, s, (const u32*)c.msm_dig.ptr,
+                       (u32*)c.msm_bh.ptr, (u64)n, p.nb, p.tile, p.ntiles);
+    hipLaunchKernelGGL(msm::colscan_kernel, dim3((p.nb + 255) / 256, p.W), dim3(256), 0, s, (u32*)c.msm_bh.ptr,
+                       (u32*)c.msm_tot.ptr, p.nb, p.ntiles);
+    hipLaunchKernelGGL(msm::binscan_kernel, dim3(p.W), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr,
+                       (u32*)c.msm_base.ptr, p.nb);
+    hipLaunchKernelGGL(msm::scatter_kernel, dim3(p.ntiles, p.W), dim3(msm::HIST_THREADS), lds, s,
+                       (const u32*)c.msm_dig.ptr, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr,
+                       (u32*)c.msm_sorted.ptr, (u64)n, p.nb, p.tile, p.ntiles);
+    {
+      ProfScope pa(c, PF_MSM_ACCUM);
+      hipLaunchKernelGGL(msm::accum_kernel, dim3((unsigned)((WB + 127) / 128)), dim3(128), 0, s, (const G1Affine*)d_bases,
+                         (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr,
+                         (G1Xyzz*)c.msm_buckets.ptr, (u64)n, p.nb, p.W);
+    }
+    hipLaunchKernelGGL(msm::reduce1_kernel, dim3((p.W * p.nseg + 63) / 64), dim3(64), 0, s,
+                       (const G1Xyzz*)c.msm_buckets.ptr, (G1Xyzz*)c.msm_seg.ptr, p.nb, p.nseg, p.W);
+    hipLaunchKernelGGL(msm::reduce2_kernel, dim3(p.W), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr,
+                       (G1Xyzz*)c.msm_win.ptr, p.nseg);
+    MH_HIP(hipGetLastError());
+  }
+  std::vector<uint64_t> win((size_t)p.W * 24);
+  MH_HIP(hipMemcpyAsync(win.data(), c.msm_win.ptr, win.size() * 8, hipMemcpyDeviceToHost, s));
+  MH_HIP(hipStreamSynchronize(s));
+  HG1 r = combine_windows(win, p.W, p.c);
+  memcpy(out_xyz, r.X.v, 48); memcpy(out_xyz + 6, r.Y.v, 48); memcpy(out_xyz + 12, r.Z.v, 48);
+  return MH_OK;
+}
+
+}  // namespace mh
+
+// =====================================================================================
+// extern "C"
+// =====================================================================================
+#define LOCKED_CTX()                                                 \
+  Context& c = ctx();                                                \
+  std::lock_guard<std::recursive_mutex> _lk(c.mu);                   \
+  if (!c.inited) return fail(MH_ENOINIT, "mh_init has not been called")
+
+extern "C" {
+
+const char* mh_last_error(void) { return g_err.c_str(); }
+
+int mh_init(int device_id) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (c.inited) {
+    if (c.device == device_id) return MH_OK;
+    return fail(MH_EINVAL, "mh_init: already initialised on another device (one process drives one GPU)");
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) return fail(MH_ENODEV, "no HIP device visible");
+  if (device_id < 0 || device_id >= count) return fail(MH_EINVAL, "mh_init: device id out of range");
+  MH_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  MH_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return fail(MH_ENODEV, std::string("device is not gfx950: ") + prop.gcnArchName);
+  MH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  c.own_stream = true;
+  c.device = device_id;
+  c.inited = true;
+  return MH_OK;
+}
+
+int mh_shutdown(void) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (!c.inited) return MH_OK;
+  (void)hipStreamSynchronize(c.stream);
+  if (c.tw) (void)hipFree(c.tw);
+  c.tw = nullptr; c.tw_log = 0;
+  c.ntt_tmp[0].release(); c.ntt_tmp[1].release(); c.io.release();
+  c.msm_dig.release(); c.msm_sorted.release(); c.msm_bh.release(); c.msm_tot.release(); c.msm_base.release();
+  c.msm_buckets.release(); c.msm_seg.release(); c.msm_win.release();
+  for (auto& kv : c.bases) if (kv.second.d_points) (void)hipFree(kv.second.d_points);
+  c.bases.clear();
+  for (auto& r : c.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  c.prof.clear();
+  for (auto e : c.ev_pool) (void)hipEventDestroy(e);
+  c.ev_pool.clear();
+  if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+  c.stream = nullptr; c.own_stream = false;
+  c.inited = false; c.device = -1;
+  return MH_OK;
+}
+
+int mh_set_stream(void* hip_stream) {
+  LOCKED_CTX();
+  MH_HIP(hipStreamSynchronize(c.stream));
+  if (hip_stream == nullptr) {
+    if (!c.own_stream) { MH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)); c.own_stream = true; }
+    return MH_OK;
+  }
+  if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+  c.stream = (hipStream_t)hip_stream;
+  c.own_stream = false;
+  return MH_OK;
+}
+
+int mh_synchronize(void) {
+  LOCKED_CTX();
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+
+int mh_device_info(char* name_out, size_t name_cap, int* cu_count, size_t* hbm_bytes) {
+  LOCKED_CTX();
+  hipDeviceProp_t prop;
+  MH_HIP(hipGetDeviceProperties(&prop, c.device));
+  if (name_out && name_cap) { snprintf(name_out, name_cap, "%s (%s)", prop.name, prop.gcnArchName); }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return MH_OK;
+}
+
+int mh_alloc(size_t bytes, void** dptr_out) {
+  LOCKED_CTX();
+  if (!dptr_out) return fail(MH_EINVAL, "mh_alloc: null out pointer");
+  *dptr_out = nullptr;
+  if (bytes == 0) return MH_OK;
+  MH_HIP(hipMalloc(dptr_out, bytes));
+  return MH_OK;
+}
+int mh_free(void* dptr) {
+  LOCKED_CTX();
+  if (!dptr) return MH_OK;
+  MH_HIP(hipStreamSynchronize(c.stream));
+  MH_HIP(hipFree(dptr));
+  return MH_OK;
+}
+int mh_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  LOCKED_CTX();
+  if (bytes == 0) return MH_OK;
+  MH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+int mh_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  LOCKED_CTX();
+  if (bytes == 0) return MH_OK;
+  MH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+int mh_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+  LOCKED_CTX();
+  if (bytes == 0) return MH_OK;
+  MH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c.stream));
+  return MH_OK;
+}
+int mh_memset(void* dst, int byte, size_t bytes) {
+  LOCKED_CTX();
+  if (bytes == 0) return MH_OK;
+  MH_HIP(hipMemsetAsync(dst, byte, bytes, c.stream));
+  return MH_OK;
+}
+
+int mh_ntt_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
+  LOCKED_CTX();
+  if (field != MH_FIELD_BLS12_381_FR) return fail(MH_EINVAL, "mh_ntt: unsupported field");
+  if (!d_in || !d_out) return fail(MH_EINVAL, "mh_ntt_dev: null pointer");
+  return ntt_device(c, d_in, d_out, log_n, inverse);
+}
+
+int mh_ntt(int field, uint64_t* data, uint32_t log_n, int inverse) {
+  LOCKED_CTX();
+  if (field != MH_FIELD_BLS12_381_FR) return fail(MH_EINVAL, "mh_ntt: unsupported field");
+  if (!data) return fail(MH_EINVAL, "mh_ntt: null pointer");
+  if (log_n > 32) return fail(MH_EINVAL, "log_n > two-adicity (32)");
+  size_t bytes = (size_t)32 << log_n;
+  MH_TRY(c.io.ensure(bytes));
+  MH_HIP(hipMemcpyAsync(c.io.ptr, data, bytes, hipMemcpyHostToDevice, c.stream));
+  MH_TRY(ntt_device(c, c.io.ptr, c.io.ptr, log_n, inverse));
+  MH_HIP(hipMemcpyAsync(data, c.io.ptr, bytes, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+
+int mh_bases_upload(int curve, const uint64_t* xy, size_t n, uint64_t* handle_out) {
+  LOCKED_CTX();
+  if (curve != MH_CURVE_BLS12_381_G1) return fail(MH_EINVAL, "unsupported curve");
+  if (!handle_out || (!xy && n)) return fail(MH_EINVAL, "mh_bases_upload: null pointer");
+  BaseSet b;
+  b.n = n;
+  if (n) {
+    MH_HIP(hipMalloc(&b.d_points, n * 96));
+    MH_HIP(hipMemcpyAsync(b.d_points, xy, n * 96, hipMemcpyHostToDevice, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));
+  }
+  uint64_t h = c.next_handle++;
+  c.bases[h] = b;
+  *handle_out = h;
+  return MH_OK;
+}
+
+int mh_bases_from_dev(int curve, const void* d_xy, size_t n, uint64_t* handle_out) {
+  LOCKED_CTX();
+  if (curve != MH_CURVE_BLS12_381_G1) return fail(MH_EINVAL, "unsupported curve");
+  if (!handle_out || (!d_xy && n)) return fail(MH_EINVAL, "mh_bases_from_dev: null pointer");
+  BaseSet b;
+  b.n = n;
+  if (n) {
+    MH_HIP(hipMalloc(&b.d_points, n * 96));
+    MH_HIP(hipMemcpyAsync(b.d_points, d_xy, n * 96, hipMemcpyDeviceToDevice, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));
+  }
+  uint64_t h = c.next_handle++;
+  c.bases[h] = b;
+  *handle_out = h;
+  return MH_OK;
+}
+
+int mh_bases_free(uint64_t handle) {
+  LOCKED_CTX();
+  auto it = c.bases.find(handle);
+  if (it == c.bases.end()) return fail(MH_EINVAL, "mh_bases_free: unknown handle");
+  MH_HIP(hipStreamSynchronize(c.stream));
+  if (it->second.d_points) (void)hipFree(it->second.d_points);
+  c.bases.erase(it);
+  return MH_OK;
+}
+
+int mh_bases_len(uint64_t handle, size_t* n_out) {
+  LOCKED_CTX();
+  auto it = c.bases.find(handle);
+  if (it == c.bases.end()) return fail(MH_EINVAL, "mh_bases_len: unknown handle");
+  if (n_out) *n_out = it->second.n;
+  return MH_OK;
+}
+
+int mh_msm_dev(uint64_t handle, size_t base_offset, const void* d_scalars, int is_mont, size_t n, uint64_t* out_xyz) {
+  LOCKED_CTX();
+  if (!out_xyz) return fail(MH_EINVAL, "mh_msm: null output");
+  auto it = c.bases.find(handle);
+  if (it == c.bases.end()) return fail(MH_EINVAL, "mh_msm: unknown bases handle");
+  if (base_offset > it->second.n || n > it->second.n - base_offset)
+    return fail(MH_EINVAL, "mh_msm: base_offset + n exceeds the uploaded base set");
+  if (n && !d_scalars) return fail(MH_EINVAL, "mh_msm: null scalars");
+  return msm_device(c, (const char*)it->second.d_points + base_offset * 96, d_scalars, is_mont, n, out_xyz);
+}
+
+int mh_msm(uint64_t handle, size_t base_offset, const uint64_t* scalars, int is_mont, size_t n, uint64_t* out_xyz) {
+  LOCKED_CTX();
+  if (n && !scalars) return fail(MH_EINVAL, "mh_msm: null scalars");
+  MH_TRY(c.io.ensure(n * 32));
+  if (n) MH_HIP(hipMemcpyAsync(c.io.ptr, scalars, n * 32, hipMemcpyHostToDevice, c.stream));
+  return mh_msm_dev(handle, base_offset, c.io.ptr, is_mont, n, out_xyz);
+}
+
+int mh_g1_to_affine(const uint64_t* xyz, uint64_t* xy_out, int* inf_out) {
+  if (!xyz || !xy_out) return fail(MH_EINVAL, "mh_g1_to_affine: null pointer");
+  HG1 p;
+  memcpy(p.X.v, xyz, 48); memcpy(p.Y.v, xyz + 6, 48); memcpy(p.Z.v, xyz + 12, 48);
+  HG1Affine a = p.to_affine();
+  if (a.inf) { a.x = HFq::zero(); a.y = HFq::one(); }   // arkworks GroupAffine::zero() = (0, 1, true)
+  memcpy(xy_out, a.x.v, 48); memcpy(xy_out + 6, a.y.v, 48);
+  if (inf_out) *inf_out = a.inf ? 1 : 0;
+  return MH_OK;
+}
+
+int mh_prof_enable(int on) {
+  LOCKED_CTX();
+  c.prof_on = on != 0;
+  return MH_OK;
+}
+static int prof_drain(Context& c) {
+  if (c.prof.empty()) return MH_OK;
+  MH_HIP(hipStreamSynchronize(c.stream));
+  for (auto& r : c.prof) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c.prof_ms[r.family] += ms; c.prof_n[r.family]++; }
+    c.ev_pool.push_back(r.a); c.ev_pool.push_back(r.b);
+  }
+  c.prof.clear();
+  return MH_OK;
+}
+int mh_prof_reset(void) {
+  LOCKED_CTX();
+  MH_TRY(prof_drain(c));
+  for (int i = 0; i < PF_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; }
+  return MH_OK;
+}
+int mh_prof_get(int family, double* total_ms_out, uint64_t* launches_out) {
+  LOCKED_CTX();
+  if (family < 0 || family >= PF_COUNT) return fail(MH_EINVAL, "mh_prof_get: bad family");
+  MH_TRY(prof_drain(c));
+  if (total_ms_out) *total_ms_out = c.prof_ms[family];
+  if (launches_out) *launches_out = c.prof_n[family];
+  return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// Process-wide device context of libmarlin_hip.so: one GPU, one stream, cached
+// twiddle table, scratch buffers, uploaded base sets, HIP-event profiling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/marlin_hip.h"
+
+namespace mh {
+
+extern thread_local std::string g_err;
+
+inline int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define MH_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (call);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      char _b[512];                                                                       \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return mh::fail(_e == hipErrorOutOfMemory ? MH_ENOMEM : MH_EHIP, _b);               \
+    }                                                                                     \
+  } while (0)
+
+#define MH_TRY(expr)          \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != MH_OK) return _r; \
+  } while (0)
+
+struct Scratch {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return MH_OK;
+    if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e != hipSuccess) {
+      e = hipMalloc(&ptr, bytes);
+      want = bytes;
+      if (e != hipSuccess) { ptr = nullptr; return fail(MH_ENOMEM, "hipMalloc scratch failed"); }
+    }
+    cap = want;
+    return MH_OK;
+  }
+  void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+struct BaseSet {
+  void* d_points = nullptr;  // G1Affine[n]
+  size_t n = 0;
+};
+
+enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_COUNT = 4 };
+
+struct ProfRec { int family; hipEvent_t a, b; };
+
+struct Context {
+  bool inited = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::recursive_mutex mu;
+
+  // NTT
+  void* tw = nullptr;        // Fr[2^tw_log]
+  uint32_t tw_log = 0;
+  Scratch ntt_tmp[2];
+  Scratch io;                // staging for host-pointer entry points
+
+  // MSM
+  std::map<uint64_t, BaseSet> bases;
+  uint64_t next_handle = 1;
+  Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win;
+
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  double prof_ms[PF_COUNT] = {0, 0, 0, 0};
+  uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0};
+};
+
+Context& ctx();
+
+struct ProfScope {
+  Context& c;
+  int fam;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(Context& c_, int fam_) : c(c_), fam(fam_) {
+    if (!c.prof_on) return;
+    auto get = [&]() { hipEvent_t e; if (!c.ev_pool.empty()) { e = c.ev_pool.back(); c.ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
+    a = get(); b = get();
+    (void)hipEventRecord(a, c.stream);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, c.stream);
+    c.prof.push_back({fam, a, b});
+  }
+};
+
+}  // namespace mh

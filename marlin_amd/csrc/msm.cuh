@@ -1,0 +1,247 @@
+// Pippenger multi-scalar multiplication over BLS12-381 G1 for gfx950.
+//
+// Computes what the reference obtains from ark-ec 0.3
+// `VariableBaseMSM::multi_scalar_mul(bases, scalars)` -- reached only through
+// ark-poly-commit's KZG10 commit/open, which the reference calls at
+// /root/reference src/lib.rs:125,172,193,213 (PC::commit) and src/lib.rs:292
+// (PC::open_combinations); SURVEY.md §8 a7-a9 / Appendix A.  The result is a
+// unique group element, so window size, digit signedness and bucket coordinates
+// are free design choices; they are chosen for CDNA4, not
+// copied from arkworks (which uses unsigned c-bit windows, Jacobian buckets and
+// one rayon task per window).
+//
+// Pipeline (all on one stream, no host synchronisation until the W window sums
+// are copied back):
+//   1. digits   : Montgomery -> canonical scalar, signed base-2^c recoding;
+//                 one u32 entry (bucket+1 | sign<<31, 0 = skip) per (window, scalar)
+//   2. hist     : per (window, tile) LDS-privatised histogram of bucket ids
+//   3. colscan  : per (window, bucket) exclusive prefix over tiles + bucket totals
+//   4. binscan  : per window exclusive scan over buckets -> bucket start offsets
+//   5. scatter  : per (window, tile) LDS-atomic local rank -> point-index lists
+//                 grouped by bucket (counting sort; no global atomics anywhere)
+//   6. accum    : one thread per (window, bucket): XYZZ += affine base (8M+2S)
+//   7. reduce1  : per (window, segment of S buckets): running-sum trick inside
+//                 the segment + (segment offset) * (segment total) by double-and-add
+//   8. reduce2  : per window: tree-sum of the segment results
+// The host combines the W window sums (Horner with c doublings each) and
+// normalises to affine (host_ec.h).
+#pragma once
+#include "g1.cuh"
+
+namespace msm {
+
+constexpr int HIST_THREADS = 1024;
+constexpr int SEG = 16;  // buckets per reduce1 segment
+
+struct Plan {
+  u32 c;        // window bits
+  u32 W;        // windows (W*c >= 256)
+  u32 nb;       // buckets per window = 2^(c-1)
+  u32 tile;     // entries per hist/scatter tile
+  u32 ntiles;   // tiles per window
+  u32 nseg;     // segments per window
+};
+
+inline Plan make_plan(u64 n) {
+  Plan p;
+  u32 lg = 0;
+  while ((1ull << lg) < n) lg++;
+  // average bucket load ~2^(lg-(c-1)); keep it >= ~64 for large n, LDS histogram caps c at 16
+  int c = (int)lg - 5;
+  if (c > 16) c = 16;
+  if (c < 4) c = 4;
+  p.c = (u32)c;
+  p.W = (256 + c - 1) / c;
+  p.nb = 1u << (c - 1);
+  u64 t = (n * p.W + 1023) / 1024;       // aim for ~1024 tiles in total
+  if (t < 4096) t = 4096;
+  if (t > 65536) t = 65536;
+  p.tile = (u32)t;
+  p.ntiles = (u32)((n + p.tile - 1) / p.tile);
+  p.nseg = (p.nb + SEG - 1) / SEG;
+  return p;
+}
+
+// ---- 1. digits -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void digits_kernel(const Fr* __restrict__ scalars, u32* __restrict__ dig,
+                                                     u64 n, u32 c, u32 W, int is_mont) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s = ff_load(scalars + i);
+  if (is_mont) s = ff_from_mont(s);
+  const u32 half = 1u << (c - 1);
+  const u32 mask = (1u << c) - 1;
+  u32 carry = 0;
+  for (u32 w = 0; w < W; w++) {
+    u32 bit = w * c;
+    u32 limb = bit >> 5, sh = bit & 31;
+    u32 raw = 0;
+    if (limb < 8) {
+      u64 two = s.v[limb];
+      if (limb + 1 < 8) two |= (u64)s.v[limb + 1] << 32;
+      raw = (u32)(two >> sh) & mask;
+    }
+    raw += carry;
+    u32 e;
+    if (raw > half) { e = ((1u << c) - raw) | 0x80000000u; carry = 1; }
+    else { e = raw; carry = 0; }           // raw == 0 -> skip entry
+    dig[(u64)w * n + i] = e;
+  }
+}
+
+// ---- 2. hist ---------------------------------------------------------------------
+// grid (ntiles, W); LDS: nb u32 counters
+__global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const u32* __restrict__ dig, u32* __restrict__ bh,
+                                                            u64 n, u32 nb, u32 tile, u32 ntiles) {
+  extern __shared__ __attribute__((aligned(16))) u32 h[];
+  const u32 w = blockIdx.y, tb = blockIdx.x;
+  for (u32 b = threadIdx.x; b < nb; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  const u64 lo = (u64)tb * tile;
+  u64 hi = lo + tile; if (hi > n) hi = n;
+  const u32* d = dig + (u64)w * n;
+  for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u32 e = d[i] & 0x7fffffffu;
+    if (e) atomicAdd(&h[e - 1], 1u);
+  }
+  __syncthreads();
+  u32* out = bh + ((u64)w * ntiles + tb) * nb;
+  for (u32 b = threadIdx.x; b < nb; b += blockDim.x) out[b] = h[b];
+}
+
+// ---- 3. colscan: thread per (w, bucket): exclusive prefix over tiles ----------
+__global__ __launch_bounds__(256) void colscan_kernel(u32* __restrict__ bh, u32* __restrict__ tot, u32 nb,
+                                                      u32 ntiles) {
+  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 w = blockIdx.y;
+  if (b >= nb) return;
+  u32 run = 0;
+  u32* p = bh + (u64)w * ntiles * nb + b;
+  for (u32 t = 0; t < ntiles; t++) {
+    u32 v = p[(u64)t * nb];
+    p[(u64)t * nb] = run;
+    run += v;
+  }
+  tot[(u64)w * nb + b] = run;
+}
+
+// ---- 4. binscan: block per window: exclusive scan of tot -> base -----------------
+__global__ __launch_bounds__(1024) void binscan_kernel(const u32* __restrict__ tot, u32* __restrict__ base, u32 nb) {
+  __shared__ u32 part[1024];
+  const u32 w = blockIdx.x;
+  const u32 per = (nb + 1023) / 1024;
+  const u32 lo = threadIdx.x * per;
+  u32 s = 0;
+  for (u32 k = 0; k < per; k++) { u32 b = lo + k; if (b < nb) s += tot[(u64)w * nb + b]; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 partials
+  for (u32 off = 1; off < 1024; off <<= 1) {
+    u32 v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  u32 run = part[threadIdx.x] - s;
+  for (u32 k = 0; k < per; k++) {
+    u32 b = lo + k;
+    if (b < nb) { base[(u64)w * nb + b] = run; run += tot[(u64)w * nb + b]; }
+  }
+}
+
+// ---- 5. scatter -------------------------------------------------------------------
+__global__ __launch_bounds__(HIST_THREADS) void scatter_kernel(const u32* __restrict__ dig, const u32* __restrict__ bh,
+                                                               const u32* __restrict__ base, u32* __restrict__ sorted,
+                                                               u64 n, u32 nb, u32 tile, u32 ntiles) {
+  extern __shared__ __attribute__((aligned(16))) u32 h[];
+  const u32 w = blockIdx.y, tb = blockIdx.x;
+  const u32* pre = bh + ((u64)w * ntiles + tb) * nb;
+  const u32* bs = base + (u64)w * nb;
+  for (u32 b = threadIdx.x; b < nb; b += blockDim.x) h[b] = bs[b] + pre[b];
+  __syncthreads();
+  const u64 lo = (u64)tb * tile;
+  u64 hi = lo + tile; if (hi > n) hi = n;
+  const u32* d = dig + (u64)w * n;
+  u32* out = sorted + (u64)w * n;
+  for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u32 e = d[i];
+    u32 b = e & 0x7fffffffu;
+    if (b) {
+      u32 pos = atomicAdd(&h[b - 1], 1u);
+      out[pos] = (u32)i | (e & 0x80000000u);
+    }
+  }
+}
+
+// ---- 6. accum: thread per (window, bucket) ------------------------------------------
+__global__ __launch_bounds__(128) void accum_kernel(const G1Affine* __restrict__ bases, const u32* __restrict__ sorted,
+                                                    const u32* __restrict__ base, const u32* __restrict__ tot,
+                                                    G1Xyzz* __restrict__ buckets, u64 n, u32 nb, u32 W) {
+  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (u64)W * nb) return;
+  u32 w = (u32)(gid / nb);
+  const u32* lst = sorted + (u64)w * n + base[gid];
+  u32 cnt = tot[gid];
+  G1Xyzz acc = G1Xyzz::identity();
+  for (u32 k = 0; k < cnt; k++) {
+    u32 e = lst[k];
+    G1Affine p = g1_load_affine(bases + (e & 0x7fffffffu));
+    if (e & 0x80000000u) p.y = ff_neg(p.y);
+    g1_madd(acc, p.x, p.y);
+  }
+  g1_store_xyzz(buckets + gid, acc);
+}
+
+// ---- 7. reduce1: thread per (window, segment) ----------------------------------------
+__global__ __launch_bounds__(64) void reduce1_kernel(const G1Xyzz* __restrict__ buckets, G1Xyzz* __restrict__ segsum,
+                                                     u32 nb, u32 nseg, u32 W) {
+  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= W * nseg) return;
+  u32 w = gid / nseg, s = gid % nseg;
+  u32 lo = s * SEG;
+  u32 hi = lo + SEG; if (hi > nb) hi = nb;
+  G1Xyzz running = G1Xyzz::identity(), acc = G1Xyzz::identity();
+  const G1Xyzz* B = buckets + (u64)w * nb;
+  for (u32 b = hi; b-- > lo;) {
+    G1Xyzz t = g1_load_xyzz(B + b);
+    g1_add(running, t);
+    g1_add(acc, running);
+  }
+  // + lo * running   (lo = number of buckets below this segment)
+  if (lo) {
+    G1Xyzz m = G1Xyzz::identity();
+    int top = 31 - __clz(lo);
+    for (int bit = top; bit >= 0; bit--) {
+      g1_dbl(m);
+      if ((lo >> bit) & 1) g1_add(m, running);
+    }
+    g1_add(acc, m);
+  }
+  g1_store_xyzz(segsum + gid, acc);
+}
+
+// ---- 8. reduce2: block per window -----------------------------------------------------
+__global__ __launch_bounds__(256) void reduce2_kernel(const G1Xyzz* __restrict__ segsum, G1Xyzz* __restrict__ winsum,
+                                                      u32 nseg) {
+  __shared__ G1Xyzz sh[256];
+  const u32 w = blockIdx.x;
+  G1Xyzz acc = G1Xyzz::identity();
+  for (u32 s = threadIdx.x; s < nseg; s += 256) {
+    G1Xyzz t = g1_load_xyzz(segsum + (u64)w * nseg + s);
+    g1_add(acc, t);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (u32 off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      G1Xyzz a = sh[threadIdx.x];
+      G1Xyzz b = sh[threadIdx.x + off];
+      g1_add(a, b);
+      sh[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) g1_store_xyzz(winsum + w, sh[0]);
+}
+
+}  // namespace msm

@@ -1,0 +1,100 @@
+"""Parity of the HIP Pippenger MSM (through the C ABI) against the oracle.
+Bit-exact after affine normalisation (the form the reference serialises/hashes)."""
+import numpy as np
+import pytest
+from oracle import fields as F
+from oracle import curve as EC
+from tests.util import fr_to_np, points_to_np, jac_np_to_affine, arith_bases, rand_fr, limbs_to_fq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bases4k():
+    pts, dl = arith_bases(4096)
+    return pts, dl
+
+
+def _check_dlog(gpu, B, pts, dl, scalars, offset=0, montgomery=True):
+    n = len(scalars)
+    out = gpu.msm(B, fr_to_np(scalars, montgomery=montgomery), base_offset=offset, montgomery=montgomery)
+    got = jac_np_to_affine(out)
+    k = sum(s * a for s, a in zip(scalars, dl[offset:offset + n])) % F.R_MOD
+    want = EC.scalar_mul(EC.G1_GEN, k)
+    assert got == want
+    assert EC.is_on_curve(got)
+    # host normalisation helper agrees with the oracle's
+    xy, inf = gpu.g1_to_affine(out)
+    if want is None:
+        assert inf
+    else:
+        assert not inf and (limbs_to_fq(xy[:6]), limbs_to_fq(xy[6:])) == want
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 31, 32, 33, 100, 257])
+def test_msm_small_vs_naive(gpu, bases4k, n):
+    pts, dl = bases4k
+    B = gpu.Bases(points_to_np(pts[:n]))
+    sc = rand_fr(n, n)
+    out = gpu.msm(B, fr_to_np(sc))
+    assert jac_np_to_affine(out) == EC.msm_naive(pts[:n], sc)
+    if n <= 100:
+        assert jac_np_to_affine(out) == EC.msm_pippenger(pts[:n], sc)
+
+
+@pytest.mark.parametrize("n", [1000, 4096])
+def test_msm_known_dlog(gpu, bases4k, n):
+    pts, dl = bases4k
+    B = gpu.Bases(points_to_np(pts[:n]))
+    _check_dlog(gpu, B, pts, dl, rand_fr(n, 77 + n))
+
+
+def test_msm_offsets_and_canonical_scalars(gpu, bases4k):
+    pts, dl = bases4k
+    B = gpu.Bases(points_to_np(pts))
+    _check_dlog(gpu, B, pts, dl, rand_fr(700, 5), offset=1234)
+    _check_dlog(gpu, B, pts, dl, rand_fr(300, 6), offset=3796)          # ends exactly at the last base
+    _check_dlog(gpu, B, pts, dl, rand_fr(513, 8), offset=11, montgomery=False)
+
+
+def test_msm_edge_scalars(gpu, bases4k):
+    pts, dl = bases4k
+    n = 600
+    B = gpu.Bases(points_to_np(pts[:n]))
+    r = F.R_MOD
+    _check_dlog(gpu, B, pts, dl, [0] * n)                      # identity result
+    _check_dlog(gpu, B, pts, dl, [1] * n)
+    _check_dlog(gpu, B, pts, dl, [r - 1] * n)
+    _check_dlog(gpu, B, pts, dl, [0] * (n - 1) + [5])
+    _check_dlog(gpu, B, pts, dl, [(1 << 254) + 12345] * n)     # high bit set: top-window carry
+    _check_dlog(gpu, B, pts, dl, [2 ** 15] * n)                # digit exactly half a window
+    _check_dlog(gpu, B, pts, dl, [2 ** 16 - 1] * n)
+    # scalars that cancel: s*P + (r-s)*P = O
+    sc = rand_fr(n // 2, 3)
+    B2 = gpu.Bases(points_to_np([p for p in pts[:n // 2] for _ in (0, 1)]))
+    out = gpu.msm(B2, fr_to_np([v for s in sc for v in (s, r - s)]))
+    assert jac_np_to_affine(out) is None
+
+
+def test_msm_repeated_base(gpu, bases4k):
+    """every base identical: every bucket addition after the first hits the doubling branch."""
+    pts, dl = bases4k
+    n = 500
+    B = gpu.Bases(points_to_np([pts[7]] * n))
+    sc = rand_fr(n, 21)
+    out = gpu.msm(B, fr_to_np(sc))
+    assert jac_np_to_affine(out) == EC.scalar_mul(pts[7], sum(sc) % F.R_MOD)
+    # equal scalars too: one bucket per window holds all n points
+    out = gpu.msm(B, fr_to_np([sc[0]] * n))
+    assert jac_np_to_affine(out) == EC.scalar_mul(pts[7], sc[0] * n % F.R_MOD)
+
+
+def test_msm_empty_and_errors(gpu, bases4k):
+    pts, dl = bases4k
+    B = gpu.Bases(points_to_np(pts[:8]))
+    out = gpu.msm(B, np.zeros((0, 4), dtype=np.uint64))
+    assert jac_np_to_affine(out) is None
+    with pytest.raises(gpu.MarlinHipError):
+        gpu.msm(B, fr_to_np([1] * 9))                      # more scalars than bases
+    with pytest.raises(gpu.MarlinHipError):
+        gpu.msm(B, fr_to_np([1] * 4), base_offset=6)

@@ -1,0 +1,142 @@
+// Instruction-rate and field-multiplication microbenchmarks for gfx950.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I marlin_amd/csrc tools/microbench.hip -o tools/microbench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+#include "ff.cuh"
+#include "g1.cuh"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int ITERS = 2048;
+
+__global__ void k_mad64(u64* out, u32 a, u32 b) {
+  u64 acc[8]; for (int i = 0; i < 8; i++) acc[i] = threadIdx.x + i;
+  u32 x = a + threadIdx.x, y = b;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y) : "vcc");
+  }
+  u64 s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_mullo(u64* out, u32 a, u32 b) {
+  u32 acc[8]; for (int i = 0; i < 8; i++) acc[i] = threadIdx.x + i + a;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(acc[i]) : "v"(b));
+  }
+  u64 s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_mulhi(u64* out, u32 a, u32 b) {
+  u32 acc[8]; for (int i = 0; i < 8; i++) acc[i] = threadIdx.x + i + a;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(acc[i]) : "v"(b));
+  }
+  u64 s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_addc(u64* out, u32 a, u32 b) {
+  u32 acc[8]; for (int i = 0; i < 8; i++) acc[i] = threadIdx.x + i + a;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) asm volatile("v_addc_co_u32 %0, vcc, %1, %0, vcc" : "+v"(acc[i]) : "v"(b) : "vcc");
+  }
+  u64 s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_mad24(u64* out, u32 a, u32 b) {
+  u32 acc[8]; for (int i = 0; i < 8; i++) acc[i] = threadIdx.x + i + a;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(acc[i]) : "v"(b));
+  }
+  u64 s = 0; for (int i = 0; i < 8; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_madpair(u64* out, u32 a, u32 b) {   // mad + addc pairs as in the Comba column
+  u64 acc[4]; u32 hi[4]; for (int i = 0; i < 4; i++) { acc[i] = threadIdx.x + i; hi[i] = 0; }
+  u32 x = a + threadIdx.x, y = b;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %3, %2, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+                   : "+v"(acc[i]), "+v"(hi[i]) : "v"(x), "v"(y) : "vcc");
+  }
+  u64 s = 0; for (int i = 0; i < 4; i++) s += acc[i] + hi[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <class F>
+__global__ void k_ffmul(F* out, const F* in, int iters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  F x = ff_load(in + tid), y = ff_load(in + tid + 1);
+  for (int it = 0; it < iters; it++) { F z = ff_mul(x, y); y = x; x = z; }
+  ff_store(out + tid, x);
+}
+template <class F>
+__global__ void k_ffadd(F* out, const F* in, int iters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  F x = ff_load(in + tid), y = ff_load(in + tid + 1);
+  for (int it = 0; it < iters; it++) { F z = ff_add(x, y); y = ff_sub(x, z); x = z; }
+  ff_store(out + tid, x);
+}
+__global__ void k_madd(G1Xyzz* out, const Fq* in, int iters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  G1Xyzz acc; acc.x = ff_load(in + tid); acc.y = ff_load(in + tid + 1); acc.zz = ff_load(in + tid + 2); acc.zzz = ff_load(in + tid + 3);
+  Fq px = ff_load(in + tid + 4), py = ff_load(in + tid + 5);
+  for (int it = 0; it < iters; it++) { g1_madd(acc, px, py); px = ff_add(px, py); }
+  g1_store_xyzz(out + tid, acc);
+}
+
+template <class K, class... A>
+double timeit(K k, dim3 g, dim3 b, int reps, A... args) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k, g, b, 0, 0, args...);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k, g, b, 0, 0, args...);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+
+int main() {
+  hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+  printf("device %s %s CUs=%d clock=%d kHz\n", p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate);
+  const int blocks = p.multiProcessorCount * 8, threads = 256;
+  const size_t nthreads = (size_t)blocks * threads;
+  u64* out; CK(hipMalloc(&out, nthreads * 8 + 4096));
+  double lanes_ops;
+  double ms;
+  ms = timeit(k_mad64, dim3(blocks), dim3(threads), 5, out, 3u, 5u); lanes_ops = (double)nthreads * ITERS * 8;
+  printf("v_mad_u64_u32      : %8.3f ms  %8.2f Tops/s (lane-ops)\n", ms, lanes_ops / ms / 1e9);
+  ms = timeit(k_mullo, dim3(blocks), dim3(threads), 5, out, 3u, 5u);
+  printf("v_mul_lo_u32       : %8.3f ms  %8.2f Tops/s\n", ms, lanes_ops / ms / 1e9);
+  ms = timeit(k_mulhi, dim3(blocks), dim3(threads), 5, out, 3u, 5u);
+  printf("v_mul_hi_u32       : %8.3f ms  %8.2f Tops/s\n", ms, lanes_ops / ms / 1e9);
+  ms = timeit(k_addc, dim3(blocks), dim3(threads), 5, out, 3u, 5u);
+  printf("v_addc_co_u32      : %8.3f ms  %8.2f Tops/s\n", ms, lanes_ops / ms / 1e9);
+  ms = timeit(k_mad24, dim3(blocks), dim3(threads), 5, out, 3u, 5u);
+  printf("v_mad_u32_u24      : %8.3f ms  %8.2f Tops/s\n", ms, lanes_ops / ms / 1e9);
+  ms = timeit(k_madpair, dim3(blocks), dim3(threads), 5, out, 3u, 5u);
+  printf("mad+addc pair      : %8.3f ms  %8.2f Tpairs/s\n", ms, lanes_ops / ms / 1e9);
+
+  // field ops
+  std::vector<u32> h((nthreads + 8) * 12);
+  for (size_t i = 0; i < h.size(); i++) h[i] = (u32)(i * 2654435761u) & 0x0fffffffu;
+  void *din, *dout; CK(hipMalloc(&din, h.size() * 4)); CK(hipMalloc(&dout, (nthreads + 8) * 192));
+  CK(hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  int it = 512;
+  ms = timeit(k_ffmul<Fr>, dim3(blocks), dim3(threads), 3, (Fr*)dout, (const Fr*)din, it);
+  printf("Fr mont mul (8 limb) : %8.3f ms  %8.2f Gmul/s\n", ms, (double)nthreads * it / ms / 1e6);
+  ms = timeit(k_ffmul<Fq>, dim3(blocks), dim3(threads), 3, (Fq*)dout, (const Fq*)din, it);
+  printf("Fq mont mul (12 limb): %8.3f ms  %8.2f Gmul/s\n", ms, (double)nthreads * it / ms / 1e6);
+  ms = timeit(k_ffadd<Fq>, dim3(blocks), dim3(threads), 3, (Fq*)dout, (const Fq*)din, it);
+  printf("Fq add+sub           : %8.3f ms  %8.2f Gpair/s\n", ms, (double)nthreads * it / ms / 1e6);
+  it = 64;
+  ms = timeit(k_madd, dim3(blocks), dim3(128), 3, (G1Xyzz*)dout, (const Fq*)din, it);
+  printf("G1 XYZZ madd         : %8.3f ms  %8.2f Gadd/s\n", ms, (double)blocks * 128 * it / ms / 1e6);
+  return 0;
+}
