@@ -5,6 +5,8 @@ from . import _lib
 
 FIELD_FR = 0
 CURVE_G1 = 0
+# 2^256 mod r: the Montgomery representation of 1 in Fr
+FR_ONE_MONT = np.array([0x00000001fffffffe, 0x5884b7fa00034802, 0x998c4fefecbc4ff5, 0x1824b159acc5056f], dtype=np.uint64)
 
 
 def _L():
@@ -112,6 +114,27 @@ class Bases:
         _lib.check(_L().mh_bases_upload(CURVE_G1, a.ctypes.data, a.shape[0], C.byref(h)), "mh_bases_upload")
         self.handle = h.value
         self.n = a.shape[0]
+
+    @classmethod
+    def srs_powers(cls, tau_mont, n, scale_mont=None):
+        """[scale * tau^i]G for i < n, generated on the device (KZG10::setup's powers_of_g).
+        tau_mont / scale_mont: (4,) uint64 Montgomery Fr; scale defaults to one."""
+        tau = np.ascontiguousarray(tau_mont, dtype=np.uint64).reshape(4)
+        if scale_mont is None:
+            scale_mont = FR_ONE_MONT
+        sc = np.ascontiguousarray(scale_mont, dtype=np.uint64).reshape(4)
+        h = C.c_uint64()
+        _lib.check(_L().mh_srs_powers(CURVE_G1, tau.ctypes.data, sc.ctypes.data, int(n), C.byref(h)), "mh_srs_powers")
+        self = cls.__new__(cls)
+        self.handle = h.value
+        self.n = int(n)
+        return self
+
+    def download(self, offset=0, n=None):
+        n = self.n - offset if n is None else n
+        out = np.zeros((n, 12), dtype=np.uint64)
+        _lib.check(_L().mh_bases_download(self.handle, int(offset), int(n), out.ctypes.data), "mh_bases_download")
+        return out
 
     def free(self):
         if self.handle:

@@ -5,6 +5,7 @@
 #include "g1.cuh"
 #include "msm.cuh"
 #include "ntt.cuh"
+#include "srs.cuh"
 #include "host_ff.h"
 
 using namespace mh;
@@ -134,10 +135,11 @@ static int msm_set_attrs() {
 }
 
 // window sums (device XYZZ) -> one Jacobian point on the host
-static HG1 combine_windows(const std::vector<uint64_t>& win, uint32_t W, uint32_t c) {
+static HG1 combine_windows(const std::vector<uint64_t>& win, const msm::Plan& pl) {
   HG1 acc = HG1::identity();
-  for (int w = (int)W - 1; w >= 0; w--) {
-    for (uint32_t k = 0; k < c; k++) acc = acc.dbl();
+  for (int w = (int)pl.W - 1; w >= 0; w--) {
+    // acc holds sum_{w' > w} 2^(start[w'] - start[w+1]) * S_w'; shift by the width of window w
+    for (uint32_t k = 0; k < pl.win.bits[w]; k++) acc = acc.dbl();
     const uint64_t* p = win.data() + (size_t)w * 24;
     HFq X, Y, ZZ, ZZZ;
     memcpy(X.v, p, 48); memcpy(Y.v, p + 6, 48); memcpy(ZZ.v, p + 12, 48); memcpy(ZZZ.v, p + 18, 48);
@@ -169,7 +171,7 @@ int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mo
   {
     ProfScope ps(c, PF_MSM);
     hipLaunchKernelGGL(msm::digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const Fr*)d_scalars,
-                       (u32*)c.msm_dig.ptr, (u64)n, p.c, p.W, is_mont);
+                       (u32*)c.msm_dig.ptr, (u64)n, p.W, p.win, is_mont);
     size_t lds = (size_t)p.nb * 4;
     hipLaunchKernelGGL(msm::hist_kernel, dim3(p.ntiles, p.W), dim3(msm::HIST_THREADS), lds, s, (const u32*)c.msm_dig.ptr,
                        (u32*)c.msm_bh.ptr, (u64)n, p.nb, p.tile, p.ntiles);
@@ -195,8 +197,63 @@ int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mo
   std::vector<uint64_t> win((size_t)p.W * 24);
   MH_HIP(hipMemcpyAsync(win.data(), c.msm_win.ptr, win.size() * 8, hipMemcpyDeviceToHost, s));
   MH_HIP(hipStreamSynchronize(s));
-  HG1 r = combine_windows(win, p.W, p.c);
+  HG1 r = combine_windows(win, p);
   memcpy(out_xyz, r.X.v, 48); memcpy(out_xyz + 6, r.Y.v, 48); memcpy(out_xyz + 12, r.Z.v, 48);
+  return MH_OK;
+}
+
+// --------------------------------------------------------------------------------
+// SRS generation (KZG10::setup's powers, known-tau test SRS)
+// --------------------------------------------------------------------------------
+static void* g_srs_table = nullptr;   // G1Affine[32][256]
+static int ensure_srs_table(Context& c) {
+  if (g_srs_table) return MH_OK;
+  // T[w][d] = [d * 256^w] G on the host, batch-normalised
+  static const uint64_t gx[6] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull,
+                                 0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull};
+  static const uint64_t gy[6] = {0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull,
+                                 0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+  HG1Affine g; g.x = HFq::from_canonical(gx); g.y = HFq::from_canonical(gy); g.inf = false;
+  const int NW = srs::WINDOWS, NT = srs::TABLE;
+  std::vector<HG1> jac((size_t)NW * NT);
+  HG1 base = HG1::from_affine(g);
+  for (int w = 0; w < NW; w++) {
+    jac[(size_t)w * NT] = HG1::identity();
+    HG1 acc = HG1::identity();
+    for (int d = 1; d < NT; d++) { acc = acc.add(base); jac[(size_t)w * NT + d] = acc; }
+    base = acc.add(base);                      // 256 * base
+  }
+  // batch inversion of Z (skip identities)
+  std::vector<HFq> prod(jac.size());
+  HFq run = HFq::one();
+  for (size_t i = 0; i < jac.size(); i++) { if (!jac[i].is_identity()) run = run * jac[i].Z; prod[i] = run; }
+  HFq inv = run.inv();
+  std::vector<uint64_t> host(jac.size() * 12, 0);
+  for (size_t i = jac.size(); i-- > 0;) {
+    if (jac[i].is_identity()) continue;
+    HFq prev = HFq::one();
+    for (size_t k = i; k-- > 0;) { if (!jac[k].is_identity()) { prev = prod[k]; break; } }
+    HFq zi = inv * prev;
+    inv = inv * jac[i].Z;
+    HFq zi2 = zi.sqr();
+    HFq x = jac[i].X * zi2, y = jac[i].Y * zi2 * zi;
+    memcpy(&host[i * 12], x.v, 48); memcpy(&host[i * 12 + 6], y.v, 48);
+  }
+  MH_HIP(hipMalloc(&g_srs_table, host.size() * 8));
+  MH_HIP(hipMemcpyAsync(g_srs_table, host.data(), host.size() * 8, hipMemcpyHostToDevice, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+
+int srs_powers_device(Context& c, const uint64_t* tau_mont, const uint64_t* scale_mont, size_t n, size_t first,
+                      void* d_out) {
+  MH_TRY(ensure_srs_table(c));
+  Fr tau, scale;
+  memcpy(tau.v, tau_mont, 32); memcpy(scale.v, scale_mont, 32);
+  if (n == 0) return MH_OK;
+  hipLaunchKernelGGL(srs::powers_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c.stream, (G1Affine*)d_out,
+                     (const G1Affine*)g_srs_table, tau, scale, (u64)n, (u64)first);
+  MH_HIP(hipGetLastError());
   return MH_OK;
 }
 
@@ -249,6 +306,7 @@ int mh_shutdown(void) {
   c.msm_buckets.release(); c.msm_seg.release(); c.msm_win.release();
   for (auto& kv : c.bases) if (kv.second.d_points) (void)hipFree(kv.second.d_points);
   c.bases.clear();
+  if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }
   for (auto& r : c.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   c.prof.clear();
   for (auto e : c.ev_pool) (void)hipEventDestroy(e);
@@ -382,6 +440,35 @@ int mh_bases_from_dev(int curve, const void* d_xy, size_t n, uint64_t* handle_ou
   uint64_t h = c.next_handle++;
   c.bases[h] = b;
   *handle_out = h;
+  return MH_OK;
+}
+
+int mh_srs_powers(int curve, const uint64_t* tau_mont, const uint64_t* scale_mont, size_t n, uint64_t* handle_out) {
+  LOCKED_CTX();
+  if (curve != MH_CURVE_BLS12_381_G1) return fail(MH_EINVAL, "unsupported curve");
+  if (!tau_mont || !scale_mont || !handle_out) return fail(MH_EINVAL, "mh_srs_powers: null pointer");
+  BaseSet b;
+  b.n = n;
+  if (n) {
+    MH_HIP(hipMalloc(&b.d_points, n * 96));
+    int rc = srs_powers_device(c, tau_mont, scale_mont, n, 0, b.d_points);
+    if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
+    MH_HIP(hipStreamSynchronize(c.stream));
+  }
+  uint64_t h = c.next_handle++;
+  c.bases[h] = b;
+  *handle_out = h;
+  return MH_OK;
+}
+
+int mh_bases_download(uint64_t handle, size_t offset, size_t n, uint64_t* xy_out) {
+  LOCKED_CTX();
+  auto it = c.bases.find(handle);
+  if (it == c.bases.end()) return fail(MH_EINVAL, "mh_bases_download: unknown handle");
+  if (offset > it->second.n || n > it->second.n - offset) return fail(MH_EINVAL, "mh_bases_download: out of range");
+  if (n == 0) return MH_OK;
+  MH_HIP(hipMemcpyAsync(xy_out, (const char*)it->second.d_points + offset * 96, n * 96, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
   return MH_OK;
 }
 

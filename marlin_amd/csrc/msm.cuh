@@ -33,13 +33,25 @@ namespace msm {
 constexpr int HIST_THREADS = 1024;
 constexpr int SEG = 16;  // buckets per reduce1 segment
 
+constexpr int MAX_WINDOWS = 64;
+
+// Window layout: W windows that tile exactly 256 bits (255 scalar bits + 1 bit of
+// headroom for the signed-digit carry).  Windows are c or c-1 bits wide, so no
+// window is left nearly empty (a 1-bit top window would put every carry into a
+// single bucket and serialise its accumulation).
+struct Windows {
+  unsigned char start[MAX_WINDOWS];   // first bit of window w
+  unsigned char bits[MAX_WINDOWS];    // width of window w (c or c-1)
+};
+
 struct Plan {
-  u32 c;        // window bits
-  u32 W;        // windows (W*c >= 256)
+  u32 c;        // widest window, bits
+  u32 W;        // number of windows
   u32 nb;       // buckets per window = 2^(c-1)
   u32 tile;     // entries per hist/scatter tile
   u32 ntiles;   // tiles per window
   u32 nseg;     // segments per window
+  Windows win;
 };
 
 inline Plan make_plan(u64 n) {
@@ -53,6 +65,16 @@ inline Plan make_plan(u64 n) {
   p.c = (u32)c;
   p.W = (256 + c - 1) / c;
   p.nb = 1u << (c - 1);
+  {
+    u32 narrow = p.W * c - 256;          // windows that are c-1 bits wide (the top ones)
+    u32 bit = 0;
+    for (u32 w = 0; w < p.W; w++) {
+      u32 wb = (w >= p.W - narrow) ? (u32)c - 1 : (u32)c;
+      p.win.start[w] = (unsigned char)bit;
+      p.win.bits[w] = (unsigned char)wb;
+      bit += wb;
+    }
+  }
   u64 t = (n * p.W + 1023) / 1024;       // aim for ~1024 tiles in total
   if (t < 4096) t = 4096;
   if (t > 65536) t = 65536;
@@ -64,26 +86,22 @@ inline Plan make_plan(u64 n) {
 
 // ---- 1. digits -----------------------------------------------------------------
 __global__ __launch_bounds__(256) void digits_kernel(const Fr* __restrict__ scalars, u32* __restrict__ dig,
-                                                     u64 n, u32 c, u32 W, int is_mont) {
+                                                     u64 n, u32 W, Windows win, int is_mont) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr s = ff_load(scalars + i);
   if (is_mont) s = ff_from_mont(s);
-  const u32 half = 1u << (c - 1);
-  const u32 mask = (1u << c) - 1;
   u32 carry = 0;
   for (u32 w = 0; w < W; w++) {
-    u32 bit = w * c;
+    const u32 bit = win.start[w], wb = win.bits[w];
+    const u32 half = 1u << (wb - 1);
+    const u32 mask = (1u << wb) - 1;
     u32 limb = bit >> 5, sh = bit & 31;
-    u32 raw = 0;
-    if (limb < 8) {
-      u64 two = s.v[limb];
-      if (limb + 1 < 8) two |= (u64)s.v[limb + 1] << 32;
-      raw = (u32)(two >> sh) & mask;
-    }
-    raw += carry;
+    u64 two = s.v[limb];
+    if (limb + 1 < 8) two |= (u64)s.v[limb + 1] << 32;
+    u32 raw = ((u32)(two >> sh) & mask) + carry;
     u32 e;
-    if (raw > half) { e = ((1u << c) - raw) | 0x80000000u; carry = 1; }
+    if (raw > half) { e = ((1u << wb) - raw) | 0x80000000u; carry = 1; }
     else { e = raw; carry = 0; }           // raw == 0 -> skip entry
     dig[(u64)w * n + i] = e;
   }

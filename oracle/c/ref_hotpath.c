@@ -1,0 +1,371 @@
+/* ref_hotpath.c -- CPU restatement (plain C, 64-bit limbs) of the arithmetic the
+ * reference's hot path executes: radix-2 NTT over BLS12-381 Fr and Pippenger MSM
+ * over BLS12-381 G1, in the algorithm class arkworks 0.3 uses.
+ *
+ * ORACLE / TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): used by tests/ as the
+ * checker at sizes the pure-Python oracle cannot reach, and by bench.py's
+ * `cpu_baseline` leg (kind "port").  Never linked into or called from the product.
+ *
+ * The algorithms live in third-party crates that are absent from /root/reference
+ * (ark-poly / ark-ec / ark-ff ^0.3.0, Cargo.toml:23-28); what is restated here is
+ * their published behaviour as recalled in SURVEY.md Appendix B, anchored on the
+ * reference's call sites:
+ *   ref_ntt      <- GeneralEvaluationDomain::{fft,ifft}: src/ahp/prover.rs:326,350-351,
+ *                   359,365,427,488,532-535,545,655,681  (B-1: natural order, omega =
+ *                   2-adic root squared down, inverse includes n^-1)
+ *   ref_msm      <- VariableBaseMSM::multi_scalar_mul via PC::commit src/lib.rs:172,193,
+ *                   213 and PC::open_combinations src/lib.rs:292 (B-2: c = 3 if n < 32
+ *                   else ceil(log2 n)*69/100 + 2; 2^c-1 Jacobian buckets per window,
+ *                   mixed additions, running-sum reduction, windows in parallel)
+ * Parity status: unpinned against arkworks bytes (no golden vectors exist upstream);
+ * pinned against oracle/*.py (naive DFT, naive MSM, known-dlog identities) by
+ * tests/test_oracle_c.py.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+/* ------------------------------------------------------------------ fields ---- */
+#define FRN 4
+#define FQN 6
+static const u64 FR_MOD[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+static const u64 FR_INV = 0xfffffffeffffffffull;
+static const u64 FR_ONE[4] = {0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull, 0x1824b159acc5056full};
+static const u64 FR_R2[4] = {0xc999e990f3f29c6dull, 0x2b6cedcb87925c23ull, 0x05d314967254398full, 0x0748d9d99f59ff11ull};
+static const u64 FR_ROOT32_CANON[4] = {0x3829971f439f0d2bull, 0xb63683508c2280b9ull, 0xd09b681922c813b4ull, 0x16a2a19edfe81f20ull};
+static const u64 FQ_MOD[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
+                              0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+static const u64 FQ_INV = 0x89f3fffcfffcfffdull;
+static const u64 FQ_ONE[6] = {0x760900000002fffdull, 0xebf4000bc40c0002ull, 0x5f48985753c758baull,
+                              0x77ce585370525745ull, 0x5c071a97a256ec6dull, 0x15f65ec3fa80e493ull};
+static const u64 FQ_R2[6] = {0xf4df1f341c341746ull, 0x0a76e6a609d104f1ull, 0x8de5476c4c95b6d5ull,
+                             0x67eb88a9939d83c0ull, 0x9a793e85b519952dull, 0x11988fe592cae3aaull};
+/* G1 generator (canonical), SURVEY Appendix D */
+static const u64 G1_GX[6] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull,
+                             0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull};
+static const u64 G1_GY[6] = {0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull,
+                             0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+
+#define DEF_FIELD(P, N, MOD, INV)                                                            \
+  static inline int P##_geq(const u64* a) {                                                  \
+    for (int i = N - 1; i >= 0; i--) { if (a[i] > MOD[i]) return 1; if (a[i] < MOD[i]) return 0; } \
+    return 1;                                                                                \
+  }                                                                                          \
+  static inline void P##_subm(u64* a) {                                                      \
+    u64 b = 0;                                                                               \
+    for (int i = 0; i < N; i++) { u128 d = (u128)a[i] - MOD[i] - b; a[i] = (u64)d; b = (u64)(d >> 127); } \
+  }                                                                                          \
+  static inline void P##_add(u64* r, const u64* a, const u64* b) {                           \
+    u64 c = 0;                                                                               \
+    for (int i = 0; i < N; i++) { u128 s = (u128)a[i] + b[i] + c; r[i] = (u64)s; c = (u64)(s >> 64); } \
+    if (c || P##_geq(r)) P##_subm(r);                                                        \
+  }                                                                                          \
+  static inline void P##_sub(u64* r, const u64* a, const u64* b) {                           \
+    u64 bo = 0;                                                                              \
+    for (int i = 0; i < N; i++) { u128 d = (u128)a[i] - b[i] - bo; r[i] = (u64)d; bo = (u64)(d >> 127); } \
+    if (bo) { u64 c = 0; for (int i = 0; i < N; i++) { u128 s = (u128)r[i] + MOD[i] + c; r[i] = (u64)s; c = (u64)(s >> 64); } } \
+  }                                                                                          \
+  static inline void P##_mul(u64* r, const u64* a, const u64* b) {                           \
+    u64 t[N + 2];                                                                            \
+    memset(t, 0, sizeof(t));                                                                 \
+    for (int i = 0; i < N; i++) {                                                            \
+      u64 c = 0;                                                                             \
+      for (int j = 0; j < N; j++) { u128 p = (u128)a[i] * b[j] + t[j] + c; t[j] = (u64)p; c = (u64)(p >> 64); } \
+      u128 s = (u128)t[N] + c; t[N] = (u64)s; t[N + 1] = (u64)(s >> 64);                     \
+      u64 m = t[0] * INV;                                                                    \
+      u128 p = (u128)m * MOD[0] + t[0]; c = (u64)(p >> 64);                                  \
+      for (int j = 1; j < N; j++) { p = (u128)m * MOD[j] + t[j] + c; t[j - 1] = (u64)p; c = (u64)(p >> 64); } \
+      s = (u128)t[N] + c; t[N - 1] = (u64)s; t[N] = t[N + 1] + (u64)(s >> 64);               \
+    }                                                                                        \
+    memcpy(r, t, N * 8);                                                                     \
+    if (t[N] || P##_geq(r)) P##_subm(r);                                                     \
+  }                                                                                          \
+  static inline int P##_is_zero(const u64* a) { u64 o = 0; for (int i = 0; i < N; i++) o |= a[i]; return o == 0; } \
+  static inline int P##_eq(const u64* a, const u64* b) { return memcmp(a, b, N * 8) == 0; }
+
+DEF_FIELD(fr, FRN, FR_MOD, FR_INV)
+DEF_FIELD(fq, FQN, FQ_MOD, FQ_INV)
+
+static void fr_pow(u64* r, const u64* base, u64 e) {
+  u64 acc[4], b[4];
+  memcpy(acc, FR_ONE, 32); memcpy(b, base, 32);
+  while (e) { if (e & 1) fr_mul(acc, acc, b); fr_mul(b, b, b); e >>= 1; }
+  memcpy(r, acc, 32);
+}
+static void fr_inv(u64* r, const u64* a) {  /* a^(r-2) */
+  u64 e[4]; memcpy(e, FR_MOD, 32); e[0] -= 2;
+  u64 acc[4]; memcpy(acc, FR_ONE, 32);
+  for (int i = 3; i >= 0; i--) for (int b = 63; b >= 0; b--) { fr_mul(acc, acc, acc); if ((e[i] >> b) & 1) fr_mul(acc, acc, a); }
+  memcpy(r, acc, 32);
+}
+static void fq_inv(u64* r, const u64* a) {
+  u64 e[6]; memcpy(e, FQ_MOD, 48); e[0] -= 2;
+  u64 acc[6]; memcpy(acc, FQ_ONE, 48);
+  for (int i = 5; i >= 0; i--) for (int b = 63; b >= 0; b--) { fq_mul(acc, acc, acc); if ((e[i] >> b) & 1) fq_mul(acc, acc, a); }
+  memcpy(r, acc, 48);
+}
+
+/* ------------------------------------------------------------------ NTT ------- */
+/* Radix-2 in place, natural order in/out.  Forward: DIF butterflies then bit reversal;
+ * inverse: bit reversal then DIT butterflies with omega^-1, then * n^-1 (the loop
+ * structure ark-poly's Radix2EvaluationDomain uses [UPSTREAM-RECALLED B-1]). */
+static void bitrev_permute(u64* a, uint32_t log_n) {
+  u64 n = 1ull << log_n;
+  for (u64 i = 0; i < n; i++) {
+    u64 j = 0, x = i;
+    for (uint32_t b = 0; b < log_n; b++) { j = (j << 1) | (x & 1); x >>= 1; }
+    if (i < j) { u64 t[4]; memcpy(t, a + 4 * i, 32); memcpy(a + 4 * i, a + 4 * j, 32); memcpy(a + 4 * j, t, 32); }
+  }
+}
+
+int ref_ntt(u64* a, uint32_t log_n, int inverse) {
+  if (log_n > 32) return -1;
+  u64 n = 1ull << log_n;
+  if (n == 1) return 0;
+  u64 root32[4], w_n[4];
+  fr_mul(root32, FR_ROOT32_CANON, FR_R2);                 /* to Montgomery */
+  memcpy(w_n, root32, 32);
+  for (uint32_t i = log_n; i < 32; i++) fr_mul(w_n, w_n, w_n);
+  if (inverse) fr_inv(w_n, w_n);
+  /* twiddle table w_n^k, k < n/2 */
+  u64* tw = (u64*)malloc((size_t)(n / 2) * 32);
+  if (!tw) return -2;
+  memcpy(tw, FR_ONE, 32);
+  for (u64 k = 1; k < n / 2; k++) fr_mul(tw + 4 * k, tw + 4 * (k - 1), w_n);
+  if (!inverse) {
+    /* DIF: gap n/2 .. 1 */
+    for (u64 gap = n / 2; gap >= 1; gap >>= 1) {
+      u64 step = (n / 2) / gap;
+      for (u64 s = 0; s < n; s += 2 * gap)
+        for (u64 k = 0; k < gap; k++) {
+          u64 *x = a + 4 * (s + k), *y = a + 4 * (s + k + gap), t[4];
+          fr_sub(t, x, y);
+          fr_add(x, x, y);
+          fr_mul(y, t, tw + 4 * (k * step));
+        }
+    }
+    bitrev_permute(a, log_n);
+  } else {
+    bitrev_permute(a, log_n);
+    for (u64 gap = 1; gap < n; gap <<= 1) {
+      u64 step = (n / 2) / gap;
+      for (u64 s = 0; s < n; s += 2 * gap)
+        for (u64 k = 0; k < gap; k++) {
+          u64 *x = a + 4 * (s + k), *y = a + 4 * (s + k + gap), t[4];
+          fr_mul(t, y, tw + 4 * (k * step));
+          fr_sub(y, x, t);
+          fr_add(x, x, t);
+        }
+    }
+    u64 nn[4] = {n, 0, 0, 0}, ninv[4];
+    fr_mul(nn, nn, FR_R2);
+    fr_inv(ninv, nn);
+    for (u64 i = 0; i < n; i++) fr_mul(a + 4 * i, a + 4 * i, ninv);
+  }
+  free(tw);
+  return 0;
+}
+
+/* Montgomery <-> canonical helpers for Fr vectors (arkworks into_repr / from_repr) */
+void ref_fr_from_mont(u64* a, size_t n) { static const u64 one[4] = {1, 0, 0, 0}; for (size_t i = 0; i < n; i++) fr_mul(a + 4 * i, a + 4 * i, one); }
+void ref_fr_to_mont(u64* a, size_t n) { for (size_t i = 0; i < n; i++) fr_mul(a + 4 * i, a + 4 * i, FR_R2); }
+void ref_fr_mul_vec(u64* r, const u64* a, const u64* b, size_t n) { for (size_t i = 0; i < n; i++) fr_mul(r + 4 * i, a + 4 * i, b + 4 * i); }
+
+/* ------------------------------------------------------------------ G1 -------- */
+typedef struct { u64 x[6], y[6], z[6]; } jac_t;   /* Jacobian, Z = 0 identity (arkworks GroupProjective) */
+
+static void jac_set_identity(jac_t* p) { memcpy(p->x, FQ_ONE, 48); memcpy(p->y, FQ_ONE, 48); memset(p->z, 0, 48); }
+static int jac_is_identity(const jac_t* p) { return fq_is_zero(p->z); }
+
+static void jac_double(jac_t* r, const jac_t* p) {   /* dbl-2009-l, a = 0 */
+  if (jac_is_identity(p)) { *r = *p; return; }
+  u64 A[6], B[6], C[6], D[6], E[6], F[6], t[6];
+  fq_mul(A, p->x, p->x); fq_mul(B, p->y, p->y); fq_mul(C, B, B);
+  fq_add(t, p->x, B); fq_mul(t, t, t); fq_sub(t, t, A); fq_sub(t, t, C); fq_add(D, t, t);
+  fq_add(E, A, A); fq_add(E, E, A);
+  fq_mul(F, E, E);
+  u64 z3[6]; fq_mul(z3, p->y, p->z); fq_add(z3, z3, z3);
+  u64 x3[6]; fq_sub(x3, F, D); fq_sub(x3, x3, D);
+  u64 y3[6]; fq_sub(t, D, x3); fq_mul(y3, E, t);
+  fq_add(C, C, C); fq_add(C, C, C); fq_add(C, C, C); fq_sub(y3, y3, C);
+  memcpy(r->x, x3, 48); memcpy(r->y, y3, 48); memcpy(r->z, z3, 48);
+}
+
+static void jac_add(jac_t* r, const jac_t* a, const jac_t* b) {   /* add-2007-bl */
+  if (jac_is_identity(a)) { *r = *b; return; }
+  if (jac_is_identity(b)) { *r = *a; return; }
+  u64 z1z1[6], z2z2[6], u1[6], u2[6], s1[6], s2[6], t[6];
+  fq_mul(z1z1, a->z, a->z); fq_mul(z2z2, b->z, b->z);
+  fq_mul(u1, a->x, z2z2); fq_mul(u2, b->x, z1z1);
+  fq_mul(t, b->z, z2z2); fq_mul(s1, a->y, t);
+  fq_mul(t, a->z, z1z1); fq_mul(s2, b->y, t);
+  if (fq_eq(u1, u2)) { if (fq_eq(s1, s2)) { jac_double(r, a); } else { jac_set_identity(r); } return; }
+  u64 h[6], rr[6], hh[6], hhh[6], v[6];
+  fq_sub(h, u2, u1); fq_sub(rr, s2, s1);
+  fq_mul(hh, h, h); fq_mul(hhh, h, hh); fq_mul(v, u1, hh);
+  u64 x3[6], y3[6], z3[6];
+  fq_mul(x3, rr, rr); fq_sub(x3, x3, hhh); fq_sub(x3, x3, v); fq_sub(x3, x3, v);
+  fq_sub(t, v, x3); fq_mul(y3, rr, t); fq_mul(t, s1, hhh); fq_sub(y3, y3, t);
+  fq_mul(z3, a->z, b->z); fq_mul(z3, z3, h);
+  memcpy(r->x, x3, 48); memcpy(r->y, y3, 48); memcpy(r->z, z3, 48);
+}
+
+/* r = a + (x2, y2) affine  (add_assign_mixed) */
+static void jac_add_mixed(jac_t* r, const jac_t* a, const u64* x2, const u64* y2) {
+  if (jac_is_identity(a)) { memcpy(r->x, x2, 48); memcpy(r->y, y2, 48); memcpy(r->z, FQ_ONE, 48); return; }
+  u64 z1z1[6], u2[6], s2[6], t[6];
+  fq_mul(z1z1, a->z, a->z); fq_mul(u2, x2, z1z1);
+  fq_mul(t, a->z, z1z1); fq_mul(s2, y2, t);
+  if (fq_eq(a->x, u2)) {
+    if (fq_eq(a->y, s2)) { jac_double(r, a); } else { jac_set_identity(r); }
+    return;
+  }
+  u64 h[6], rr[6], hh[6], hhh[6], v[6];
+  fq_sub(h, u2, a->x); fq_sub(rr, s2, a->y);
+  fq_mul(hh, h, h); fq_mul(hhh, h, hh); fq_mul(v, a->x, hh);
+  u64 x3[6], y3[6], z3[6];
+  fq_mul(x3, rr, rr); fq_sub(x3, x3, hhh); fq_sub(x3, x3, v); fq_sub(x3, x3, v);
+  fq_sub(t, v, x3); fq_mul(y3, rr, t); fq_mul(t, a->y, hhh); fq_sub(y3, y3, t);
+  fq_mul(z3, a->z, h);
+  memcpy(r->x, x3, 48); memcpy(r->y, y3, 48); memcpy(r->z, z3, 48);
+}
+
+static void jac_to_affine(const jac_t* p, u64* x, u64* y, int* inf) {
+  if (jac_is_identity(p)) { memset(x, 0, 48); memcpy(y, FQ_ONE, 48); *inf = 1; return; }
+  u64 zi[6], zi2[6], zi3[6];
+  fq_inv(zi, p->z); fq_mul(zi2, zi, zi); fq_mul(zi3, zi2, zi);
+  fq_mul(x, p->x, zi2); fq_mul(y, p->y, zi3); *inf = 0;
+}
+
+/* Jacobian X||Y||Z (18 limbs) -> affine x||y (12 limbs) + infinity flag */
+void ref_g1_to_affine(const u64* xyz, u64* xy, int* inf) {
+  jac_t p; memcpy(p.x, xyz, 48); memcpy(p.y, xyz + 6, 48); memcpy(p.z, xyz + 12, 48);
+  jac_to_affine(&p, xy, xy + 6, inf);
+}
+
+static void jac_mul_canon(jac_t* r, const jac_t* p, const u64* k) {  /* k: 4 canonical limbs */
+  jac_t acc; jac_set_identity(&acc);
+  for (int i = 3; i >= 0; i--) for (int b = 63; b >= 0; b--) { jac_double(&acc, &acc); if ((k[i] >> b) & 1) jac_add(&acc, &acc, p); }
+  *r = acc;
+}
+
+/* [k]G for a canonical scalar k -> Jacobian out (18 limbs, Montgomery coords) */
+void ref_g1_mul_gen(const u64* k_canon, u64* out_xyz) {
+  jac_t g; fq_mul(g.x, G1_GX, FQ_R2); fq_mul(g.y, G1_GY, FQ_R2); memcpy(g.z, FQ_ONE, 48);
+  jac_t r; jac_mul_canon(&r, &g, k_canon);
+  memcpy(out_xyz, r.x, 48); memcpy(out_xyz + 6, r.y, 48); memcpy(out_xyz + 12, r.z, 48);
+}
+
+/* bases with known discrete logs for tests: P_i = [a0 + i*d]G, i < n, affine x||y
+ * Montgomery (12 limbs each); batch-normalised.  Test-data generator, not on any path
+ * of the reference. */
+int ref_bases_arith(const u64* a0_canon, const u64* d_canon, size_t n, u64* out_xy) {
+  jac_t g; fq_mul(g.x, G1_GX, FQ_R2); fq_mul(g.y, G1_GY, FQ_R2); memcpy(g.z, FQ_ONE, 48);
+  jac_t p, d; jac_mul_canon(&p, &g, a0_canon); jac_mul_canon(&d, &g, d_canon);
+  jac_t* pts = (jac_t*)malloc(n * sizeof(jac_t));
+  u64* prod = (u64*)malloc(n * 48);
+  if (!pts || !prod) { free(pts); free(prod); return -2; }
+  u64 acc[6]; memcpy(acc, FQ_ONE, 48);
+  for (size_t i = 0; i < n; i++) {
+    pts[i] = p;
+    if (jac_is_identity(&p)) { free(pts); free(prod); return -3; }
+    fq_mul(acc, acc, p.z); memcpy(prod + 6 * i, acc, 48);
+    jac_add(&p, &p, &d);
+  }
+  u64 inv[6]; fq_inv(inv, acc);
+  for (size_t i = n; i-- > 0;) {
+    u64 zi[6];
+    if (i) fq_mul(zi, inv, prod + 6 * (i - 1)); else memcpy(zi, inv, 48);
+    fq_mul(inv, inv, pts[i].z);
+    u64 zi2[6], zi3[6];
+    fq_mul(zi2, zi, zi); fq_mul(zi3, zi2, zi);
+    fq_mul(out_xy + 12 * i, pts[i].x, zi2);
+    fq_mul(out_xy + 12 * i + 6, pts[i].y, zi3);
+  }
+  free(pts); free(prod);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ MSM ------- */
+typedef struct {
+  const u64* bases; const u64* scalars; size_t n; unsigned c; unsigned w_start; jac_t result;
+} win_job_t;
+
+static void window_sum(win_job_t* j) {
+  const unsigned c = j->c;
+  const size_t nb = ((size_t)1 << c) - 1;
+  jac_t* buckets = (jac_t*)malloc(nb * sizeof(jac_t));
+  for (size_t b = 0; b < nb; b++) jac_set_identity(&buckets[b]);
+  jac_t res; jac_set_identity(&res);
+  for (size_t i = 0; i < j->n; i++) {
+    const u64* s = j->scalars + 4 * i;
+    if ((s[0] | s[1] | s[2] | s[3]) == 0) continue;
+    /* arkworks: scalar == 1 is added directly in window 0 only */
+    if (s[0] == 1 && (s[1] | s[2] | s[3]) == 0) {
+      if (j->w_start == 0) jac_add_mixed(&res, &res, j->bases + 12 * i, j->bases + 12 * i + 6);
+      continue;
+    }
+    unsigned limb = j->w_start / 64, sh = j->w_start % 64;
+    u64 d = s[limb] >> sh;
+    if (sh + c > 64 && limb + 1 < 4) d |= s[limb + 1] << (64 - sh);
+    d &= ((u64)1 << c) - 1;
+    if (d) jac_add_mixed(&buckets[d - 1], &buckets[d - 1], j->bases + 12 * i, j->bases + 12 * i + 6);
+  }
+  jac_t running; jac_set_identity(&running);
+  for (size_t b = nb; b-- > 0;) { jac_add(&running, &running, &buckets[b]); jac_add(&res, &res, &running); }
+  free(buckets);
+  j->result = res;
+}
+
+typedef struct { win_job_t* jobs; int njobs; int next; pthread_mutex_t mu; } pool_t;
+static void* worker(void* arg) {
+  pool_t* p = (pool_t*)arg;
+  for (;;) {
+    pthread_mutex_lock(&p->mu);
+    int k = p->next < p->njobs ? p->next++ : -1;
+    pthread_mutex_unlock(&p->mu);
+    if (k < 0) break;
+    window_sum(&p->jobs[k]);
+  }
+  return NULL;
+}
+
+/* bases: n x (x||y) Montgomery; scalars: n x 4 limbs (Montgomery if is_mont, as arkworks holds
+ * coefficients; converted with into_repr first, like KZG10::commit does); out: Jacobian X||Y||Z. */
+int ref_msm(const u64* bases, const u64* scalars_in, int is_mont, size_t n, int threads, u64* out_xyz) {
+  jac_t total; jac_set_identity(&total);
+  if (n == 0) goto done;
+  {
+    u64* scalars = (u64*)malloc(n * 32);
+    if (!scalars) return -2;
+    memcpy(scalars, scalars_in, n * 32);
+    if (is_mont) ref_fr_from_mont(scalars, n);
+    unsigned c;
+    if (n < 32) c = 3;
+    else { unsigned lg = 0; while (((size_t)1 << lg) < n) lg++; c = lg * 69 / 100 + 2; }
+    int nw = (255 + c - 1) / c;
+    win_job_t* jobs = (win_job_t*)calloc(nw, sizeof(win_job_t));
+    for (int w = 0; w < nw; w++) { jobs[w].bases = bases; jobs[w].scalars = scalars; jobs[w].n = n; jobs[w].c = c; jobs[w].w_start = w * c; }
+    pool_t pool; pool.jobs = jobs; pool.njobs = nw; pool.next = 0; pthread_mutex_init(&pool.mu, NULL);
+    if (threads < 1) threads = 1;
+    if (threads > nw) threads = nw;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    for (int t = 1; t < threads; t++) pthread_create(&th[t], NULL, worker, &pool);
+    worker(&pool);
+    for (int t = 1; t < threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    /* combine: lowest window first is special-cased upstream; mathematically Horner from the top */
+    for (int w = nw - 1; w >= 0; w--) {
+      for (unsigned k = 0; k < c; k++) jac_double(&total, &total);
+      jac_add(&total, &total, &jobs[w].result);
+    }
+    free(jobs); free(scalars);
+  }
+done:
+  memcpy(out_xyz, total.x, 48); memcpy(out_xyz + 6, total.y, 48); memcpy(out_xyz + 12, total.z, 48);
+  return 0;
+}

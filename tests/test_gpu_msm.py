@@ -49,6 +49,20 @@ def test_msm_known_dlog(gpu, bases4k, n):
     _check_dlog(gpu, B, pts, dl, rand_fr(n, 77 + n))
 
 
+@pytest.mark.parametrize("n", [2 ** 13 + 5, 2 ** 14, 2 ** 15 - 1, 2 ** 16, 2 ** 17 + 3, 2 ** 18])
+def test_msm_every_window_width(gpu, bases4k, n):
+    """n chosen so the plan uses c = 9 ... 13 (mixed c / c-1 wide windows); bases are the
+    4096 known-dlog points tiled, so the answer is one scalar multiplication."""
+    pts, dl = bases4k
+    reps = (n + 4095) // 4096
+    big = np.tile(points_to_np(pts), (reps, 1))[:n]
+    B = gpu.Bases(big)
+    sc = rand_fr(n, n)
+    out = gpu.msm(B, fr_to_np(sc))
+    k = sum(s * dl[i % 4096] for i, s in enumerate(sc)) % F.R_MOD
+    assert jac_np_to_affine(out) == EC.scalar_mul(EC.G1_GEN, k)
+
+
 def test_msm_offsets_and_canonical_scalars(gpu, bases4k):
     pts, dl = bases4k
     B = gpu.Bases(points_to_np(pts))

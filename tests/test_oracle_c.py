@@ -1,0 +1,47 @@
+"""Pins the C restatement (oracle/c/ref_hotpath.c) against the pure-Python oracle:
+naive DFT / radix-2 NTT, naive MSM, known-dlog identities.  CPU only."""
+import numpy as np
+from oracle import fields as F, curve as EC, poly as OP, cref
+from tests.util import fr_to_np, np_to_fr, points_to_np, jac_np_to_affine, arith_bases, rand_fr, limbs_to_fq
+
+
+def test_c_ntt_matches_python():
+    for log_n in range(0, 11):
+        v = rand_fr(1 << log_n, log_n)
+        assert np_to_fr(cref.ntt(fr_to_np(v))) == OP.ntt(v, log_n)
+        assert np_to_fr(cref.ntt(fr_to_np(v), inverse=True)) == OP.ntt(v, log_n, inverse=True)
+    v = rand_fr(32, 99)
+    assert np_to_fr(cref.ntt(fr_to_np(v))) == OP.dft_naive(v, 5)
+
+
+def test_c_bases_and_mul_gen():
+    pts, dl = arith_bases(40)
+    got, dl2 = cref.bases_arith(40)
+    assert dl == dl2
+    assert np.array_equal(got, points_to_np(pts))
+    for k in [0, 1, 2, F.R_MOD - 1, 0xdeadbeef12345]:
+        assert jac_np_to_affine(cref.g1_mul_gen(k)) == EC.scalar_mul(EC.G1_GEN, k)
+
+
+def test_c_msm_matches_python():
+    pts, dl = arith_bases(64)
+    b = points_to_np(pts)
+    for n in [1, 3, 31, 32, 64]:
+        sc = rand_fr(n, n)
+        want = EC.msm_naive(pts[:n], sc)
+        assert jac_np_to_affine(cref.msm(b[:n], fr_to_np(sc))) == want
+        assert jac_np_to_affine(cref.msm(b[:n], fr_to_np(sc, montgomery=False), montgomery=False, threads=4)) == want
+    # edge scalars incl. the scalar==1 shortcut and zeros
+    sc = [0, 1, 1, F.R_MOD - 1, 2, 0, 1 << 254, 5] * 8
+    assert jac_np_to_affine(cref.msm(b, fr_to_np(sc))) == EC.msm_naive(pts, sc)
+    xy, inf = cref.g1_to_affine(cref.msm(b, fr_to_np([0] * 64)))
+    assert inf
+
+
+def test_c_msm_known_dlog_large():
+    n = 20000
+    b, dl = cref.bases_arith(n)
+    sc = rand_fr(n, 5)
+    k = sum(s * a for s, a in zip(sc, dl)) % F.R_MOD
+    out = cref.msm(b, fr_to_np(sc), threads=8)
+    assert jac_np_to_affine(out) == EC.scalar_mul(EC.G1_GEN, k)
