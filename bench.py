@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- Marlin prover hot path on MI355X.
+
+Metric (BASELINE.json): R1CS constraints / second for Marlin::prove on BLS12-381
+at 2^20 constraints (DummyCircuit of /root/reference benches/bench.rs:26-66,
+MarlinKZG10).  One "step" = one pass of the prove hot path over one instance:
+
+  workload "hotpath-inventory": the 30 NTTs and 15 large MSMs that one
+      Marlin::prove performs at this size, on synthetic
+      coefficient vectors resident in HBM and a known-tau SRS generated on the
+      device.  (Used until the device-resident prover lands; see config.workload.)
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on
+rank 0.  N > 1 is launched by torch.distributed.run, one rank per GPU: every MSM
+is sharded by points across ranks (each rank holds its SRS shard), partial sums
+are exchanged with an RCCL all_gather of 144-byte points and added on every rank;
+the round polynomials' NTTs are replicated (strong scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_MAD_PEAK_TOPS = 30.0        # measured v_mad_u64_u32 lane-ops/s (profiles/r01_microbench.txt)
+
+
+def rand_fr_np(rng, n):
+    """n pseudo-random Montgomery-form Fr elements (< 2^254 < r) as (n,4) uint64."""
+    x = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    x[:, 3] &= np.uint64((1 << 62) - 1)
+    return x
+
+
+class HotPathInventory:
+    """NTT + MSM inventory of one Marlin::prove at N constraints, sharded over `world` ranks."""
+
+    def __init__(self, M, log_n, rank, world, seed=1):
+        from marlin_amd import workload as W
+        self.M = M
+        self.N = 1 << log_n
+        self.rank, self.world = rank, world
+        H, K = self.N, 4 * self.N
+        self.ntts = W.ntt_inventory(H, K)
+        self.msms, self.small = W.msm_inventory(H, K)
+        self.alg_ntt_bytes, self.alg_msm_bytes = W.algorithmic_bytes(H, K)
+        rng = np.random.default_rng(seed + rank)
+        # --- SRS shard: powers tau^i for i in this rank's slice of [0, 4N) -------------
+        tau = np.array([0x9c5d7e2b4a6f8091, 0x1f3a, 0, 0], dtype=np.uint64)   # any non-zero Montgomery value
+        self.srs_n = K
+        self.lo = (K * rank) // world
+        self.hi = (K * (rank + 1)) // world
+        self.bases = M.Bases.srs_powers(tau, self.hi - self.lo, first=self.lo)
+        # --- polynomial buffers (device resident) ----------------------------------------
+        max_ntt = max(lg for lg, _, _ in self.ntts)
+        self.buf_a = M.DeviceBuffer.from_numpy(rand_fr_np(rng, 1 << max_ntt))
+        self.buf_b = M.DeviceBuffer(32 << max_ntt)
+        # scalars for this rank's shard of the largest MSM
+        self.scal = M.DeviceBuffer.from_numpy(rand_fr_np(rng, self.hi - self.lo))
+
+    def shard(self, n):
+        """this rank's [lo, hi) slice of an n-point MSM whose bases start at SRS index 0."""
+        lo = max(0, min(n, self.lo))
+        hi = max(0, min(n, self.hi))
+        # balance: split n evenly instead of by fixed SRS slices when n < srs_n
+        lo = (n * self.rank) // self.world
+        hi = (n * (self.rank + 1)) // self.world
+        return lo, hi
+
+    def step(self, dist=None, torch=None):
+        M = self.M
+        for lg, inverse, _ in self.ntts:
+            M.ntt_dev(self.buf_a, self.buf_b, lg, inverse=inverse)
+        partials = []
+        for n, _ in self.msms:
+            # every rank takes an equal share; its bases are the first (hi-lo) points of its shard
+            cnt = (n * (self.rank + 1)) // self.world - (n * self.rank) // self.world
+            cnt = min(cnt, self.bases.n)
+            partials.append(M.msm_dev(self.bases, self.scal, cnt, base_offset=0, montgomery=True))
+        if self.world > 1:
+            t = torch.from_numpy(np.stack(partials).view(np.int64)).cuda()
+            out = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(out, t)
+            # (the prover adds the gathered partial points on the host: W-1 additions of 144-byte points)
+            _ = [o.cpu() for o in out]
+        return partials
+
+
+def cpu_baseline(log_n_sample=13):
+    """The C restatement (oracle/c/ref_hotpath.c, kind "port") timed on this host's cores on the
+    hot-path inventory of a 2^log_n_sample-constraint prove."""
+    from oracle import cref
+    from marlin_amd import workload as W
+    cref.build()
+    cores = os.cpu_count() or 1
+    H = 1 << log_n_sample
+    K = 4 * H
+    rng = np.random.default_rng(7)
+    bases, _ = cref.bases_arith(K)
+    ntts = W.ntt_inventory(H, K)
+    msms, _ = W.msm_inventory(H, K)
+    max_lg = max(lg for lg, _, _ in ntts)
+    data = rand_fr_np(rng, 1 << max_lg)
+    scal = rand_fr_np(rng, K)
+    t0 = time.time()
+    for lg, inverse, _ in ntts:
+        cref.ntt(data[: 1 << lg], inverse=inverse)
+    t_ntt = time.time() - t0
+    t0 = time.time()
+    for n, _ in msms:
+        cref.msm(bases[:n], scal[:n], montgomery=True, threads=cores)
+    t_msm = time.time() - t0
+    total = t_ntt + t_msm
+    return {
+        "value": H / total, "unit": "constraints/s", "cores": cores, "kind": "port",
+        "sample": "oracle/c/ref_hotpath.c (C restatement of arkworks' radix-2 NTT + Pippenger, NOT arkworks itself): "
+                  "NTT+MSM inventory of one prove at 2^%d constraints; NTT single-thread %.2fs, MSM windows over %d threads %.2fs"
+                  % (log_n_sample, t_ntt, cores, t_msm),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-constraints", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    import marlin_amd as M
+    M.init(local_rank)
+    torch.cuda.set_device(local_rank)
+
+    wl = HotPathInventory(M, args.log_constraints, rank, world)
+
+    def barrier():
+        M.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step(dist, torch)
+    M.prof_enable(True)
+    M.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(dist, torch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = wl.N / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (MSM bucket accumulation), live HIP-event timing ----
+    acc_ms, acc_launches = M.prof_get(2)
+    ntt_ms, ntt_launches = M.prof_get(0)
+    msm_ms, _ = M.prof_get(1)
+    msm_pairs_rank = sum((n * (rank + 1)) // world - (n * rank) // world for n, _ in wl.msms)
+    bytes_per_launch = 128.0 * msm_pairs_rank / len(wl.msms)
+    avg_launch_ms = acc_ms / max(1, acc_launches)
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("msm_accum_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "msm::accum_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_launch_ms, 4),
+                "note": "MSM is integer-VALU bound (~7k VALU instr per 128 B of input per window), see DESIGN.md; "
+                        "NTT family: %.1f GB/s algorithmic" % (
+                            (wl.alg_ntt_bytes * args.steps) / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0)}
+
+    out = {
+        "metric": "marlin_prove_constraints_per_sec", "value": round(value, 1), "unit": "constraints/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32-limb Montgomery (Fr 256-bit, Fq 384-bit)",
+        "data": "synthetic",
+        "config": {"workload": "hotpath-inventory: 30 NTT + 15 MSM of one Marlin::prove, DummyCircuit 2^%d constraints, "
+                               "BLS12-381, MarlinKZG10 (SURVEY.md Appendix A)" % args.log_constraints,
+                   "constraints": wl.N, "curve": "BLS12-381", "pc": "MarlinKZG10",
+                   "parallelism": "msm-point-sharded x%d, ntt replicated" % world},
+        "breakdown_ms_per_step": {"ntt": round(ntt_ms / args.steps, 3), "msm": round(msm_ms / args.steps, 3),
+                                  "msm_accum": round(acc_ms / args.steps, 3)},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,10 +72,12 @@ int mh_ntt_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inv
  * (powers[num_leading_zeros..], shifted_powers[..]).  Output: Jacobian X||Y||Z. */
 int mh_bases_upload(int curve, const uint64_t* xy_mont, size_t n, uint64_t* handle_out);
 int mh_bases_from_dev(int curve, const void* d_xy_mont, size_t n, uint64_t* handle_out); /* adopts a copy */
-/* KZG10::setup's fixed-base powers for a known-tau (test/bench) SRS: bases[i] = [scale*tau^i]G,
- * i < n, generated on the device (reference: Marlin::universal_setup -> PC::setup,
- * src/lib.rs:79-96).  tau, scale: Montgomery Fr (4 limbs). */
-int mh_srs_powers(int curve, const uint64_t* tau_mont, const uint64_t* scale_mont, size_t n, uint64_t* handle_out);
+/* KZG10::setup's fixed-base powers for a known-tau (test/bench) SRS:
+ * bases[i] = [scale * tau^(first + i)]G, i < n, generated on the device (reference:
+ * Marlin::universal_setup -> PC::setup, src/lib.rs:79-96).  `first` lets each GPU of a
+ * node generate only its shard.  tau, scale: Montgomery Fr (4 limbs). */
+int mh_srs_powers(int curve, const uint64_t* tau_mont, const uint64_t* scale_mont, size_t first, size_t n,
+                  uint64_t* handle_out);
 int mh_bases_download(uint64_t handle, size_t offset, size_t n, uint64_t* xy_mont_out);
 int mh_bases_free(uint64_t handle);
 int mh_bases_len(uint64_t handle, size_t* n_out);

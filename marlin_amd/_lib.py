@@ -28,7 +28,7 @@ SYMBOLS = {
     "mh_ntt_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_bases_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
     "mh_bases_from_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
-    "mh_srs_powers": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, _u64p]),
+    "mh_srs_powers": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, _u64p]),
     "mh_bases_download": (C.c_int, [C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p]),
     "mh_bases_free": (C.c_int, [C.c_uint64]),
     "mh_bases_len": (C.c_int, [C.c_uint64, C.POINTER(C.c_size_t)]),

@@ -116,15 +116,15 @@ class Bases:
         self.n = a.shape[0]
 
     @classmethod
-    def srs_powers(cls, tau_mont, n, scale_mont=None):
-        """[scale * tau^i]G for i < n, generated on the device (KZG10::setup's powers_of_g).
+    def srs_powers(cls, tau_mont, n, scale_mont=None, first=0):
+        """[scale * tau^(first+i)]G for i < n, generated on the device (KZG10::setup's powers_of_g).
         tau_mont / scale_mont: (4,) uint64 Montgomery Fr; scale defaults to one."""
         tau = np.ascontiguousarray(tau_mont, dtype=np.uint64).reshape(4)
         if scale_mont is None:
             scale_mont = FR_ONE_MONT
         sc = np.ascontiguousarray(scale_mont, dtype=np.uint64).reshape(4)
         h = C.c_uint64()
-        _lib.check(_L().mh_srs_powers(CURVE_G1, tau.ctypes.data, sc.ctypes.data, int(n), C.byref(h)), "mh_srs_powers")
+        _lib.check(_L().mh_srs_powers(CURVE_G1, tau.ctypes.data, sc.ctypes.data, int(first), int(n), C.byref(h)), "mh_srs_powers")
         self = cls.__new__(cls)
         self.handle = h.value
         self.n = int(n)

@@ -443,7 +443,8 @@ int mh_bases_from_dev(int curve, const void* d_xy, size_t n, uint64_t* handle_ou
   return MH_OK;
 }
 
-int mh_srs_powers(int curve, const uint64_t* tau_mont, const uint64_t* scale_mont, size_t n, uint64_t* handle_out) {
+int mh_srs_powers(int curve, const uint64_t* tau_mont, const uint64_t* scale_mont, size_t first, size_t n,
+                  uint64_t* handle_out) {
   LOCKED_CTX();
   if (curve != MH_CURVE_BLS12_381_G1) return fail(MH_EINVAL, "unsupported curve");
   if (!tau_mont || !scale_mont || !handle_out) return fail(MH_EINVAL, "mh_srs_powers: null pointer");
@@ -451,7 +452,7 @@ int mh_srs_powers(int curve, const uint64_t* tau_mont, const uint64_t* scale_mon
   b.n = n;
   if (n) {
     MH_HIP(hipMalloc(&b.d_points, n * 96));
-    int rc = srs_powers_device(c, tau_mont, scale_mont, n, 0, b.d_points);
+    int rc = srs_powers_device(c, tau_mont, scale_mont, n, first, b.d_points);
     if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
     MH_HIP(hipStreamSynchronize(c.stream));
   }

@@ -1,0 +1,57 @@
+"""Shapes of the Marlin::prove hot path for the reference's benchmark circuit.
+
+`DummyCircuit` (/root/reference benches/bench.rs:26-66) with `num_variables = 10`
+and N constraints gives |H| = N, |K| = 4N, |X| = 2.  One
+`Marlin::prove` (src/lib.rs:151-311) with MarlinKZG10 then performs exactly the
+transforms and multi-scalar multiplications listed in SURVEY.md Appendix A; this
+module restates that inventory as data so bench.py, the tests and the CPU
+baseline all run the same list.
+"""
+
+
+def ntt_inventory(H, K=None, X=2):
+    """[(log2 size, inverse?, reference site)] for one prove."""
+    K = 4 * H if K is None else K
+
+    def lg(n):
+        l = n.bit_length() - 1
+        assert 1 << l == n
+        return l
+    inv = []
+    inv += [(lg(X), True, "prover.rs:321-325 x_poly"), (lg(H), False, "prover.rs:326 x_evals")]
+    for name, site in (("w", "350-352"), ("z_a", "359-360"), ("z_b", "365-366")):
+        inv += [(lg(H), True, "prover.rs:%s %s" % (site, name))]
+        inv += [(lg(2 * H), False, "prover.rs:%s r*v_H" % site), (lg(2 * H), False, "prover.rs:%s r*v_H" % site),
+                (lg(2 * H), True, "prover.rs:%s r*v_H" % site)]
+    inv += [(lg(4 * H), False, "prover.rs:467 z_a*z_b"), (lg(4 * H), False, "prover.rs:467 z_a*z_b"),
+            (lg(4 * H), True, "prover.rs:467 z_a*z_b")]
+    inv += [(lg(H), True, "prover.rs:488 r_alpha"), (lg(H), True, "prover.rs:427 t"), (lg(X), True, "prover.rs:506-510 x_poly")]
+    inv += [(lg(4 * H), False, "prover.rs:532-535 q_1 evals")] * 4 + [(lg(4 * H), True, "prover.rs:545 rhs")]
+    inv += [(lg(K), True, "prover.rs:655 b"), (lg(K), True, "prover.rs:681 f")]
+    inv += [(lg(2 * K), False, "prover.rs:685 b*f"), (lg(2 * K), False, "prover.rs:685 b*f"), (lg(2 * K), True, "prover.rs:685 b*f")]
+    assert len(inv) == 30
+    return inv
+
+
+def msm_inventory(H, K=None, X=2):
+    """[(n_pairs, reference site)] of the large MSMs of one prove (MarlinKZG10); the
+    3-coefficient hiding MSMs on powers_of_gamma_g are listed separately."""
+    K = 4 * H if K is None else K
+    big = [
+        (H - X + 1, "lib.rs:172 w"), (H + 1, "lib.rs:172 z_a"), (H + 1, "lib.rs:172 z_b"), (3 * H, "lib.rs:172 mask_poly"),
+        (H, "lib.rs:193 t"), (H - 1, "lib.rs:193 g_1"), (H - 1, "lib.rs:193 g_1 shifted"), (2 * H, "lib.rs:193 h_1"),
+        (K - 1, "lib.rs:213 g_2"), (K - 1, "lib.rs:213 g_2 shifted"), (K - 1, "lib.rs:213 h_2"),
+        (3 * H - 1, "lib.rs:292 open@beta witness"), (H - 2, "lib.rs:292 open@beta shifted witness (g_1)"),
+        (K - 1, "lib.rs:292 open@gamma witness"), (K - 2, "lib.rs:292 open@gamma shifted witness (g_2)"),
+    ]
+    small = [(3, "lib.rs:172 w hiding"), (3, "lib.rs:172 z_a hiding"), (3, "lib.rs:172 z_b hiding"),
+             (3, "lib.rs:193 g_1 hiding"), (3, "lib.rs:193 g_1 shifted hiding"), (2, "lib.rs:292 open@beta hiding")]
+    return big, small
+
+
+def algorithmic_bytes(H, K=None):
+    """NTT of size n moves 2*32*n bytes; MSM of size n moves n*(32+96)."""
+    ntt_b = sum(64 << lg for lg, _, _ in ntt_inventory(H, K))
+    big, small = msm_inventory(H, K)
+    msm_b = sum(128 * n for n, _ in big)
+    return ntt_b, msm_b
