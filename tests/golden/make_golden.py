@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/marlin_proofs.json with the pure-Python oracle (oracle/marlin.py).
+
+No arkworks output can be produced in this environment (no Rust toolchain), so
+these are NOT arkworks-produced vectors: they freeze the oracle's restatement so that (a) oracle
+drift is detected by the CPU tests and (b) the HIP prover is compared byte-for-byte against them
+on the GPU box.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ahp as AHP, marlin as MR, fs as FS, fields as F  # noqa: E402
+
+TAU, GAMMA = 0x1f3a9c5d7e2b4a6f8091a2b3c4d5e6f708192a3b4c5d6e7f, 0x5eed5eed5eed5eed0123456789abcdef
+ZK_SEED = bytes(range(32))
+
+CASES = [
+    # kind, num_constraints, num_variables   (src/test.rs:165-203 shapes + benches/bench.rs DummyCircuit)
+    ("test_circuit", 25, 25), ("test_circuit", 26, 25), ("test_circuit", 25, 26),
+    ("test_circuit", 100, 25), ("test_circuit", 25, 100),
+    ("dummy_circuit", 32, 10), ("dummy_circuit", 64, 10),
+]
+
+
+def build(kind, nc, nv):
+    rng = FS.test_rng()
+    a, b = FS.fr_rand(rng), FS.fr_rand(rng)
+    if kind == "test_circuit":
+        cs = AHP.finalize_test_circuit(AHP.test_circuit(a, b, nc, nv))
+        pub = [a * b % F.R_MOD, a * b % F.R_MOD * b % F.R_MOD]
+    else:
+        cs = AHP.dummy_circuit(a, b, nv, nc)
+        pub = [a * b % F.R_MOD]
+    cs = AHP.pad_and_square(cs)
+    return a, b, cs, pub
+
+
+def main():
+    out = {"tau": hex(TAU), "gamma": hex(GAMMA), "zk_seed": ZK_SEED.hex(), "zk_rng": "ChaCha20 (rand_chacha ChaChaRng::from_seed)",
+           "cases": []}
+    for kind, nc, nv in CASES:
+        a, b, cs, pub = build(kind, nc, nv)
+        nnz = 3 * max(nc, nv)
+        srs = MR.universal_setup(max(nc, nv), max(nc, nv), nnz, TAU, GAMMA)
+        pk = MR.marlin_index(srs, cs)
+        pr = MR.prove(pk, cs, FS.ChaChaRng(ZK_SEED, 20))
+        assert MR.verify(pk, pub, pr) and not MR.verify(pk, [a] * len(pub), pr)
+        pb = MR.proof_bytes(pr)
+        out["cases"].append({
+            "kind": kind, "num_constraints": nc, "num_variables": nv, "a": hex(a), "b": hex(b),
+            "H": pk.index.domain_h.size, "K": pk.index.domain_k.size, "srs_max_degree": srs.max_degree,
+            "vk_bytes_blake2s": hashlib.blake2s(MR.vk_bytes(pk)).hexdigest(),
+            "challenges": {k: hex(v) for k, v in pr.challenges.items()},
+            "evaluations": [hex(e) for e in pr.evaluations],
+            "proof_bytes": pb.hex(),
+        })
+        print(kind, nc, nv, "H", pk.index.domain_h.size, "K", pk.index.domain_k.size, len(pb), "bytes")
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "marlin_proofs.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
