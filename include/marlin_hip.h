@@ -88,6 +88,32 @@ int mh_msm_dev(uint64_t bases_handle, size_t base_offset, const void* d_scalars,
 /* Jacobian -> affine x||y (Montgomery) + infinity flag, on the host (GroupProjective::into_affine) */
 int mh_g1_to_affine(const uint64_t* xyz_mont, uint64_t* xy_mont_out, int* is_infinity_out);
 
+/* ---- Marlin index / prove with device-resident polynomials --------------------------------
+ * Host-side mirror of Marlin::<Fr, MarlinKZG10<Bls12_381>, SimpleHashFiatShamirRng<Blake2s,
+ * ChaChaRng>>::{index, prove} (src/lib.rs:100-148, 151-311).  The R1CS is given as the padded,
+ * square matrices ark-relations' `to_matrices()` yields after the reference's padding
+ * (src/ahp/constraint_systems.rs:45-81): CSR per matrix, columns = instance variables first
+ * (the formatted public input, leading 1 included, padded to a power of two), then witnesses. */
+typedef struct {
+  uint64_t num_constraints;        /* = number of variables (square) */
+  uint64_t num_instance;           /* formatted public inputs incl. the leading one; power of two */
+  const uint64_t* row_ptr[3];      /* A, B, C: row_ptr[k][num_constraints + 1] */
+  const uint32_t* col[3];          /* column indices */
+  const uint64_t* val[3];          /* Montgomery Fr coefficients, 4 limbs each; NULL = every coefficient is 1 */
+} mh_r1cs_matrices;
+/* srs_g: bases handle holding powers_of_g[0..=max_degree]; srs_gamma_g: >= 3 powers_of_gamma_g. */
+int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamma_g, uint64_t* pk_out);
+int mh_marlin_pk_free(uint64_t pk);
+/* info8: |H|, |K|, |X|, num_non_zero, index max_degree, srs max_degree, num_constraints, num_instance */
+int mh_marlin_pk_info(uint64_t pk, uint64_t* info8);
+/* IndexVerifierKey::write bytes (index_info || 6 index commitments); out may be NULL to query the length */
+int mh_marlin_vk_bytes(uint64_t pk, uint8_t* out, size_t cap, size_t* len_out);
+/* instance: num_instance Montgomery Fr (formatted input); witness: num_constraints - num_instance
+ * Montgomery Fr; zk_rng = rand_chacha ChaCha{8,12,20}Rng::from_seed(zk_seed).  proof_out receives
+ * the flat ToBytes-layout proof (9 commitments, 4 evaluations, 2 opening proofs; 2143 bytes). */
+int mh_marlin_prove(uint64_t pk, const uint64_t* instance_mont, const uint64_t* witness_mont, const uint8_t* zk_seed32,
+                    int zk_chacha_rounds, uint8_t* proof_out, size_t cap, size_t* len_out);
+
 /* ---- profiling: accumulated HIP-event time per kernel family on the library stream ----
  * family: 0 = ntt passes, 1 = msm (all stages), 2 = msm accum only, 3 = glue.  */
 int mh_prof_enable(int on);

@@ -1,6 +1,6 @@
 // libmarlin_hip.so -- C ABI entry points (include/marlin_hip.h) and the host-side
 // drivers that sequence the gfx950 kernels.
-#include "context.h"
+#include "drivers.h"
 #include "ff.cuh"
 #include "g1.cuh"
 #include "msm.cuh"
@@ -42,6 +42,8 @@ static int ensure_twiddles(Context& c, uint32_t log_n) {
   c.tw_log = want;
   return MH_OK;
 }
+
+int ensure_twiddles_public(Context& c, uint32_t log_n) { return ensure_twiddles(c, log_n); }
 
 static void plan_passes(uint32_t log_n, uint32_t* bits, int* npass) {
   int np = (int)((log_n + ntt::MAX_B - 1) / ntt::MAX_B);

@@ -1,0 +1,12 @@
+// Internal host-side drivers shared between translation units of libmarlin_hip.so.
+#pragma once
+#include "context.h"
+
+namespace mh {
+// NTT over Fr on device buffers (d_in may equal d_out); see ntt.cuh.
+int ntt_device(Context& c, const void* d_in, void* d_out, uint32_t log_n, int inverse);
+// MSM: d_bases = G1Affine[n] (Montgomery), d_scalars = Fr[n]; out = Jacobian X||Y||Z (18 u64, Montgomery).
+int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mont, size_t n, uint64_t* out_xyz);
+// twiddle table (tw[2^(l-1) + e] = omega_{2^l}^e) covering at least log_n levels
+int ensure_twiddles_public(Context& c, uint32_t log_n);
+}  // namespace mh

@@ -1,0 +1,768 @@
+// Marlin index + prove with every polynomial resident in HBM.
+//
+// Host-side mirror (C++, because no Rust toolchain exists in this image) of the reference's
+//   Marlin::index   /root/reference src/lib.rs:100-148  (+ src/ahp/indexer.rs:151-234,
+//                   src/ahp/constraint_systems.rs:125-262)
+//   Marlin::prove   /root/reference src/lib.rs:151-311  (+ src/ahp/prover.rs:211-706,
+//                   src/ahp/verifier.rs:44-188, src/ahp/mod.rs:110-221, src/rng.rs:54-79)
+// with PC = MarlinKZG10<Bls12_381> and FS = SimpleHashFiatShamirRng<Blake2s, ChaChaRng>
+// (src/test.rs:128-130).  Function names follow the reference.  The transcript, the
+// challenges and the 3-coefficient hiding polynomials live on the host; every O(n) object lives
+// on the device and is only ever touched by the kernels in ntt.cuh / msm.cuh / poly.cuh.
+#include <algorithm>
+#include <memory>
+#include "drivers.h"
+#include "ff.cuh"
+#include "fs_host.h"
+#include "g1.cuh"
+#include "host_ff.h"
+#include "poly.cuh"
+
+using namespace mh;
+using hostff::HFq;
+using hostff::HFr;
+using hostff::HG1;
+using hostff::HG1Affine;
+using poly::FrArg;
+
+namespace {
+
+inline Fr dfr(const HFr& h) { Fr r; memcpy(r.v, h.v, 32); return r; }
+inline FrArg arg(const HFr& h) { FrArg a; a.v = dfr(h); return a; }
+inline uint32_t log2u(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }
+inline uint64_t np2(uint64_t n) { return 1ull << log2u(n < 1 ? 1 : n); }
+
+struct DBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int alloc(size_t b) {
+    if (b == 0) b = 32;
+    hipError_t e = hipMalloc(&p, b);
+    if (e != hipSuccess) { p = nullptr; return fail(MH_ENOMEM, "hipMalloc failed in prover key allocation"); }
+    bytes = b;
+    return MH_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  Fr* fr() const { return (Fr*)p; }
+};
+
+struct Csr { DBuf row_ptr, col, val; bool has_val = false; uint64_t nnz = 0; };
+
+struct HidingRand { std::vector<HFr> blind; };          // kzg10::Randomness (blinding polynomial coeffs)
+struct PolyRand { HidingRand rand; bool has_shifted = false; HidingRand shifted; };   // marlin_pc::Randomness
+
+struct ProverKey {
+  uint64_t nc = 0, ni = 0, nnz = 0;         // constraints (= variables), formatted inputs, non-zeros of the joint matrix
+  uint64_t H = 0, K = 0, X = 0;
+  uint32_t logH = 0, logK = 0, logX = 0;
+  uint64_t srs_g = 0, srs_max_degree = 0, index_max_degree = 0;
+  HG1Affine gamma_g[3];
+  // index (device)
+  DBuf ev_row, ev_col, ev_row_col, ev_val_a, ev_val_b, ev_val_c;       // evals on K
+  DBuf p_row, p_col, p_a_val, p_b_val, p_c_val, p_row_col;            // coefficient form (K each)
+  Csr A, B;
+  DBuf t_items, t_erow, t_ecoef, t_item_ptr;
+  uint64_t t_nitems = 0; bool t_has_coef = false;
+  std::vector<fsh::Commitment> index_comms;
+  std::vector<uint8_t> vk_bytes;
+  // persistent polynomials of one proof + scratch
+  DBuf z, za_ev, zb_ev, xpoly, w, za, zb, mask, t, g1, h1, g2, h2, outer, inner;
+  DBuf S[8];
+  DBuf small;       // partial sums / carries
+  void free_all() {
+    DBuf* all[] = {&ev_row, &ev_col, &ev_row_col, &ev_val_a, &ev_val_b, &ev_val_c, &p_row, &p_col, &p_a_val, &p_b_val, &p_c_val,
+                   &p_row_col, &A.row_ptr, &A.col, &A.val, &B.row_ptr, &B.col, &B.val, &t_items, &t_erow, &t_ecoef, &t_item_ptr,
+                   &z, &za_ev, &zb_ev, &xpoly, &w, &za, &zb, &mask, &t, &g1, &h1, &g2, &h2, &outer, &inner, &small};
+    for (auto* b : all) b->release();
+    for (auto& s : S) s.release();
+  }
+};
+
+std::map<uint64_t, std::unique_ptr<ProverKey>> g_pks;
+uint64_t g_next_pk = 1;
+
+// ---- small launch helpers ------------------------------------------------------------------
+#define KLAUNCH(kern, n, ...)                                                                          \
+  do {                                                                                                 \
+    hipLaunchKernelGGL(kern, dim3(poly::grid_for(n)), dim3(poly::TPB), 0, c.stream, __VA_ARGS__);      \
+  } while (0)
+
+int zero_tail(Context& c, Fr* p, uint64_t from, uint64_t to) {
+  if (to > from) MH_HIP(hipMemsetAsync(p + from, 0, (to - from) * 32, c.stream));
+  return MH_OK;
+}
+int d2d(Context& c, Fr* dst, const Fr* src, uint64_t n) {
+  if (n) MH_HIP(hipMemcpyAsync(dst, src, n * 32, hipMemcpyDeviceToDevice, c.stream));
+  return MH_OK;
+}
+int h2d(Context& c, void* dst, const void* src, size_t bytes) {
+  if (bytes) MH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c.stream));
+  return MH_OK;
+}
+int set_fr(Context& c, Fr* dst, const HFr& v) {     // synchronous-safe: value copied from pageable host memory
+  MH_HIP(hipMemcpyAsync(dst, v.v, 32, hipMemcpyHostToDevice, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+int get_fr(Context& c, HFr* out, const Fr* src) {
+  MH_HIP(hipMemcpyAsync(out->v, src, 32, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+
+struct Term { const Fr* p; uint64_t len; HFr coef; };
+int lincomb(Context& c, Fr* out, uint64_t n, const std::vector<Term>& terms) {
+  poly::LinComb lc;
+  if (terms.size() > (size_t)poly::MAX_TERMS) return fail(MH_EINVAL, "lincomb: too many terms");
+  lc.nterms = (int)terms.size();
+  for (int j = 0; j < lc.nterms; j++) {
+    lc.src[j] = terms[j].p; lc.len[j] = terms[j].len; lc.coef[j] = dfr(terms[j].coef);
+    lc.is_one[j] = terms[j].coef == HFr::one();
+  }
+  ProfScope ps(c, PF_GLUE);
+  KLAUNCH(poly::lincomb_kernel, n, out, (u64)n, lc);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// p(z) for a device polynomial
+int eval_poly(Context& c, ProverKey& pk, const Fr* p, uint64_t len, const HFr& z, HFr* out) {
+  if (len == 0) { *out = HFr::zero(); return MH_OK; }
+  uint64_t nthreads = (len + poly::EV_CH - 1) / poly::EV_CH;
+  unsigned blocks = poly::grid_for(nthreads);
+  Fr* partial = pk.small.fr();
+  {
+    ProfScope ps(c, PF_GLUE);
+    hipLaunchKernelGGL(poly::eval_partial_kernel, dim3(blocks), dim3(poly::TPB), 0, c.stream, partial, p, (u64)len, arg(z));
+    hipLaunchKernelGGL(poly::sum_kernel, dim3(1), dim3(poly::TPB), 0, c.stream, partial + blocks, (const Fr*)partial, (u64)blocks);
+  }
+  MH_HIP(hipGetLastError());
+  return get_fr(c, out, partial + blocks);
+}
+
+// (q, -) = p / (X^n - 1); q gets len - n coefficients.  scratch: nchunks * n elements.
+int div_vanishing(Context& c, Fr* q, const Fr* p, uint64_t len, uint64_t n, Fr* scratch) {
+  if (len <= n) return MH_OK;
+  uint64_t nrows = (len + n - 1) / n;
+  uint64_t nchunks = (nrows - 1 + poly::DIV_ROWS - 1) / poly::DIV_ROWS;
+  ProfScope ps(c, PF_GLUE);
+  KLAUNCH(poly::divvan_partial_kernel, n * nchunks, scratch, p, (u64)len, (u64)n, (u64)nchunks);
+  KLAUNCH(poly::divvan_scan_kernel, n, scratch, (u64)n, (u64)nchunks);
+  KLAUNCH(poly::divvan_final_kernel, n * nchunks, q, (const Fr*)scratch, p, (u64)len, (u64)n, (u64)nchunks);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// q = (p - p(z)) / (X - z); q gets len - 1 coefficients.  scratch >= 2 * (len/64 + len/4096 + ...) elements
+int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* scratch) {
+  if (len <= 1) return MH_OK;
+  ProfScope ps(c, PF_GLUE);
+  // levels: A_0 = p; A_{j+1}[c] = Horner(A_j chunk c, m_j), m_0 = z, m_{j+1} = m_j^64
+  std::vector<const Fr*> A; std::vector<uint64_t> L; std::vector<HFr> M;
+  A.push_back(p); L.push_back(len); M.push_back(z);
+  Fr* cur = scratch;
+  std::vector<Fr*> V;      // V[j] = A_{j+1}
+  while (true) {
+    uint64_t n = L.back();
+    uint64_t nch = (n + poly::LIN_CH - 1) / poly::LIN_CH;
+    Fr* v = cur; cur += nch;
+    KLAUNCH(poly::divlin_chunk_kernel, nch, v, A.back(), (u64)n, arg(M.back()));
+    V.push_back(v);
+    HFr m = M.back();
+    for (int i = 0; i < 6; i++) m = m.sqr();     // ^64
+    A.push_back(v); L.push_back(nch); M.push_back(m);
+    if (nch <= 2048) break;
+  }
+  // top: carries into the chunks of the last A_j (j = A.size()-2) from A_{j+1} = V.back()
+  int top = (int)V.size() - 1;
+  std::vector<Fr*> C(V.size());
+  for (size_t j = 0; j < V.size(); j++) { C[j] = cur; cur += L[j + 1]; }
+  hipLaunchKernelGGL(poly::divlin_top_kernel, dim3(1), dim3(1), 0, c.stream, C[top], (const Fr*)V[top], (u64)L[top + 1], arg(M[top + 1]));
+  for (int j = top - 1; j >= 0; j--) {
+    // carries into chunks of A_j (count L[j+1]) from group carries C[j+1] (groups of 64 chunks), values V[j], multiplier M[j+1]
+    uint64_t ngroups = L[j + 2];
+    KLAUNCH(poly::divlin_expand_kernel, ngroups, C[j], (const Fr*)V[j], (const Fr*)C[j + 1], (u64)L[j + 1], arg(M[j + 1]));
+  }
+  KLAUNCH(poly::divlin_final_kernel, L[1], q, p, (const Fr*)C[0], (u64)len, arg(z));
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// affine normalisation of an MSM result
+HG1 jac_from(const uint64_t* xyz) { HG1 p; memcpy(p.X.v, xyz, 48); memcpy(p.Y.v, xyz + 6, 48); memcpy(p.Z.v, xyz + 12, 48); return p; }
+
+HG1 small_msm(const HG1Affine* bases, const std::vector<HFr>& scalars) {
+  HG1 acc = HG1::identity();
+  for (size_t i = 0; i < scalars.size(); i++) {
+    if (scalars[i].is_zero()) continue;
+    uint64_t k[4]; scalars[i].to_canonical(k);
+    acc = acc.add(HG1::from_affine(bases[i]).mul(k, 4));
+  }
+  return acc;
+}
+
+HFr host_eval(const std::vector<HFr>& p, const HFr& z) {
+  HFr acc = HFr::zero();
+  for (size_t i = p.size(); i-- > 0;) acc = acc * z + p[i];
+  return acc;
+}
+std::vector<HFr> host_div_linear(const std::vector<HFr>& p, const HFr& z) {
+  std::vector<HFr> q;
+  if (p.size() <= 1) return q;
+  q.resize(p.size() - 1);
+  HFr run = HFr::zero();
+  for (size_t i = p.size() - 1; i >= 1; i--) { run = p[i] + z * run; q[i - 1] = run; }
+  return q;
+}
+void host_axpy(std::vector<HFr>& acc, const HFr& f, const std::vector<HFr>& p) {
+  if (acc.size() < p.size()) acc.resize(p.size(), HFr::zero());
+  for (size_t i = 0; i < p.size(); i++) acc[i] = acc[i] + f * p[i];
+}
+bool host_is_zero(const std::vector<HFr>& p) { for (auto& x : p) if (!x.is_zero()) return false; return true; }
+
+// KZG10::commit (ark-poly-commit kzg10 [SURVEY B-3]): MSM over powers_of_g[offset..] plus, when hiding,
+// a fresh 3-coefficient blinding polynomial committed on powers_of_gamma_g.
+template <class Rng>
+int kzg_commit(Context& c, ProverKey& pk, const Fr* d_poly, uint64_t len, uint64_t offset, bool hiding, Rng* rng,
+               HG1Affine* out, HidingRand* rand_out) {
+  auto it = c.bases.find(pk.srs_g);
+  if (it == c.bases.end()) return fail(MH_EINVAL, "prover key refers to a freed SRS handle");
+  if (offset + len > it->second.n) return fail(MH_EINVAL, "polynomial degree exceeds the SRS");
+  uint64_t xyz[18];
+  MH_TRY(msm_device(c, (const char*)it->second.d_points + offset * 96, d_poly, 1, len, xyz));
+  HG1 comm = jac_from(xyz);
+  rand_out->blind.clear();
+  if (hiding) {
+    for (int i = 0; i < 3; i++) rand_out->blind.push_back(fsh::fr_rand(*rng));   // P::rand(hiding_bound + 1), hiding_bound = 1
+    comm = comm.add(small_msm(pk.gamma_g, rand_out->blind));
+  }
+  *out = comm.to_affine();
+  return MH_OK;
+}
+
+// MarlinKZG10::commit for one labeled polynomial [SURVEY B-4]
+template <class Rng>
+int marlin_commit(Context& c, ProverKey& pk, const Fr* d_poly, uint64_t len, bool has_bound, uint64_t bound, bool hiding,
+                  Rng* rng, fsh::Commitment* comm, PolyRand* rand) {
+  MH_TRY(kzg_commit(c, pk, d_poly, len, 0, hiding, rng, &comm->comm, &rand->rand));
+  comm->has_shifted = has_bound;
+  rand->has_shifted = has_bound;
+  if (has_bound) {
+    if (len > bound + 1) return fail(MH_EINVAL, "polynomial exceeds its degree bound");
+    MH_TRY(kzg_commit(c, pk, d_poly, len, pk.srs_max_degree - bound, hiding, rng, &comm->shifted, &rand->shifted));
+  }
+  return MH_OK;
+}
+
+uint64_t reindex_by_subdomain(uint64_t H, uint64_t X, uint64_t index) {
+  uint64_t period = H / X;
+  if (index < X) return index * period;
+  uint64_t i = index - X, x = period - 1;
+  return i + (i / x) + 1;
+}
+
+}  // namespace
+
+namespace mh {
+int ensure_twiddles_public(Context& c, uint32_t log_n);
+}
+
+// ===========================================================================================
+// C ABI
+// ===========================================================================================
+#define LOCKED_CTX()                                                 \
+  Context& c = ctx();                                                \
+  std::lock_guard<std::recursive_mutex> _lk(c.mu);                   \
+  if (!c.inited) return fail(MH_ENOINIT, "mh_init has not been called")
+
+extern "C" {
+
+int mh_marlin_pk_free(uint64_t pk_handle) {
+  LOCKED_CTX();
+  auto it = g_pks.find(pk_handle);
+  if (it == g_pks.end()) return fail(MH_EINVAL, "mh_marlin_pk_free: unknown handle");
+  MH_HIP(hipStreamSynchronize(c.stream));
+  it->second->free_all();
+  g_pks.erase(it);
+  return MH_OK;
+}
+
+// Marlin::index (lib.rs:100-148)
+int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamma_g, uint64_t* pk_out) {
+  LOCKED_CTX();
+  if (!m || !pk_out) return fail(MH_EINVAL, "mh_marlin_index: null pointer");
+  const uint64_t nc = m->num_constraints, ni = m->num_instance;
+  if (nc == 0 || ni == 0 || (ni & (ni - 1)) != 0 || ni > nc)
+    return fail(MH_EINVAL, "mh_marlin_index: num_instance must be a power of two <= num_constraints (InvalidPublicInputLength)");
+  for (int k = 0; k < 3; k++)
+    if (!m->row_ptr[k] || (m->row_ptr[k][nc] && !m->col[k])) return fail(MH_EINVAL, "mh_marlin_index: null matrix arrays");
+  auto sg = c.bases.find(srs_g), sgg = c.bases.find(srs_gamma_g);
+  if (sg == c.bases.end() || sgg == c.bases.end()) return fail(MH_EINVAL, "mh_marlin_index: unknown SRS handle");
+  if (sgg->second.n < 3) return fail(MH_EINVAL, "mh_marlin_index: powers_of_gamma_g needs >= 3 points");
+
+  std::unique_ptr<ProverKey> pkp(new ProverKey());
+  ProverKey& pk = *pkp;
+  pk.nc = nc; pk.ni = ni;
+  pk.srs_g = srs_g; pk.srs_max_degree = sg->second.n - 1;
+  {
+    uint64_t gg[36];
+    MH_HIP(hipMemcpy(gg, sgg->second.d_points, 3 * 96, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; i++) { memcpy(pk.gamma_g[i].x.v, gg + 12 * i, 48); memcpy(pk.gamma_g[i].y.v, gg + 12 * i + 6, 48); pk.gamma_g[i].inf = false; }
+  }
+  // ---- joint matrix (indexer.rs:83-102): per row, sorted union of the column sets --------------------
+  std::vector<uint64_t> jptr(nc + 1, 0);
+  std::vector<uint32_t> jcol;
+  for (uint64_t r = 0; r < nc; r++) {
+    std::vector<uint32_t> cols;
+    for (int k = 0; k < 3; k++)
+      for (uint64_t e = m->row_ptr[k][r]; e < m->row_ptr[k][r + 1]; e++) {
+        if (m->col[k][e] >= nc) return fail(MH_EINVAL, "mh_marlin_index: column index out of range (NonSquareMatrix)");
+        cols.push_back(m->col[k][e]);
+      }
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    jcol.insert(jcol.end(), cols.begin(), cols.end());
+    jptr[r + 1] = jcol.size();
+  }
+  pk.nnz = jcol.size();
+  pk.H = np2(nc); pk.K = np2(pk.nnz); pk.X = ni;
+  pk.logH = log2u(pk.H); pk.logK = log2u(pk.K); pk.logX = log2u(pk.X);
+  const uint64_t H = pk.H, K = pk.K, X = pk.X;
+  if (pk.logK + 1 > 32) return fail(MH_EINVAL, "PolynomialDegreeTooLarge");
+  // AHPForR1CS::max_degree (mod.rs:71-93)
+  pk.index_max_degree = std::max(std::max(2 * H + 1 - 2, 3 * H + 2 - 3), std::max(H, K - 1));
+  if (pk.srs_max_degree < pk.index_max_degree) return fail(MH_EINVAL, "IndexTooLarge: SRS max degree below the index's");
+  if (K - 2 > pk.srs_max_degree) return fail(MH_EINVAL, "IndexTooLarge");
+
+  // ---- arithmetize_matrix (constraint_systems.rs:125-262) on the host ---------------------------------
+  // val_M(k) = M[r][i] * u_H(col_val, col_val)^-1 = M[r][i] * col_val / |H|   (col_val^|H| = 1)
+  std::vector<HFr> elems(H);
+  {
+    HFr w = hostff::fr_two_adic_root();
+    for (uint32_t i = pk.logH; i < 32; i++) w = w.sqr();
+    HFr x = HFr::one();
+    for (uint64_t i = 0; i < H; i++) { elems[i] = x; x = x * w; }
+  }
+  const HFr h_inv = HFr::from_u64(H).inv();
+  std::vector<uint64_t> row_v(K * 4), col_v(K * 4), rc_v(K * 4), va(K * 4, 0), vb(K * 4, 0), vc(K * 4, 0);
+  {
+    uint64_t k = 0;
+    std::vector<uint64_t>* vals[3] = {&va, &vb, &vc};
+    for (uint64_t r = 0; r < nc; r++) {
+      uint64_t pos[3] = {m->row_ptr[0][r], m->row_ptr[1][r], m->row_ptr[2][r]};
+      for (uint64_t e = jptr[r]; e < jptr[r + 1]; e++, k++) {
+        uint32_t i = jcol[e];
+        const HFr& col_val = elems[reindex_by_subdomain(H, X, i)];
+        const HFr& row_val = elems[r];
+        memcpy(&row_v[4 * k], col_val.v, 32);       // transpose: row <- column element
+        memcpy(&col_v[4 * k], row_val.v, 32);
+        HFr rc = col_val * row_val;
+        memcpy(&rc_v[4 * k], rc.v, 32);
+        HFr scale = col_val * h_inv;
+        for (int q = 0; q < 3; q++) {
+          // entries of a row may be unsorted / repeated: sum all entries of matrix q at (r, i)
+          HFr acc = HFr::zero(); bool any = false;
+          for (uint64_t ee = m->row_ptr[q][r]; ee < m->row_ptr[q][r + 1]; ee++)
+            if (m->col[q][ee] == i) {
+              HFr v = HFr::one();
+              if (m->val[q]) memcpy(v.v, m->val[q] + 4 * ee, 32);
+              acc = acc + v; any = true;
+            }
+          (void)pos;
+          if (any) { HFr v = acc * scale; memcpy(&(*vals[q])[4 * k], v.v, 32); }
+        }
+      }
+    }
+    HFr e0sq = elems[0] * elems[0];
+    for (; k < K; k++) { memcpy(&row_v[4 * k], elems[0].v, 32); memcpy(&col_v[4 * k], elems[0].v, 32); memcpy(&rc_v[4 * k], e0sq.v, 32); }
+  }
+  DBuf* evs[6] = {&pk.ev_row, &pk.ev_col, &pk.ev_val_a, &pk.ev_val_b, &pk.ev_val_c, &pk.ev_row_col};
+  DBuf* pls[6] = {&pk.p_row, &pk.p_col, &pk.p_a_val, &pk.p_b_val, &pk.p_c_val, &pk.p_row_col};   // INDEXER_POLYNOMIALS order
+  std::vector<uint64_t>* hv[6] = {&row_v, &col_v, &va, &vb, &vc, &rc_v};
+  for (int q = 0; q < 6; q++) {
+    MH_TRY(evs[q]->alloc(K * 32)); MH_TRY(pls[q]->alloc(K * 32));
+    MH_TRY(h2d(c, evs[q]->p, hv[q]->data(), K * 32));
+    MH_TRY(ntt_device(c, evs[q]->p, pls[q]->p, pk.logK, 1));          // interpolate (constraint_systems.rs:234-239)
+  }
+  MH_HIP(hipStreamSynchronize(c.stream));
+  // ---- index commitments: PC::commit(ck, index.iter(), None) (lib.rs:123-126) ----------------------------
+  pk.index_comms.resize(6);
+  for (int q = 0; q < 6; q++) {
+    uint64_t xyz[18];
+    MH_TRY(msm_device(c, sg->second.d_points, pls[q]->p, 1, K, xyz));
+    pk.index_comms[q].comm = jac_from(xyz).to_affine();
+    pk.index_comms[q].has_shifted = false;
+  }
+  // IndexVerifierKey::write (data_structures.rs:36-43)
+  fsh::put_u64(pk.vk_bytes, nc); fsh::put_u64(pk.vk_bytes, nc); fsh::put_u64(pk.vk_bytes, pk.nnz);
+  for (auto& cm : pk.index_comms) fsh::put_commitment(pk.vk_bytes, cm);
+
+  // ---- matrices on the device: CSR A, B for z_A, z_B (prover.rs:256-276) -------------------------------
+  Csr* cs[2] = {&pk.A, &pk.B};
+  for (int q = 0; q < 2; q++) {
+    uint64_t nz = m->row_ptr[q][nc];
+    cs[q]->nnz = nz;
+    MH_TRY(cs[q]->row_ptr.alloc((nc + 1) * 8)); MH_TRY(h2d(c, cs[q]->row_ptr.p, m->row_ptr[q], (nc + 1) * 8));
+    MH_TRY(cs[q]->col.alloc(nz * 4)); MH_TRY(h2d(c, cs[q]->col.p, m->col[q], nz * 4));
+    cs[q]->has_val = m->val[q] != nullptr;
+    if (cs[q]->has_val) { MH_TRY(cs[q]->val.alloc(nz * 32)); MH_TRY(h2d(c, cs[q]->val.p, m->val[q], nz * 32)); }
+  }
+  // ---- calculate_t structure (prover.rs:411-428): entries grouped by output index, then by matrix ----------
+  {
+    uint64_t total = m->row_ptr[0][nc] + m->row_ptr[1][nc] + m->row_ptr[2][nc];
+    pk.t_has_coef = m->val[0] || m->val[1] || m->val[2];
+    // counting sort by key = (k, matrix)
+    std::vector<uint64_t> cnt(3 * H + 1, 0);
+    for (int q = 0; q < 3; q++)
+      for (uint64_t e = 0; e < m->row_ptr[q][nc]; e++) cnt[3 * reindex_by_subdomain(H, X, m->col[q][e]) + q + 1]++;
+    for (uint64_t i = 0; i < 3 * H; i++) cnt[i + 1] += cnt[i];
+    std::vector<uint32_t> erow(total);
+    std::vector<uint64_t> ecoef(pk.t_has_coef ? total * 4 : 0);
+    std::vector<uint64_t> cursor(cnt.begin(), cnt.end() - 1);
+    for (int q = 0; q < 3; q++)
+      for (uint64_t r = 0; r < nc; r++)
+        for (uint64_t e = m->row_ptr[q][r]; e < m->row_ptr[q][r + 1]; e++) {
+          uint64_t key = 3 * reindex_by_subdomain(H, X, m->col[q][e]) + q;
+          uint64_t pos = cursor[key]++;
+          erow[pos] = (uint32_t)r;
+          if (pk.t_has_coef) { if (m->val[q]) memcpy(&ecoef[4 * pos], m->val[q] + 4 * e, 32); else memcpy(&ecoef[4 * pos], HFr::one().v, 32); }
+        }
+    std::vector<poly::TItem> items;
+    std::vector<uint64_t> item_ptr(H + 1, 0);
+    const uint32_t ITEM = 128;
+    for (uint64_t k = 0; k < H; k++) {
+      item_ptr[k] = items.size();
+      for (int q = 0; q < 3; q++) {
+        uint64_t lo = cnt[3 * k + q], hi = cnt[3 * k + q + 1];
+        for (uint64_t s = lo; s < hi; s += ITEM) {
+          poly::TItem it; it.first = s; it.count = (uint32_t)std::min<uint64_t>(ITEM, hi - s); it.k = (uint32_t)k; it.m = q; it.pad = 0;
+          items.push_back(it);
+        }
+      }
+    }
+    item_ptr[H] = items.size();
+    pk.t_nitems = items.size();
+    MH_TRY(pk.t_items.alloc(items.size() * sizeof(poly::TItem))); MH_TRY(h2d(c, pk.t_items.p, items.data(), items.size() * sizeof(poly::TItem)));
+    MH_TRY(pk.t_erow.alloc(total * 4)); MH_TRY(h2d(c, pk.t_erow.p, erow.data(), total * 4));
+    if (pk.t_has_coef) { MH_TRY(pk.t_ecoef.alloc(total * 32)); MH_TRY(h2d(c, pk.t_ecoef.p, ecoef.data(), total * 32)); }
+    MH_TRY(pk.t_item_ptr.alloc((H + 1) * 8)); MH_TRY(h2d(c, pk.t_item_ptr.p, item_ptr.data(), (H + 1) * 8));
+    MH_HIP(hipStreamSynchronize(c.stream));
+  }
+  // ---- workspace ------------------------------------------------------------------------------------------------
+  const uint64_t big = std::max<uint64_t>(2 * K, 4 * H) + 64;
+  MH_TRY(pk.z.alloc(H * 32)); MH_TRY(pk.za_ev.alloc(H * 32)); MH_TRY(pk.zb_ev.alloc(H * 32)); MH_TRY(pk.xpoly.alloc((X + 8) * 32));
+  MH_TRY(pk.w.alloc((H + 8) * 32)); MH_TRY(pk.za.alloc((H + 8) * 32)); MH_TRY(pk.zb.alloc((H + 8) * 32));
+  MH_TRY(pk.mask.alloc((3 * H + 8) * 32)); MH_TRY(pk.t.alloc(H * 32)); MH_TRY(pk.g1.alloc(H * 32)); MH_TRY(pk.h1.alloc((3 * H + 8) * 32));
+  MH_TRY(pk.g2.alloc(K * 32)); MH_TRY(pk.h2.alloc(K * 32)); MH_TRY(pk.outer.alloc((3 * H + 8) * 32)); MH_TRY(pk.inner.alloc(K * 32));
+  for (auto& s : pk.S) MH_TRY(s.alloc(big * 32));
+  MH_TRY(pk.small.alloc((big / 8 + pk.t_nitems + 4096) * 32));
+  MH_TRY(ensure_twiddles_public(c, std::max(pk.logK + 1, pk.logH + 2)));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  uint64_t h = g_next_pk++;
+  g_pks[h] = std::move(pkp);
+  *pk_out = h;
+  return MH_OK;
+}
+
+int mh_marlin_pk_info(uint64_t pk_handle, uint64_t* info8) {
+  LOCKED_CTX();
+  auto it = g_pks.find(pk_handle);
+  if (it == g_pks.end() || !info8) return fail(MH_EINVAL, "mh_marlin_pk_info: bad argument");
+  ProverKey& pk = *it->second;
+  info8[0] = pk.H; info8[1] = pk.K; info8[2] = pk.X; info8[3] = pk.nnz; info8[4] = pk.index_max_degree;
+  info8[5] = pk.srs_max_degree; info8[6] = pk.nc; info8[7] = pk.ni;
+  return MH_OK;
+}
+
+int mh_marlin_vk_bytes(uint64_t pk_handle, uint8_t* out, size_t cap, size_t* len_out) {
+  LOCKED_CTX();
+  auto it = g_pks.find(pk_handle);
+  if (it == g_pks.end()) return fail(MH_EINVAL, "mh_marlin_vk_bytes: unknown handle");
+  if (len_out) *len_out = it->second->vk_bytes.size();
+  if (out) {
+    if (cap < it->second->vk_bytes.size()) return fail(MH_EINVAL, "mh_marlin_vk_bytes: buffer too small");
+    memcpy(out, it->second->vk_bytes.data(), it->second->vk_bytes.size());
+  }
+  return MH_OK;
+}
+
+// Marlin::prove (lib.rs:151-311).  instance: formatted public input (X elements, leading one included);
+// witness: nc - X elements (padding witnesses included).  zk_rng = ChaCha(zk_seed, rounds) drawn in the
+// order of SURVEY.md Appendix C.  proof_out: the flat ToBytes-layout proof.
+int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, const uint8_t* zk_seed,
+                    int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out) {
+  LOCKED_CTX();
+  auto pit = g_pks.find(pk_handle);
+  if (pit == g_pks.end()) return fail(MH_EINVAL, "mh_marlin_prove: unknown prover key");
+  if (!instance || !witness || !zk_seed || !proof_out) return fail(MH_EINVAL, "mh_marlin_prove: null pointer");
+  if (zk_rounds != 8 && zk_rounds != 12 && zk_rounds != 20) return fail(MH_EINVAL, "mh_marlin_prove: ChaCha rounds must be 8, 12 or 20");
+  ProverKey& pk = *pit->second;
+  const uint64_t H = pk.H, K = pk.K, X = pk.X, nc = pk.nc;
+  const uint64_t nw = nc - X;
+  const uint32_t lgH = pk.logH, lgK = pk.logK, lgX = pk.logX;
+  fsh::ChaChaRng zk(zk_seed, zk_rounds);
+  Fr** Sp = nullptr; (void)Sp;
+  Fr* S[8]; for (int i = 0; i < 8; i++) S[i] = pk.S[i].fr();
+  const Fr* tw = (const Fr*)c.tw;
+
+  // ---------------- prover_init (prover.rs:211-306): z = x || w, z_A = A z, z_B = B z --------------------
+  MH_TRY(h2d(c, pk.z.fr(), instance, X * 32));
+  MH_TRY(h2d(c, pk.z.fr() + X, witness, nw * 32));
+  {
+    ProfScope ps(c, PF_GLUE);
+    KLAUNCH(poly::spmv_kernel, nc, pk.za_ev.fr(), (const u64*)pk.A.row_ptr.p, (const u32*)pk.A.col.p,
+            pk.A.has_val ? (const Fr*)pk.A.val.p : (const Fr*)nullptr, (const Fr*)pk.z.fr(), (u64)nc);
+    KLAUNCH(poly::spmv_kernel, nc, pk.zb_ev.fr(), (const u64*)pk.B.row_ptr.p, (const u32*)pk.B.col.p,
+            pk.B.has_val ? (const Fr*)pk.B.val.p : (const Fr*)nullptr, (const Fr*)pk.z.fr(), (u64)nc);
+  }
+  MH_TRY(zero_tail(c, pk.za_ev.fr(), nc, H)); MH_TRY(zero_tail(c, pk.zb_ev.fr(), nc, H));
+  std::vector<HFr> pub(X - 1);                      // public_input() = formatted input without the leading one
+  for (uint64_t i = 1; i < X; i++) memcpy(pub[i - 1].v, instance + 4 * i, 32);
+  fsh::FiatShamirRng fs;
+  {
+    std::vector<uint8_t> init; const char* name = "MARLIN-2019";
+    init.insert(init.end(), name, name + 11);
+    init.insert(init.end(), pk.vk_bytes.begin(), pk.vk_bytes.end());
+    for (auto& x : pub) fsh::put_fr(init, x);
+    fs.initialize(init);                                  // lib.rs:161-163
+  }
+
+  // ---------------- first round (prover.rs:309-409) -----------------------------------------------------------
+  MH_TRY(ntt_device(c, pk.z.fr(), pk.xpoly.fr(), lgX, 1));              // x_poly = interpolate(formatted input)
+  MH_TRY(d2d(c, S[0], pk.xpoly.fr(), X)); MH_TRY(zero_tail(c, S[0], X, H));
+  MH_TRY(ntt_device(c, S[0], S[1], lgH, 0));                            // x_evals = domain_h.fft(x_poly)
+  { ProfScope ps(c, PF_GLUE);
+    KLAUNCH(poly::w_evals_kernel, H, S[2], (const Fr*)(pk.z.fr() + X), (u64)nw, (const Fr*)S[1], (u64)H, (u64)(H / X)); }
+  MH_TRY(ntt_device(c, S[2], S[3], lgH, 1));
+  // + r * v_H: the reference multiplies by FFT (prover.rs:352); the product is exactly [-r, 0.., 0, r]
+  HFr r_w = fsh::fr_rand(zk);
+  {
+    HFr c0; MH_TRY(get_fr(c, &c0, S[3])); c0 = c0 - r_w;
+    MH_TRY(set_fr(c, S[3], c0)); MH_TRY(set_fr(c, S[3] + H, r_w));
+  }
+  const uint64_t w_len = H + 1 - X;                                       // (w + r v_H) / v_X, remainder zero
+  MH_TRY(div_vanishing(c, pk.w.fr(), S[3], H + 1, X, S[4]));
+  auto blind_h = [&](Fr* dst, const Fr* evals, HFr* r_out) -> int {
+    MH_TRY(ntt_device(c, evals, dst, lgH, 1));
+    HFr r = fsh::fr_rand(zk); *r_out = r;
+    HFr c0; MH_TRY(get_fr(c, &c0, dst)); c0 = c0 - r;
+    MH_TRY(set_fr(c, dst, c0)); MH_TRY(set_fr(c, dst + H, r));
+    return MH_OK;
+  };
+  HFr r_za, r_zb;
+  MH_TRY(blind_h(pk.za.fr(), pk.za_ev.fr(), &r_za));
+  MH_TRY(blind_h(pk.zb.fr(), pk.zb_ev.fr(), &r_zb));
+  const uint64_t za_len = H + 1;
+  // mask polynomial (prover.rs:369-381): 3H sequential draws, then force sum over H to zero
+  const uint64_t mask_len = 3 * H;          // degree 3H + 2*zk_bound - 3
+  {
+    std::vector<uint64_t> hm(mask_len * 4);
+    for (uint64_t i = 0; i < mask_len; i++) { HFr v = fsh::fr_rand(zk); memcpy(&hm[4 * i], v.v, 32); }
+    HFr r0 = HFr::zero();
+    for (uint64_t i = 0; i <= (mask_len - 1) / H; i++) { HFr v; memcpy(v.v, &hm[4 * H * i], 32); r0 = r0 + v; }
+    HFr m0; memcpy(m0.v, &hm[0], 32); m0 = m0 - r0; memcpy(&hm[0], m0.v, 32);
+    MH_HIP(hipMemcpyAsync(pk.mask.fr(), hm.data(), mask_len * 32, hipMemcpyHostToDevice, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));
+  }
+  // PC::commit first round (lib.rs:172): w, z_a, z_b hiding 1; mask none
+  fsh::Commitment c_w, c_za, c_zb, c_mask; PolyRand rd_w, rd_za, rd_zb, rd_mask;
+  MH_TRY(marlin_commit(c, pk, pk.w.fr(), w_len, false, 0, true, &zk, &c_w, &rd_w));
+  MH_TRY(marlin_commit(c, pk, pk.za.fr(), za_len, false, 0, true, &zk, &c_za, &rd_za));
+  MH_TRY(marlin_commit(c, pk, pk.zb.fr(), za_len, false, 0, true, &zk, &c_zb, &rd_zb));
+  MH_TRY(marlin_commit(c, pk, pk.mask.fr(), mask_len, false, 0, false, &zk, &c_mask, &rd_mask));
+  {
+    std::vector<uint8_t> b;
+    fsh::put_commitment(b, c_w); fsh::put_commitment(b, c_za); fsh::put_commitment(b, c_zb); fsh::put_commitment(b, c_mask);
+    fs.absorb(b);                                                            // lib.rs:180
+  }
+  // verifier_first_round (verifier.rs:44-79)
+  auto v_h = [&](const HFr& x) { return x.pow_u64(H) - HFr::one(); };
+  HFr alpha = fs.rand_fr();
+  while (v_h(alpha).is_zero()) alpha = fs.rand_fr();
+  HFr eta_a = fs.rand_fr(), eta_b = fs.rand_fr(), eta_c = fs.rand_fr();
+
+  // ---------------- second round (prover.rs:443-570) ---------------------------------------------------------
+  const uint32_t lg4H = lgH + 2; const uint64_t H4 = 4 * H;
+  MH_TRY(d2d(c, S[2], pk.za.fr(), za_len)); MH_TRY(zero_tail(c, S[2], za_len, H4));
+  MH_TRY(d2d(c, S[3], pk.zb.fr(), za_len)); MH_TRY(zero_tail(c, S[3], za_len, H4));
+  MH_TRY(ntt_device(c, S[2], S[0], lg4H, 0));
+  MH_TRY(ntt_device(c, S[3], S[1], lg4H, 0));
+  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_kernel, H4, S[0], (const Fr*)S[0], (const Fr*)S[1], (u64)H4); }
+  MH_TRY(ntt_device(c, S[0], S[2], lg4H, 1));                               // z_c = z_a * z_b  (2H+1 coefficients)
+  const uint64_t zc_len = 2 * H + 1;
+  MH_TRY(lincomb(c, S[3], zc_len, {{S[2], zc_len, eta_c}, {pk.za.fr(), za_len, eta_a}, {pk.zb.fr(), za_len, eta_b}}));   // summed_z_m
+  // r_alpha_x evals on H (mod.rs:311-318)
+  HFr vH_alpha = v_h(alpha);
+  { ProfScope ps(c, PF_GLUE);
+    KLAUNCH(poly::x_minus_elements_kernel, H, S[4], tw, arg(alpha), lgH);
+    KLAUNCH(poly::batch_inverse_kernel, (H + poly::INV_CH - 1) / poly::INV_CH, S[4], S[5], (u64)H, arg(vH_alpha), 1); }
+  MH_TRY(ntt_device(c, S[4], S[5], lgH, 1));                                 // r_alpha_poly
+  // t (prover.rs:411-428)
+  { ProfScope ps(c, PF_GLUE);
+    Fr* partial = pk.small.fr();
+    KLAUNCH(poly::t_items_kernel, pk.t_nitems, partial, (const poly::TItem*)pk.t_items.p, (u64)pk.t_nitems, (const u32*)pk.t_erow.p,
+            pk.t_has_coef ? (const Fr*)pk.t_ecoef.p : (const Fr*)nullptr, (const Fr*)S[4], arg(eta_a), arg(eta_b), arg(eta_c));
+    KLAUNCH(poly::t_sum_kernel, H, S[6], (const Fr*)partial, (const u64*)pk.t_item_ptr.p, (u64)H); }
+  MH_TRY(ntt_device(c, S[6], pk.t.fr(), lgH, 1));
+  // z = w * v_X + x  (prover.rs:503-516)
+  const uint64_t z_len = w_len + X;
+  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::z_poly_kernel, z_len, S[7], (const Fr*)pk.w.fr(), (u64)w_len, (u64)X, (const Fr*)pk.xpoly.fr(), (u64)X); }
+  // q_1 (prover.rs:520-547): four forward transforms on the 4H domain, pointwise, one inverse
+  MH_TRY(zero_tail(c, S[5], H, H4)); MH_TRY(ntt_device(c, S[5], S[0], lg4H, 0));         // r_alpha
+  MH_TRY(zero_tail(c, S[3], zc_len, H4)); MH_TRY(ntt_device(c, S[3], S[1], lg4H, 0));    // summed_z_m
+  MH_TRY(zero_tail(c, S[7], z_len, H4)); MH_TRY(ntt_device(c, S[7], S[2], lg4H, 0));     // z
+  MH_TRY(d2d(c, S[6], pk.t.fr(), H)); MH_TRY(zero_tail(c, S[6], H, H4)); MH_TRY(ntt_device(c, S[6], S[4], lg4H, 0));   // t
+  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_sub_mul_kernel, H4, S[0], (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2], (const Fr*)S[4], (u64)H4); }
+  MH_TRY(ntt_device(c, S[0], S[1], lg4H, 1));                                  // rhs
+  MH_TRY(lincomb(c, S[2], H4, {{pk.mask.fr(), mask_len, HFr::one()}, {S[1], H4, HFr::one()}}));      // q_1 = mask + rhs
+  // (h_1, x g_1) = q_1 / v_H (prover.rs:550-551)
+  MH_TRY(div_vanishing(c, pk.h1.fr(), S[2], H4, H, S[3]));
+  const uint64_t h1_len = 2 * H;                                                // deg <= 2H + 2*zk_bound - 2 - ... (upper H coefficients are zero)
+  MH_TRY(lincomb(c, S[4], H, {{S[2], H, HFr::one()}, {pk.h1.fr(), H, HFr::one()}}));   // remainder = x g_1
+  MH_TRY(d2d(c, pk.g1.fr(), S[4] + 1, H - 1));
+  const uint64_t g1_len = H - 1;
+  fsh::Commitment c_t, c_g1, c_h1; PolyRand rd_t, rd_g1, rd_h1;
+  MH_TRY(marlin_commit(c, pk, pk.t.fr(), H, false, 0, false, &zk, &c_t, &rd_t));
+  MH_TRY(marlin_commit(c, pk, pk.g1.fr(), g1_len, true, H - 2, true, &zk, &c_g1, &rd_g1));
+  MH_TRY(marlin_commit(c, pk, pk.h1.fr(), h1_len, false, 0, false, &zk, &c_h1, &rd_h1));
+  {
+    std::vector<uint8_t> b;
+    fsh::put_commitment(b, c_t); fsh::put_commitment(b, c_g1); fsh::put_commitment(b, c_h1);
+    fs.absorb(b);                                                               // lib.rs:201
+  }
+  HFr beta = fs.rand_fr();
+  while (v_h(beta).is_zero()) beta = fs.rand_fr();                              // verifier.rs:82-91
+
+  // ---------------- third round (prover.rs:588-706) ----------------------------------------------------------
+  const uint32_t lg2K = lgK + 1; const uint64_t K2 = 2 * K;
+  HFr vH_beta = v_h(beta);
+  HFr vv = vH_alpha * vH_beta;
+  HFr ea = eta_a * vv, eb = eta_b * vv, ec = eta_c * vv;
+  MH_TRY(lincomb(c, S[0], K, {{pk.p_a_val.fr(), K, ea}, {pk.p_b_val.fr(), K, eb}, {pk.p_c_val.fr(), K, ec}}));    // a_poly
+  HFr alpha_beta = alpha * beta;
+  { ProfScope ps(c, PF_GLUE);
+    KLAUNCH(poly::b_evals_kernel, K, S[1], (const Fr*)pk.ev_row.p, (const Fr*)pk.ev_col.p, (const Fr*)pk.ev_row_col.p, arg(alpha), arg(beta), arg(alpha_beta), (u64)K); }
+  MH_TRY(ntt_device(c, S[1], S[2], lgK, 1));                                    // b_poly
+  { ProfScope ps(c, PF_GLUE);
+    KLAUNCH(poly::denom_kernel, K, S[1], (const Fr*)pk.ev_row.p, (const Fr*)pk.ev_col.p, arg(alpha), arg(beta), (u64)K);
+    KLAUNCH(poly::batch_inverse_kernel, (K + poly::INV_CH - 1) / poly::INV_CH, S[1], S[3], (u64)K, arg(HFr::one()), 0);
+    KLAUNCH(poly::f_evals_kernel, K, S[3], (const Fr*)S[1], (const Fr*)pk.ev_val_a.p, (const Fr*)pk.ev_val_b.p, (const Fr*)pk.ev_val_c.p, arg(ea), arg(eb), arg(ec), (u64)K); }
+  MH_TRY(ntt_device(c, S[3], S[4], lgK, 1));                                    // f
+  MH_TRY(d2d(c, pk.g2.fr(), S[4] + 1, K - 1));                                  // g_2 = f / X
+  const uint64_t g2_len = K - 1;
+  MH_TRY(zero_tail(c, S[2], K, K2)); MH_TRY(ntt_device(c, S[2], S[5], lg2K, 0));
+  MH_TRY(zero_tail(c, S[4], K, K2)); MH_TRY(ntt_device(c, S[4], S[6], lg2K, 0));
+  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_kernel, K2, S[5], (const Fr*)S[5], (const Fr*)S[6], (u64)K2); }
+  MH_TRY(ntt_device(c, S[5], S[6], lg2K, 1));                                   // b * f
+  HFr minus_one = HFr::one().neg();
+  MH_TRY(lincomb(c, S[5], K2, {{S[0], K, HFr::one()}, {S[6], K2, minus_one}}));    // a - b f
+  MH_TRY(div_vanishing(c, pk.h2.fr(), S[5], K2, K, S[7]));                         // h_2
+  const uint64_t h2_len = K - 1;
+  fsh::Commitment c_g2, c_h2; PolyRand rd_g2, rd_h2;
+  MH_TRY(marlin_commit(c, pk, pk.g2.fr(), g2_len, true, K - 2, false, &zk, &c_g2, &rd_g2));
+  MH_TRY(marlin_commit(c, pk, pk.h2.fr(), h2_len, false, 0, false, &zk, &c_h2, &rd_h2));
+  {
+    std::vector<uint8_t> b;
+    fsh::put_commitment(b, c_g2); fsh::put_commitment(b, c_h2);
+    fs.absorb(b);                                                                // lib.rs:221
+  }
+  HFr gamma = fs.rand_fr();                                                      // verifier.rs:94-100
+
+  // ---------------- evaluations (lib.rs:272-287): g_1, g_2, t, z_b in label order ---------------------------
+  HFr g1_beta, g2_gamma, t_beta, zb_beta;
+  MH_TRY(eval_poly(c, pk, pk.g1.fr(), g1_len, beta, &g1_beta));
+  MH_TRY(eval_poly(c, pk, pk.g2.fr(), g2_len, gamma, &g2_gamma));
+  MH_TRY(eval_poly(c, pk, pk.t.fr(), H, beta, &t_beta));
+  MH_TRY(eval_poly(c, pk, pk.zb.fr(), za_len, beta, &zb_beta));
+  {
+    std::vector<uint8_t> b;
+    fsh::put_fr(b, g1_beta); fsh::put_fr(b, g2_gamma); fsh::put_fr(b, t_beta); fsh::put_fr(b, zb_beta);
+    fs.absorb(b);                                                                // lib.rs:289
+  }
+  HFr xi = fs.rand_u128_as_fr();                                                 // lib.rs:290
+
+  // ---------------- construct_linear_combinations (mod.rs:110-221) --------------------------------------------
+  // r_alpha(beta) = (v_H(alpha) - v_H(beta)) / (alpha - beta)
+  HFr r_ab = (alpha == beta) ? HFr::from_u64(H) * alpha.pow_u64(H - 1) : (vH_alpha - vH_beta) * (alpha - beta).inv();
+  HFr vX_beta = beta.pow_u64(X) - HFr::one();
+  HFr vK_gamma = gamma.pow_u64(K) - HFr::one();
+  HFr c_za_lc = r_ab * (eta_a + eta_c * zb_beta);
+  HFr c_w_lc = (t_beta * vX_beta).neg();
+  HFr c_h1_lc = vH_beta.neg();
+  MH_TRY(lincomb(c, pk.outer.fr(), mask_len, {{pk.mask.fr(), mask_len, HFr::one()}, {pk.za.fr(), za_len, c_za_lc},
+                                               {pk.w.fr(), w_len, c_w_lc}, {pk.h1.fr(), h1_len, c_h1_lc}}));
+  HFr mult = gamma * g2_gamma + t_beta * HFr::from_u64(K).inv();
+  MH_TRY(lincomb(c, pk.inner.fr(), K, {{pk.p_a_val.fr(), K, ea}, {pk.p_b_val.fr(), K, eb}, {pk.p_c_val.fr(), K, ec},
+                                       {pk.p_row.fr(), K, alpha * mult}, {pk.p_col.fr(), K, beta * mult}, {pk.p_row_col.fr(), K, mult.neg()},
+                                       {pk.h2.fr(), h2_len, vK_gamma.neg()}}));
+
+  // ---------------- PC::open_combinations (lib.rs:292) -> batch_open -> MarlinKZG10::open ---------------------
+  auto xi_pow = [&](unsigned e) { return xi.pow_u64(e); };
+  auto sg = c.bases.find(pk.srs_g);
+  if (sg == c.bases.end()) return fail(MH_EINVAL, "prover key refers to a freed SRS handle");
+  const char* srs_pts = (const char*)sg->second.d_points;
+  // --- at beta: labels g_1, outer_sumcheck, t, z_b  -> challenges xi^0 (g_1), xi^1 (g_1 shifted), xi^2, xi^3, xi^4
+  HG1Affine w_beta; bool has_rv_beta = false; HFr rv_beta = HFr::zero();
+  {
+    MH_TRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(2)},
+                                       {pk.t.fr(), H, xi_pow(3)}, {pk.zb.fr(), za_len, xi_pow(4)}}));
+    MH_TRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));
+    uint64_t xyz[18];
+    MH_TRY(msm_device(c, srs_pts, S[1], 1, mask_len - 1, xyz));
+    HG1 wacc = jac_from(xyz);
+    // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b)
+    std::vector<HFr> r;
+    host_axpy(r, HFr::one(), rd_g1.rand.blind);
+    std::vector<HFr> r_outer; host_axpy(r_outer, c_za_lc, rd_za.rand.blind); host_axpy(r_outer, c_w_lc, rd_w.rand.blind);
+    host_axpy(r, xi_pow(2), r_outer);
+    host_axpy(r, xi_pow(4), rd_zb.rand.blind);
+    if (!host_is_zero(r)) {
+      wacc = wacc.add(small_msm(pk.gamma_g, host_div_linear(r, beta)));
+      rv_beta = host_eval(r, beta); has_rv_beta = true;
+    }
+    // degree-bounded g_1: shifted witness
+    MH_TRY(div_linear(c, S[3], pk.g1.fr(), g1_len, beta, S[2]));
+    MH_TRY(lincomb(c, S[4], g1_len - 1, {{S[3], g1_len - 1, xi_pow(1)}}));
+    MH_TRY(msm_device(c, srs_pts + (pk.srs_max_degree - (H - 2)) * 96, S[4], 1, g1_len - 1, xyz));
+    HG1 sw = jac_from(xyz);
+    std::vector<HFr> sr; host_axpy(sr, xi_pow(1), rd_g1.shifted.blind);
+    if (!host_is_zero(rd_g1.shifted.blind)) {
+      std::vector<HFr> srw; host_axpy(srw, xi_pow(1), host_div_linear(rd_g1.shifted.blind, beta));
+      sw = sw.add(small_msm(pk.gamma_g, srw));
+      HFr srv = host_eval(sr, beta);
+      rv_beta = has_rv_beta ? rv_beta + srv : srv; has_rv_beta = true;
+    }
+    wacc = wacc.add(sw);
+    w_beta = wacc.to_affine();
+  }
+  // --- at gamma: labels g_2, inner_sumcheck -> challenges xi^0 (g_2), xi^1 (g_2 shifted), xi^2
+  HG1Affine w_gamma;
+  {
+    MH_TRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(2)}}));
+    MH_TRY(div_linear(c, S[1], S[0], K, gamma, S[2]));
+    uint64_t xyz[18];
+    MH_TRY(msm_device(c, srs_pts, S[1], 1, K - 1, xyz));
+    HG1 wacc = jac_from(xyz);
+    MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
+    MH_TRY(lincomb(c, S[4], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
+    MH_TRY(msm_device(c, srs_pts + (pk.srs_max_degree - (K - 2)) * 96, S[4], 1, g2_len - 1, xyz));
+    wacc = wacc.add(jac_from(xyz));
+    w_gamma = wacc.to_affine();
+  }
+
+  // ---------------- Proof (lib.rs:305-310), flat ToBytes layout ------------------------------------------------
+  std::vector<uint8_t> out;
+  fsh::Commitment* all[9] = {&c_w, &c_za, &c_zb, &c_mask, &c_t, &c_g1, &c_h1, &c_g2, &c_h2};
+  for (auto* cm : all) fsh::put_commitment(out, *cm);
+  fsh::put_fr(out, g1_beta); fsh::put_fr(out, g2_gamma); fsh::put_fr(out, t_beta); fsh::put_fr(out, zb_beta);
+  fsh::put_g1(out, w_beta);
+  out.push_back(has_rv_beta ? 1 : 0); fsh::put_fr(out, has_rv_beta ? rv_beta : HFr::zero());
+  fsh::put_g1(out, w_gamma);
+  out.push_back(0); fsh::put_fr(out, HFr::zero());
+  if (len_out) *len_out = out.size();
+  if (cap < out.size()) return fail(MH_EINVAL, "mh_marlin_prove: proof buffer too small");
+  memcpy(proof_out, out.data(), out.size());
+  return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""Python mirror of the reference's `Marlin<F, PC, FS>` surface (src/lib.rs:64-311) over the C ABI:
+universal_setup / index / prove with PC = MarlinKZG10<Bls12_381>, FS = SimpleHashFiatShamirRng<
+Blake2s, ChaChaRng>.  Plumbing only: arguments are marshalled into the arkworks in-memory layout
+and handed to libmarlin_hip.so; nothing is computed here."""
+import ctypes as C
+import numpy as np
+from . import _lib
+from .api import Bases, FR_ONE_MONT
+
+R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+_MONT_R = (1 << 256) % R_MOD
+
+
+def fr_mont(x):
+    """canonical int -> (4,) uint64 Montgomery limbs."""
+    v = (x % R_MOD) * _MONT_R % R_MOD
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+class _R1csMatrices(C.Structure):
+    _fields_ = [("num_constraints", C.c_uint64), ("num_instance", C.c_uint64),
+                ("row_ptr", C.c_void_p * 3), ("col", C.c_void_p * 3), ("val", C.c_void_p * 3)]
+
+
+def max_degree(num_constraints, num_variables, num_non_zero):
+    """AHPForR1CS::max_degree (src/ahp/mod.rs:71-93)."""
+    def np2(n):
+        s = 1
+        while s < n:
+            s *= 2
+        return s
+    h = np2(max(num_variables, num_constraints))
+    k = np2(num_non_zero)
+    return max(2 * h - 1, 3 * h - 1, h, k - 1)
+
+
+class UniversalSRS:
+    """KZG10 universal parameters for a known (test) tau: powers_of_g and powers_of_gamma_g on the device."""
+
+    def __init__(self, max_deg, tau, gamma):
+        self.max_degree = int(max_deg)
+        self.tau, self.gamma = int(tau) % R_MOD, int(gamma) % R_MOD
+        self.powers_of_g = Bases.srs_powers(fr_mont(self.tau), self.max_degree + 1)
+        self.powers_of_gamma_g = Bases.srs_powers(fr_mont(self.tau), 3, scale_mont=fr_mont(self.gamma))
+
+
+def universal_setup(num_constraints, num_variables, num_non_zero, tau, gamma):
+    """Marlin::universal_setup (src/lib.rs:79-96) with a caller-chosen tau (test/bench SRS)."""
+    return UniversalSRS(max_degree(num_constraints, num_variables, num_non_zero), tau, gamma)
+
+
+class IndexProverKey:
+    def __init__(self, handle):
+        self.handle = handle
+        info = (C.c_uint64 * 8)()
+        _lib.check(_lib.load().mh_marlin_pk_info(handle, info), "mh_marlin_pk_info")
+        (self.H, self.K, self.X, self.num_non_zero, self.max_degree, self.srs_max_degree, self.num_constraints,
+         self.num_instance) = [int(x) for x in info]
+
+    def vk_bytes(self):
+        n = C.c_size_t()
+        _lib.check(_lib.load().mh_marlin_vk_bytes(self.handle, None, 0, C.byref(n)), "mh_marlin_vk_bytes")
+        buf = (C.c_uint8 * n.value)()
+        _lib.check(_lib.load().mh_marlin_vk_bytes(self.handle, buf, n.value, C.byref(n)), "mh_marlin_vk_bytes")
+        return bytes(buf)
+
+    def free(self):
+        if self.handle:
+            _lib.check(_lib.load().mh_marlin_pk_free(self.handle), "mh_marlin_pk_free")
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def index(srs, num_constraints, num_instance, matrices):
+    """Marlin::index (src/lib.rs:100-148).  matrices = [(row_ptr uint64[nc+1], col uint32[nnz], val (nnz,4) uint64
+    Montgomery or None for all-ones)] for A, B, C -- already padded and square."""
+    keep = []
+    m = _R1csMatrices()
+    m.num_constraints = int(num_constraints)
+    m.num_instance = int(num_instance)
+    for k, (rp, col, val) in enumerate(matrices):
+        rp = np.ascontiguousarray(rp, dtype=np.uint64)
+        col = np.ascontiguousarray(col, dtype=np.uint32)
+        keep += [rp, col]
+        m.row_ptr[k] = rp.ctypes.data
+        m.col[k] = col.ctypes.data if col.size else None
+        if val is not None:
+            val = np.ascontiguousarray(val, dtype=np.uint64)
+            keep.append(val)
+            m.val[k] = val.ctypes.data
+        else:
+            m.val[k] = None
+    h = C.c_uint64()
+    _lib.check(_lib.load().mh_marlin_index(C.byref(m), srs.powers_of_g.handle, srs.powers_of_gamma_g.handle, C.byref(h)),
+               "mh_marlin_index")
+    pk = IndexProverKey(h.value)
+    pk.srs = srs
+    return pk
+
+
+PROOF_BYTES = 2143
+
+
+def prove(pk, instance_mont, witness_mont, zk_seed, zk_rounds=20):
+    """Marlin::prove (src/lib.rs:151-311).  Returns the flat ToBytes-layout proof."""
+    x = np.ascontiguousarray(instance_mont, dtype=np.uint64)
+    w = np.ascontiguousarray(witness_mont, dtype=np.uint64)
+    assert x.shape == (pk.num_instance, 4) and w.shape == (pk.num_constraints - pk.num_instance, 4), (x.shape, w.shape)
+    out = (C.c_uint8 * 4096)()
+    n = C.c_size_t()
+    _lib.check(_lib.load().mh_marlin_prove(pk.handle, x.ctypes.data, w.ctypes.data, bytes(zk_seed), int(zk_rounds), out, 4096,
+                                           C.byref(n)), "mh_marlin_prove")
+    return bytes(out[:n.value])
+
+
+# ---- the reference's benchmark / test circuits as padded square R1CS (host-side input preparation) ----
+def dummy_circuit(a, b, num_variables, num_constraints):
+    """DummyCircuit of benches/bench.rs:26-66 after pad_input / make_matrices_square: returns
+    (num_constraints_padded, num_instance, matrices, instance_mont, witness_mont)."""
+    assert num_variables >= 3 and num_constraints >= 2
+    ni = 2                                   # One, c
+    nvars = ni + (2 + num_variables - 3)
+    nc = max(num_constraints, nvars)
+    extra_wit = nc - nvars if num_constraints >= nvars else 0
+    n_rows_real = num_constraints - 1
+
+    def mat(colidx):
+        rp = np.zeros(nc + 1, dtype=np.uint64)
+        rp[1:n_rows_real + 1] = np.arange(1, n_rows_real + 1, dtype=np.uint64)
+        rp[n_rows_real + 1:] = n_rows_real
+        return rp, np.full(n_rows_real, colidx, dtype=np.uint32), None
+    matrices = [mat(ni + 0), mat(ni + 1), mat(1)]
+    a, b = a % R_MOD, b % R_MOD
+    inst = np.stack([FR_ONE_MONT, fr_mont(a * b)])
+    am = fr_mont(a)
+    wit = np.empty((nc - ni, 4), dtype=np.uint64)
+    wit[0] = am
+    wit[1] = fr_mont(b)
+    wit[2:2 + num_variables - 3] = am
+    wit[2 + num_variables - 3:] = FR_ONE_MONT        # make_matrices_square: dummy witnesses = one
+    assert extra_wit == nc - ni - (2 + num_variables - 3)
+    return nc, ni, matrices, inst, wit
+
+
+def test_circuit(a, b, num_constraints, num_variables):
+    """Circuit of src/test.rs:9-50 after padding: inputs (1, c, d, 0)."""
+    ni = 4
+    nvars = ni + (2 + num_variables - 3)
+    nc = max(num_constraints, nvars)
+    a, b = a % R_MOD, b % R_MOD
+    c = a * b % R_MOD
+    d = c * b % R_MOD
+    col_a, col_b, col_c, col_d = ni, ni + 1, 1, 2
+
+    def mat(main, last):
+        rp = np.zeros(nc + 1, dtype=np.uint64)
+        rp[1:num_constraints + 1] = np.arange(1, num_constraints + 1, dtype=np.uint64)
+        rp[num_constraints + 1:] = num_constraints
+        col = np.full(num_constraints, main, dtype=np.uint32)
+        col[-1] = last
+        return rp, col, None
+    matrices = [mat(col_a, col_c), mat(col_b, col_b), mat(col_c, col_d)]
+    inst = np.stack([FR_ONE_MONT, fr_mont(c), fr_mont(d), fr_mont(0)])
+    wit = np.empty((nc - ni, 4), dtype=np.uint64)
+    wit[:] = FR_ONE_MONT
+    wit[0] = fr_mont(a)
+    wit[1] = fr_mont(b)
+    wit[2:2 + num_variables - 3] = fr_mont(a)
+    return nc, ni, matrices, inst, wit
