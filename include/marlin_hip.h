@@ -114,6 +114,11 @@ int mh_marlin_vk_bytes(uint64_t pk, uint8_t* out, size_t cap, size_t* len_out);
 int mh_marlin_prove(uint64_t pk, const uint64_t* instance_mont, const uint64_t* witness_mont, const uint8_t* zk_seed32,
                     int zk_chacha_rounds, uint8_t* proof_out, size_t cap, size_t* len_out);
 
+/* Coefficients (Montgomery Fr) of a prover / indexer polynomial of the last proof made with this key, by the
+ * reference's label ("w","z_a","z_b","mask_poly","t","g_1","h_1","g_2","h_2","row","col","a_val","b_val",
+ * "c_val","row_col"; src/ahp/mod.rs:33-45).  out == NULL queries the length. */
+int mh_marlin_get_poly(uint64_t pk, const char* label, uint64_t* out, size_t cap_elems, size_t* len_out);
+
 /* ---- profiling: accumulated HIP-event time per kernel family on the library stream ----
  * family: 0 = ntt passes, 1 = msm (all stages), 2 = msm accum only, 3 = glue.  */
 int mh_prof_enable(int on);

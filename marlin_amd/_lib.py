@@ -41,6 +41,7 @@ SYMBOLS = {
     "mh_marlin_vk_bytes": (C.c_int, [C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mh_marlin_prove": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t,
                                   C.POINTER(C.c_size_t)]),
+    "mh_marlin_get_poly": (C.c_int, [C.c_uint64, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mh_prof_enable": (C.c_int, [C.c_int]),
     "mh_prof_reset": (C.c_int, []),
     "mh_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), _u64p]),

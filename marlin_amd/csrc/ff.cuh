@@ -198,9 +198,13 @@ template <class P>
 __device__ __noinline__ Fp<P> ff_inv(const Fp<P>& a) {
   constexpr int N = P::N;
   u32 e[N];
+  u32 borrow = 2;   // e = p - 2 with borrow propagation (Fr's low word is 1)
 #pragma unroll
-  for (int i = 0; i < N; i++) e[i] = P::MOD[i];
-  e[0] -= 2;  // p is odd and > 2: no borrow for these moduli (low word >= 2)
+  for (int i = 0; i < N; i++) {
+    u64 d = (u64)P::MOD[i] - borrow;
+    e[i] = (u32)d;
+    borrow = (u32)(d >> 63);
+  }
   Fp<P> acc = Fp<P>::one();
   for (int i = N - 1; i >= 0; i--) {
     for (int b = 31; b >= 0; b--) {

@@ -69,6 +69,7 @@ struct ProverKey {
   DBuf z, za_ev, zb_ev, xpoly, w, za, zb, mask, t, g1, h1, g2, h2, outer, inner;
   DBuf S[8];
   DBuf small;       // partial sums / carries
+  std::map<std::string, std::pair<const Fr*, uint64_t>> last_polys;   // prover oracles of the last proof (label -> ptr, len)
   void free_all() {
     DBuf* all[] = {&ev_row, &ev_col, &ev_row_col, &ev_val_a, &ev_val_b, &ev_val_c, &p_row, &p_col, &p_a_val, &p_b_val, &p_c_val,
                    &p_row_col, &A.row_ptr, &A.col, &A.val, &B.row_ptr, &B.col, &B.val, &t_items, &t_erow, &t_ecoef, &t_item_ptr,
@@ -486,6 +487,22 @@ int mh_marlin_vk_bytes(uint64_t pk_handle, uint8_t* out, size_t cap, size_t* len
   return MH_OK;
 }
 
+// Coefficients (Montgomery) of a prover / indexer polynomial of the last proof, by the reference's label
+// (PROVER_POLYNOMIALS / INDEXER_POLYNOMIALS, src/ahp/mod.rs:33-45).  out == NULL queries the length.
+int mh_marlin_get_poly(uint64_t pk_handle, const char* label, uint64_t* out, size_t cap_elems, size_t* len_out) {
+  LOCKED_CTX();
+  auto it = g_pks.find(pk_handle);
+  if (it == g_pks.end() || !label) return fail(MH_EINVAL, "mh_marlin_get_poly: bad argument");
+  auto pit = it->second->last_polys.find(label);
+  if (pit == it->second->last_polys.end()) return fail(MH_EINVAL, "mh_marlin_get_poly: unknown label (or no proof yet)");
+  if (len_out) *len_out = pit->second.second;
+  if (!out) return MH_OK;
+  if (cap_elems < pit->second.second) return fail(MH_EINVAL, "mh_marlin_get_poly: buffer too small");
+  MH_HIP(hipMemcpyAsync(out, pit->second.first, pit->second.second * 32, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+
 // Marlin::prove (lib.rs:151-311).  instance: formatted public input (X elements, leading one included);
 // witness: nc - X elements (padding witnesses included).  zk_rng = ChaCha(zk_seed, rounds) drawn in the
 // order of SURVEY.md Appendix C.  proof_out: the flat ToBytes-layout proof.
@@ -725,8 +742,10 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     MH_TRY(lincomb(c, S[4], g1_len - 1, {{S[3], g1_len - 1, xi_pow(1)}}));
     MH_TRY(msm_device(c, srs_pts + (pk.srs_max_degree - (H - 2)) * 96, S[4], 1, g1_len - 1, xyz));
     HG1 sw = jac_from(xyz);
+    // open_with_witness_polynomial(shifted_powers, point, shifted_r, shifted_w, Some(shifted_r_witness)):
+    // the hiding witness is always Some(..) on this path, so random_v is always Some(shifted_r(point))
     std::vector<HFr> sr; host_axpy(sr, xi_pow(1), rd_g1.shifted.blind);
-    if (!host_is_zero(rd_g1.shifted.blind)) {
+    {
       std::vector<HFr> srw; host_axpy(srw, xi_pow(1), host_div_linear(rd_g1.shifted.blind, beta));
       sw = sw.add(small_msm(pk.gamma_g, srw));
       HFr srv = host_eval(sr, beta);
@@ -750,6 +769,11 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     w_gamma = wacc.to_affine();
   }
 
+  pk.last_polys = {{"w", {pk.w.fr(), w_len}}, {"z_a", {pk.za.fr(), za_len}}, {"z_b", {pk.zb.fr(), za_len}},
+                   {"mask_poly", {pk.mask.fr(), mask_len}}, {"t", {pk.t.fr(), H}}, {"g_1", {pk.g1.fr(), g1_len}},
+                   {"h_1", {pk.h1.fr(), h1_len}}, {"g_2", {pk.g2.fr(), g2_len}}, {"h_2", {pk.h2.fr(), h2_len}},
+                   {"row", {pk.p_row.fr(), K}}, {"col", {pk.p_col.fr(), K}}, {"a_val", {pk.p_a_val.fr(), K}},
+                   {"b_val", {pk.p_b_val.fr(), K}}, {"c_val", {pk.p_c_val.fr(), K}}, {"row_col", {pk.p_row_col.fr(), K}}};
   // ---------------- Proof (lib.rs:305-310), flat ToBytes layout ------------------------------------------------
   std::vector<uint8_t> out;
   fsh::Commitment* all[9] = {&c_w, &c_za, &c_zb, &c_mask, &c_t, &c_g1, &c_h1, &c_g2, &c_h2};
@@ -758,7 +782,9 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   fsh::put_g1(out, w_beta);
   out.push_back(has_rv_beta ? 1 : 0); fsh::put_fr(out, has_rv_beta ? rv_beta : HFr::zero());
   fsh::put_g1(out, w_gamma);
-  out.push_back(0); fsh::put_fr(out, HFr::zero());
+  // at gamma nothing is hiding, but the degree-bounded g_2 goes through open_with_witness_polynomial with
+  // Some(empty witness): random_v = Some(0) [ark-poly-commit marlin_pc::open, SURVEY B-4]
+  out.push_back(1); fsh::put_fr(out, HFr::zero());
   if (len_out) *len_out = out.size();
   if (cap < out.size()) return fail(MH_EINVAL, "mh_marlin_prove: proof buffer too small");
   memcpy(proof_out, out.data(), out.size());

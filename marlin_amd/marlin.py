@@ -64,6 +64,15 @@ class IndexProverKey:
         _lib.check(_lib.load().mh_marlin_vk_bytes(self.handle, buf, n.value, C.byref(n)), "mh_marlin_vk_bytes")
         return bytes(buf)
 
+    def get_poly(self, label):
+        """(len,4) uint64 Montgomery coefficients of a prover/indexer polynomial of the last proof."""
+        n = C.c_size_t()
+        _lib.check(_lib.load().mh_marlin_get_poly(self.handle, label.encode(), None, 0, C.byref(n)), "mh_marlin_get_poly")
+        out = np.zeros((n.value, 4), dtype=np.uint64)
+        _lib.check(_lib.load().mh_marlin_get_poly(self.handle, label.encode(), out.ctypes.data, n.value, C.byref(n)),
+                   "mh_marlin_get_poly")
+        return out
+
     def free(self):
         if self.handle:
             _lib.check(_lib.load().mh_marlin_pk_free(self.handle), "mh_marlin_pk_free")

@@ -39,6 +39,29 @@ def test_proof_bytes_match_golden(gpu, case):
     assert proof.hex() == case["proof_bytes"]
 
 
+def test_prover_polynomials_match_oracle(gpu):
+    """Every prover oracle polynomial (coefficient form) equals the oracle's, for a test.rs shape."""
+    from tests.util import np_to_fr
+    from oracle.poly import trim
+    rng = FS.test_rng()
+    a, b = FS.fr_rand(rng), FS.fr_rand(rng)
+    nc, nv = 25, 25
+    cs = AHP.pad_and_square(AHP.finalize_test_circuit(AHP.test_circuit(a, b, nc, nv)))
+    srs_o = MR.universal_setup(nc, nv, 3 * nc, TAU, GAMMA)
+    pk_o = MR.marlin_index(srs_o, cs)
+    pr = MR.prove(pk_o, cs, FS.ChaChaRng(SEED, 20))
+    srs = GM.universal_setup(nc, nv, 3 * nc, TAU, GAMMA)
+    ncp, ni, mats, inst, wit = GM.test_circuit(a, b, nc, nv)
+    pk = GM.index(srs, ncp, ni, mats)
+    GM.prove(pk, inst, wit, SEED)
+    bad = []
+    for label in ["row", "col", "a_val", "b_val", "c_val", "row_col", "w", "z_a", "z_b", "mask_poly", "t", "g_1", "h_1", "g_2", "h_2"]:
+        got = trim(np_to_fr(pk.get_poly(label)))
+        if got != trim(pr.polys[label]):
+            bad.append(label)
+    assert not bad, bad
+
+
 def test_proof_matches_fresh_oracle_and_verifies(gpu):
     """A size not in the fixtures: DummyCircuit with 2^7 constraints; oracle run here."""
     rng = FS.test_rng()
