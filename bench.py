@@ -5,10 +5,12 @@ Metric (BASELINE.json): R1CS constraints / second for Marlin::prove on BLS12-381
 at 2^20 constraints (DummyCircuit of /root/reference benches/bench.rs:26-66,
 MarlinKZG10).  One "step" = one pass of the prove hot path over one instance:
 
-  workload "hotpath-inventory": the 30 NTTs and 15 large MSMs that one
-      Marlin::prove performs at this size (SURVEY.md Appendix A), on synthetic
-      coefficient vectors resident in HBM and a known-tau SRS generated on the
-      device.  (Used until the device-resident prover lands; see config.workload.)
+  workload "marlin-prove" (default): one full Marlin::prove (mh_marlin_prove: AHP rounds, 21 NTTs,
+      15 large MSMs, Fiat-Shamir, batch opening) of DummyCircuit with its index, SRS, instance and
+      witness resident in HBM; the proof it emits is byte-identical to the oracle's at the sizes
+      the oracle reaches (tests/test_gpu_marlin.py) and verifies at 2^20.
+  workload "hotpath-inventory": the 30 NTTs and 15 large MSMs of one prove on synthetic vectors
+      (kernel-only view; the only mode available for N > 1 GPUs in round 1).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on
 rank 0.  N > 1 is launched by torch.distributed.run, one rank per GPU: every MSM
@@ -92,6 +94,31 @@ class HotPathInventory:
         return partials
 
 
+class MarlinProve:
+    """One Marlin::prove of DummyCircuit (benches/bench.rs:26-66) at 2^log_n constraints."""
+
+    def __init__(self, M, log_n):
+        from marlin_amd import marlin as GM, workload as W
+        self.M, self.GM = M, GM
+        self.N = 1 << log_n
+        n = self.N
+        self.alg_ntt_bytes, self.alg_msm_bytes = W.algorithmic_bytes(n, 4 * n)
+        self.msms, _ = W.msm_inventory(n, 4 * n)
+        tau, gamma = 0x1f3a9c5d7e2b4a6f8091a2b3c4d5e6f708192a3b4c5d6e7f, 0x5eed5eed5eed5eed0123456789abcdef
+        a, b = 0x2d1f0e3c4b5a69788796a5b4c3d2e1f00f1e2d3c4b5a6978, 0x1a2b3c4d5e6f708192a3b4c5d6e7f8091a2b3c4d5e6f7081
+        t0 = time.time()
+        self.srs = GM.universal_setup(n, n, 3 * n, tau, gamma)
+        nc, ni, mats, self.inst, self.wit = GM.dummy_circuit(a, b, 10, n)
+        self.pk = GM.index(self.srs, nc, ni, mats)
+        self.setup_s = time.time() - t0
+        self.seed = bytes(range(32))
+        self.proof = None
+
+    def step(self, dist=None, torch=None):
+        self.proof = self.GM.prove(self.pk, self.inst, self.wit, self.seed)
+        return self.proof
+
+
 def cpu_baseline(log_n_sample=13):
     """The C restatement (oracle/c/ref_hotpath.c, kind "port") timed on this host's cores on the
     hot-path inventory of a 2^log_n_sample-constraint prove."""
@@ -132,6 +159,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["marlin-prove", "hotpath-inventory"], default=None)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,7 +176,10 @@ def main():
     M.init(local_rank)
     torch.cuda.set_device(local_rank)
 
-    wl = HotPathInventory(M, args.log_constraints, rank, world)
+    workload = args.workload or ("marlin-prove" if world == 1 else "hotpath-inventory")
+    if workload == "marlin-prove" and world > 1:
+        raise SystemExit("marlin-prove is single-GPU in round 1; use --workload hotpath-inventory for N > 1")
+    wl = MarlinProve(M, args.log_constraints) if workload == "marlin-prove" else HotPathInventory(M, args.log_constraints, rank, world)
 
     def barrier():
         M.synchronize()
@@ -179,6 +210,7 @@ def main():
     acc_ms, acc_launches = M.prof_get(2)
     ntt_ms, ntt_launches = M.prof_get(0)
     msm_ms, _ = M.prof_get(1)
+    glue_ms, _ = M.prof_get(3)
     msm_pairs_rank = sum((n * (rank + 1)) // world - (n * rank) // world for n, _ in wl.msms)
     bytes_per_launch = 128.0 * msm_pairs_rank / len(wl.msms)
     avg_launch_ms = acc_ms / max(1, acc_launches)
@@ -202,12 +234,16 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32-limb Montgomery (Fr 256-bit, Fq 384-bit)",
         "data": "synthetic",
-        "config": {"workload": "hotpath-inventory: 30 NTT + 15 MSM of one Marlin::prove, DummyCircuit 2^%d constraints, "
-                               "BLS12-381, MarlinKZG10 (SURVEY.md Appendix A)" % args.log_constraints,
+        "config": {"workload": ("marlin-prove: full Marlin::prove (AHP rounds + KZG10 commit/open + Fiat-Shamir), "
+                                if workload == "marlin-prove" else
+                                "hotpath-inventory: 30 NTT + 15 MSM of one Marlin::prove on synthetic vectors, ")
+                               + "DummyCircuit 2^%d constraints, BLS12-381, MarlinKZG10 (benches/bench.rs shape; SURVEY.md Appendix A)"
+                               % args.log_constraints,
                    "constraints": wl.N, "curve": "BLS12-381", "pc": "MarlinKZG10",
                    "parallelism": "msm-point-sharded x%d, ntt replicated" % world},
         "breakdown_ms_per_step": {"ntt": round(ntt_ms / args.steps, 3), "msm": round(msm_ms / args.steps, 3),
-                                  "msm_accum": round(acc_ms / args.steps, 3)},
+                                  "msm_accum": round(acc_ms / args.steps, 3), "glue": round(glue_ms / args.steps, 3),
+                                  "host_and_other": round(ms_per_step - (ntt_ms + msm_ms + glue_ms) / args.steps, 3)},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -80,3 +80,26 @@ def test_proof_matches_fresh_oracle_and_verifies(gpu):
     assert MR.verify(pk_o, [a * b % F.R_MOD], pr) and not MR.verify(pk_o, [a], pr)
     # a different zk seed gives a different (still valid-looking) proof: the rng really is consumed
     assert GM.prove(pk, inst, wit, bytes(32)) != proof
+
+
+@pytest.mark.parametrize("log_n", [12, 16, 18, 20])
+def test_full_size_proof_verifies(gpu, log_n):
+    """BASELINE.json sizes (2^18 = configs[1], 2^20 = configs[2]): the proof of DummyCircuit made on the
+    device verifies under the oracle's verifier, and a wrong public input / tampered proof is rejected
+    (the reference's own acceptance property, src/test.rs:158-161)."""
+    from tests.verify_adapter import oracle_verify
+    rng = FS.test_rng()
+    a, b = FS.fr_rand(rng), FS.fr_rand(rng)
+    n = 1 << log_n
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA)
+    ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
+    pk = GM.index(srs, ncp, ni, mats)
+    assert (pk.H, pk.K) == (n, 4 * n)
+    proof = GM.prove(pk, inst, wit, SEED)
+    vk = pk.vk_bytes()
+    c = a * b % F.R_MOD
+    assert oracle_verify(vk, srs.max_degree, TAU, GAMMA, [c], proof)
+    assert not oracle_verify(vk, srs.max_degree, TAU, GAMMA, [a], proof)
+    bad = bytearray(proof); bad[195 * 9 + 3] ^= 1                     # flip a bit of an evaluation
+    assert not oracle_verify(vk, srs.max_degree, TAU, GAMMA, [c], bytes(bad))
+    assert GM.prove(pk, inst, wit, SEED) == proof                    # deterministic given the zk seed

@@ -1,0 +1,67 @@
+"""Adapter: verify a flat proof from the HIP prover with the oracle's verifier (oracle/marlin.py
+verify: Fiat-Shamir replay + known-tau KZG identity).  O(1) group operations, so it works at
+2^20 constraints where the Python oracle could never produce the proof itself."""
+from oracle import fields as F, curve as EC, marlin as MR
+from oracle.poly import Domain
+
+
+class _LazyPowers:
+    """srs.powers_of_g[i] = [tau^i]G computed on demand."""
+
+    def __init__(self, tau):
+        self.tau = tau
+
+    def __getitem__(self, i):
+        return EC.scalar_mul(EC.G1_GEN, pow(self.tau, i, F.R_MOD))
+
+
+def _g1(b):
+    x = int.from_bytes(b[0:48], "little")
+    y = int.from_bytes(b[48:96], "little")
+    return None if b[96] else (x, y)
+
+
+def _commitment(b):
+    comm = _g1(b[0:97])
+    has = b[97]
+    sh = _g1(b[98:195])
+    return (comm, (sh,) if has else None)
+
+
+def parse_vk(vk):
+    nv = int.from_bytes(vk[0:8], "little"); nc = int.from_bytes(vk[8:16], "little"); nnz = int.from_bytes(vk[16:24], "little")
+    comms = [_commitment(vk[24 + 195 * i: 24 + 195 * (i + 1)]) for i in range(6)]
+    return nv, nc, nnz, comms
+
+
+def parse_proof(pb):
+    assert len(pb) == 2143
+    pr = MR.Proof()
+    cs = [_commitment(pb[195 * i: 195 * (i + 1)]) for i in range(9)]
+    pr.commitments = [cs[0:4], cs[4:7], cs[7:9]]
+    o = 195 * 9
+    pr.evaluations = [int.from_bytes(pb[o + 32 * i: o + 32 * (i + 1)], "little") for i in range(4)]
+    o += 128
+    pr.pc_proof = []
+    for _ in range(2):
+        w = _g1(pb[o:o + 97]); has = pb[o + 97]; rv = int.from_bytes(pb[o + 98:o + 130], "little")
+        pr.pc_proof.append((w, rv if has else None))
+        o += 130
+    return pr
+
+
+def oracle_verify(vk_bytes, srs_max_degree, tau, gamma, public_input, proof_bytes):
+    nv, nc, nnz, comms = parse_vk(vk_bytes)
+    pk = MR.IndexKeys()
+    idx = type("Idx", (), {})()
+    idx.num_variables, idx.num_constraints, idx.num_non_zero = nv, nc, nnz
+    idx.domain_h, idx.domain_k = Domain(nc), Domain(nnz)
+    pk.index = idx
+    pk.index_comms = comms
+    srs = type("Srs", (), {})()
+    srs.max_degree, srs.tau, srs.gamma = srs_max_degree, tau % F.R_MOD, gamma % F.R_MOD
+    srs.g = EC.G1_GEN
+    srs.gamma_g = EC.scalar_mul(EC.G1_GEN, gamma)
+    srs.powers_of_g = _LazyPowers(tau)
+    pk.srs = srs
+    return MR.verify(pk, list(public_input), parse_proof(proof_bytes))
