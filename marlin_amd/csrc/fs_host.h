@@ -67,13 +67,16 @@ struct Blake2s {
 
 // ---------------------------------------------------------------- ChaCha RNG (rand_chacha BlockRng order)
 struct ChaChaRng {
+  // The output is one sequential stream of little-endian u32 words (block b = ChaCha(key, counter = b));
+  // rand_chacha's BlockRng buffers 4 blocks at a time, which does not change the order in which words
+  // are consumed, so the generator is modelled by its word position.
   uint32_t key[8];
-  uint64_t counter;
   int rounds;
-  uint32_t buf[64];
-  int idx;
-  ChaChaRng() : counter(0), rounds(20), idx(64) { memset(key, 0, sizeof(key)); }
-  ChaChaRng(const uint8_t seed[32], int rounds_) : counter(0), rounds(rounds_), idx(64) { memcpy(key, seed, 32); }
+  uint64_t pos;          // words consumed so far
+  uint64_t cached_block; // block held in buf
+  uint32_t buf[16];
+  ChaChaRng() : rounds(20), pos(0), cached_block(~0ull) { memset(key, 0, sizeof(key)); }
+  ChaChaRng(const uint8_t seed[32], int rounds_) : rounds(rounds_), pos(0), cached_block(~0ull) { memcpy(key, seed, 32); }
   static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
   static void block(const uint32_t key[8], uint64_t counter, int rounds, uint32_t out[16]) {
     uint32_t st[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
@@ -90,16 +93,14 @@ struct ChaChaRng {
 #undef CQR
     for (int i = 0; i < 16; i++) out[i] = w[i] + st[i];
   }
-  void refill() { for (int b = 0; b < 4; b++) { block(key, counter, rounds, buf + 16 * b); counter++; } idx = 0; }
-  uint64_t next_u64() {
-    if (idx >= 63) {
-      if (idx == 63) { uint32_t lo = buf[63]; refill(); uint32_t hi = buf[0]; idx = 1; return (uint64_t)lo | ((uint64_t)hi << 32); }
-      refill();
-    }
-    uint64_t v = (uint64_t)buf[idx] | ((uint64_t)buf[idx + 1] << 32);
-    idx += 2;
-    return v;
+  uint32_t next_u32() {
+    uint64_t b = pos >> 4;
+    if (b != cached_block) { block(key, b, rounds, buf); cached_block = b; }
+    return buf[(pos++) & 15];
   }
+  uint64_t next_u64() { uint64_t lo = next_u32(); uint64_t hi = next_u32(); return lo | (hi << 32); }
+  uint64_t word_pos() const { return pos; }
+  void seek_words(uint64_t p) { pos = p; }
 };
 
 // Fp256::rand for BLS12-381 Fr: accepted raw limbs are the Montgomery representation.

@@ -17,6 +17,9 @@
 #include "g1.cuh"
 #include "host_ff.h"
 #include "poly.cuh"
+#include "rng.cuh"
+#include <chrono>
+#include <cstdlib>
 
 using namespace mh;
 using hostff::HFq;
@@ -69,11 +72,12 @@ struct ProverKey {
   DBuf z, za_ev, zb_ev, xpoly, w, za, zb, mask, t, g1, h1, g2, h2, outer, inner;
   DBuf S[8];
   DBuf small;       // partial sums / carries
+  DBuf scal;        // a few device scalars (scan totals)
   std::map<std::string, std::pair<const Fr*, uint64_t>> last_polys;   // prover oracles of the last proof (label -> ptr, len)
   void free_all() {
     DBuf* all[] = {&ev_row, &ev_col, &ev_row_col, &ev_val_a, &ev_val_b, &ev_val_c, &p_row, &p_col, &p_a_val, &p_b_val, &p_c_val,
                    &p_row_col, &A.row_ptr, &A.col, &A.val, &B.row_ptr, &B.col, &B.val, &t_items, &t_erow, &t_ecoef, &t_item_ptr,
-                   &z, &za_ev, &zb_ev, &xpoly, &w, &za, &zb, &mask, &t, &g1, &h1, &g2, &h2, &outer, &inner, &small};
+                   &z, &za_ev, &zb_ev, &xpoly, &w, &za, &zb, &mask, &t, &g1, &h1, &g2, &h2, &outer, &inner, &small, &scal};
     for (auto* b : all) b->release();
     for (auto& s : S) s.release();
   }
@@ -220,6 +224,52 @@ void host_axpy(std::vector<HFr>& acc, const HFr& f, const std::vector<HFr>& p) {
   for (size_t i = 0; i < p.size(); i++) acc[i] = acc[i] + f * p[i];
 }
 bool host_is_zero(const std::vector<HFr>& p) { for (auto& x : p) if (!x.is_zero()) return false; return true; }
+
+// DensePolynomial::rand(needed - 1, zk_rng) on the device (rng.cuh): out[0..needed) <- the next `needed`
+// accepted Fp256::rand draws of the ChaCha stream; advances the host generator past the consumed words.
+int device_poly_rand(Context& c, ProverKey& pk, fsh::ChaChaRng& zk, Fr* out, uint64_t needed, Fr* cand, u32* flag) {
+  if (zk.word_pos() % 8) return fail(MH_EINVAL, "zk_rng is not aligned to a field-element draw");
+  uint64_t c0 = zk.word_pos() / 8, produced = 0;
+  rng::Key key; memcpy(key.k, zk.key, 32);
+  u32* sums = (u32*)pk.small.p;
+  u32* d_total = (u32*)pk.scal.p;
+  u64* d_last = (u64*)((char*)pk.scal.p + 64);
+  const uint64_t cap = pk.S[0].bytes / 32;
+  while (produced < needed) {
+    uint64_t want = needed - produced;
+    uint64_t n = want + want / 8 + 4096;
+    if (n > cap) n = cap;
+    uint64_t nblk = (n + 1023) / 1024;
+    ProfScope ps(c, PF_GLUE);
+    hipLaunchKernelGGL(rng::candidates_kernel, dim3(poly::grid_for(n / 2 + 2)), dim3(256), 0, c.stream, cand, flag, key, zk.rounds, (u64)c0, (u64)n);
+    hipLaunchKernelGGL(rng::scan_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, c.stream, (const u32*)flag, sums, (u64)n);
+    hipLaunchKernelGGL(rng::scan_sums_kernel, dim3(1), dim3(1024), 0, c.stream, sums, (u64)nblk, d_total);
+    hipLaunchKernelGGL(rng::scan_scatter_kernel, dim3((unsigned)nblk), dim3(256), 0, c.stream, out, (const Fr*)cand, (const u32*)flag,
+                       (const u32*)sums, (u64)n, (u64)needed, (u64)produced, d_last);
+    MH_HIP(hipGetLastError());
+    uint32_t total = 0; uint64_t last = 0;
+    MH_HIP(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, c.stream));
+    MH_HIP(hipMemcpyAsync(&last, d_last, 8, hipMemcpyDeviceToHost, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));
+    if (produced + total >= needed) { c0 += last + 1; produced = needed; }
+    else { produced += total; c0 += n; }
+  }
+  zk.seek_words(c0 * 8);
+  return MH_OK;
+}
+
+struct Trace {
+  bool on; std::chrono::steady_clock::time_point t0, last; Context& c;
+  explicit Trace(Context& c_) : c(c_) { on = getenv("MH_TRACE") != nullptr; t0 = last = std::chrono::steady_clock::now(); }
+  void mark(const char* label) {
+    if (!on) return;
+    (void)hipStreamSynchronize(c.stream);
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mh_trace] %-52s %9.3f ms (t=%9.3f)\n", label, std::chrono::duration<double, std::milli>(now - last).count(),
+            std::chrono::duration<double, std::milli>(now - t0).count());
+    last = now;
+  }
+};
 
 // KZG10::commit (ark-poly-commit kzg10 [SURVEY B-3]): MSM over powers_of_g[offset..] plus, when hiding,
 // a fresh 3-coefficient blinding polynomial committed on powers_of_gamma_g.
@@ -457,6 +507,7 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
   MH_TRY(pk.g2.alloc(K * 32)); MH_TRY(pk.h2.alloc(K * 32)); MH_TRY(pk.outer.alloc((3 * H + 8) * 32)); MH_TRY(pk.inner.alloc(K * 32));
   for (auto& s : pk.S) MH_TRY(s.alloc(big * 32));
   MH_TRY(pk.small.alloc((big / 8 + pk.t_nitems + 4096) * 32));
+  MH_TRY(pk.scal.alloc(256));
   MH_TRY(ensure_twiddles_public(c, std::max(pk.logK + 1, pk.logH + 2)));
   MH_HIP(hipStreamSynchronize(c.stream));
   uint64_t h = g_next_pk++;
@@ -518,6 +569,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   const uint64_t nw = nc - X;
   const uint32_t lgH = pk.logH, lgK = pk.logK, lgX = pk.logX;
   fsh::ChaChaRng zk(zk_seed, zk_rounds);
+  Trace tr(c);
   Fr** Sp = nullptr; (void)Sp;
   Fr* S[8]; for (int i = 0; i < 8; i++) S[i] = pk.S[i].fr();
   const Fr* tw = (const Fr*)c.tw;
@@ -544,6 +596,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     fs.initialize(init);                                  // lib.rs:161-163
   }
 
+  tr.mark("AHP::Prover::Init (z_A, z_B)");
   // ---------------- first round (prover.rs:309-409) -----------------------------------------------------------
   MH_TRY(ntt_device(c, pk.z.fr(), pk.xpoly.fr(), lgX, 1));              // x_poly = interpolate(formatted input)
   MH_TRY(d2d(c, S[0], pk.xpoly.fr(), X)); MH_TRY(zero_tail(c, S[0], X, H));
@@ -572,15 +625,9 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   const uint64_t za_len = H + 1;
   // mask polynomial (prover.rs:369-381): 3H sequential draws, then force sum over H to zero
   const uint64_t mask_len = 3 * H;          // degree 3H + 2*zk_bound - 3
-  {
-    std::vector<uint64_t> hm(mask_len * 4);
-    for (uint64_t i = 0; i < mask_len; i++) { HFr v = fsh::fr_rand(zk); memcpy(&hm[4 * i], v.v, 32); }
-    HFr r0 = HFr::zero();
-    for (uint64_t i = 0; i <= (mask_len - 1) / H; i++) { HFr v; memcpy(v.v, &hm[4 * H * i], 32); r0 = r0 + v; }
-    HFr m0; memcpy(m0.v, &hm[0], 32); m0 = m0 - r0; memcpy(&hm[0], m0.v, 32);
-    MH_HIP(hipMemcpyAsync(pk.mask.fr(), hm.data(), mask_len * 32, hipMemcpyHostToDevice, c.stream));
-    MH_HIP(hipStreamSynchronize(c.stream));
-  }
+  MH_TRY(device_poly_rand(c, pk, zk, pk.mask.fr(), mask_len, S[0], (u32*)S[1]));
+  hipLaunchKernelGGL(rng::mask_fix_kernel, dim3(1), dim3(1), 0, c.stream, pk.mask.fr(), (u64)H, (u64)mask_len);
+  tr.mark("AHP::Prover::FirstRound (w, z_A, z_B, mask polys)");
   // PC::commit first round (lib.rs:172): w, z_a, z_b hiding 1; mask none
   fsh::Commitment c_w, c_za, c_zb, c_mask; PolyRand rd_w, rd_za, rd_zb, rd_mask;
   MH_TRY(marlin_commit(c, pk, pk.w.fr(), w_len, false, 0, true, &zk, &c_w, &rd_w));
@@ -592,6 +639,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     fsh::put_commitment(b, c_w); fsh::put_commitment(b, c_za); fsh::put_commitment(b, c_zb); fsh::put_commitment(b, c_mask);
     fs.absorb(b);                                                            // lib.rs:180
   }
+  tr.mark("Committing to first round polys");
   // verifier_first_round (verifier.rs:44-79)
   auto v_h = [&](const HFr& x) { return x.pow_u64(H) - HFr::one(); };
   HFr alpha = fs.rand_fr();
@@ -638,6 +686,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   MH_TRY(lincomb(c, S[4], H, {{S[2], H, HFr::one()}, {pk.h1.fr(), H, HFr::one()}}));   // remainder = x g_1
   MH_TRY(d2d(c, pk.g1.fr(), S[4] + 1, H - 1));
   const uint64_t g1_len = H - 1;
+  tr.mark("AHP::Prover::SecondRound");
   fsh::Commitment c_t, c_g1, c_h1; PolyRand rd_t, rd_g1, rd_h1;
   MH_TRY(marlin_commit(c, pk, pk.t.fr(), H, false, 0, false, &zk, &c_t, &rd_t));
   MH_TRY(marlin_commit(c, pk, pk.g1.fr(), g1_len, true, H - 2, true, &zk, &c_g1, &rd_g1));
@@ -647,6 +696,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     fsh::put_commitment(b, c_t); fsh::put_commitment(b, c_g1); fsh::put_commitment(b, c_h1);
     fs.absorb(b);                                                               // lib.rs:201
   }
+  tr.mark("Committing to second round polys");
   HFr beta = fs.rand_fr();
   while (v_h(beta).is_zero()) beta = fs.rand_fr();                              // verifier.rs:82-91
 
@@ -675,6 +725,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   MH_TRY(lincomb(c, S[5], K2, {{S[0], K, HFr::one()}, {S[6], K2, minus_one}}));    // a - b f
   MH_TRY(div_vanishing(c, pk.h2.fr(), S[5], K2, K, S[7]));                         // h_2
   const uint64_t h2_len = K - 1;
+  tr.mark("AHP::Prover::ThirdRound");
   fsh::Commitment c_g2, c_h2; PolyRand rd_g2, rd_h2;
   MH_TRY(marlin_commit(c, pk, pk.g2.fr(), g2_len, true, K - 2, false, &zk, &c_g2, &rd_g2));
   MH_TRY(marlin_commit(c, pk, pk.h2.fr(), h2_len, false, 0, false, &zk, &c_h2, &rd_h2));
@@ -683,6 +734,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     fsh::put_commitment(b, c_g2); fsh::put_commitment(b, c_h2);
     fs.absorb(b);                                                                // lib.rs:221
   }
+  tr.mark("Committing to third round polys");
   HFr gamma = fs.rand_fr();                                                      // verifier.rs:94-100
 
   // ---------------- evaluations (lib.rs:272-287): g_1, g_2, t, z_b in label order ---------------------------
@@ -713,6 +765,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
                                        {pk.p_row.fr(), K, alpha * mult}, {pk.p_col.fr(), K, beta * mult}, {pk.p_row_col.fr(), K, mult.neg()},
                                        {pk.h2.fr(), h2_len, vK_gamma.neg()}}));
 
+  tr.mark("Evaluating linear combinations over query set");
   // ---------------- PC::open_combinations (lib.rs:292) -> batch_open -> MarlinKZG10::open ---------------------
   auto xi_pow = [&](unsigned e) { return xi.pow_u64(e); };
   auto sg = c.bases.find(pk.srs_g);
@@ -769,6 +822,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     w_gamma = wacc.to_affine();
   }
 
+  tr.mark("PC::open_combinations");
   pk.last_polys = {{"w", {pk.w.fr(), w_len}}, {"z_a", {pk.za.fr(), za_len}}, {"z_b", {pk.zb.fr(), za_len}},
                    {"mask_poly", {pk.mask.fr(), mask_len}}, {"t", {pk.t.fr(), H}}, {"g_1", {pk.g1.fr(), g1_len}},
                    {"h_1", {pk.h1.fr(), h1_len}}, {"g_2", {pk.g2.fr(), g2_len}}, {"h_2", {pk.h2.fr(), h2_len}},
