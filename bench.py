@@ -10,13 +10,13 @@ MarlinKZG10).  One "step" = one pass of the prove hot path over one instance:
       witness resident in HBM; the proof it emits is byte-identical to the oracle's at the sizes
       the oracle reaches (tests/test_gpu_marlin.py) and verifies at 2^20.
   workload "hotpath-inventory": the 30 NTTs and 15 large MSMs of one prove on synthetic vectors
-      (kernel-only view; the only mode available for N > 1 GPUs in round 1).
+      (kernel-only view, --workload hotpath-inventory).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on
-rank 0.  N > 1 is launched by torch.distributed.run, one rank per GPU: every MSM
-is sharded by points across ranks (each rank holds its SRS shard), partial sums
-are exchanged with an RCCL all_gather of 144-byte points and added on every rank;
-the round polynomials' NTTs are replicated (strong scaling).
+rank 0.  N > 1 is launched by torch.distributed.run, one rank per GPU: every rank runs
+the whole prover but multiplies only its slice of each MSM; the 144-byte partial points
+are exchanged with an RCCL all_gather and added on every rank, so all ranks derive the
+same transcript; the AHP rounds (NTTs + glue) are replicated (strong scaling).
 """
 import argparse
 import json
@@ -176,10 +176,14 @@ def main():
     M.init(local_rank)
     torch.cuda.set_device(local_rank)
 
-    workload = args.workload or ("marlin-prove" if world == 1 else "hotpath-inventory")
-    if workload == "marlin-prove" and world > 1:
-        raise SystemExit("marlin-prove is single-GPU in round 1; use --workload hotpath-inventory for N > 1")
-    wl = MarlinProve(M, args.log_constraints) if workload == "marlin-prove" else HotPathInventory(M, args.log_constraints, rank, world)
+    workload = args.workload or "marlin-prove"
+    if workload == "marlin-prove":
+        wl = MarlinProve(M, args.log_constraints)
+        if world > 1:
+            from marlin_amd import dist as MD
+            MD.enable_sharded_prove(dist, device=torch.device("cuda", local_rank))
+    else:
+        wl = HotPathInventory(M, args.log_constraints, rank, world)
 
     def barrier():
         M.synchronize()
@@ -212,6 +216,8 @@ def main():
     msm_ms, _ = M.prof_get(1)
     glue_ms, _ = M.prof_get(3)
     msm_pairs_rank = sum((n * (rank + 1)) // world - (n * rank) // world for n, _ in wl.msms)
+    if workload == "marlin-prove":      # 6 index-independent launches fewer/more never happen: 15 MSMs per prove
+        acc_launches = max(acc_launches, 1)
     bytes_per_launch = 128.0 * msm_pairs_rank / len(wl.msms)
     avg_launch_ms = acc_ms / max(1, acc_launches)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0

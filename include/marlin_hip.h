@@ -88,6 +88,10 @@ int mh_msm_dev(uint64_t bases_handle, size_t base_offset, const void* d_scalars,
 /* Jacobian -> affine x||y (Montgomery) + infinity flag, on the host (GroupProjective::into_affine) */
 int mh_g1_to_affine(const uint64_t* xyz_mont, uint64_t* xy_mont_out, int* is_infinity_out);
 
+/* Sum of n Jacobian points on the host (no device needed): the combine step of a point-sharded MSM after
+ * the ranks all_gather their 144-byte partial results. */
+int mh_g1_sum(const uint64_t* xyz_points, size_t n, uint64_t* out_xyz);
+
 /* ---- Marlin index / prove with device-resident polynomials --------------------------------
  * Host-side mirror of Marlin::<Fr, MarlinKZG10<Bls12_381>, SimpleHashFiatShamirRng<Blake2s,
  * ChaChaRng>>::{index, prove} (src/lib.rs:100-148, 151-311).  The R1CS is given as the padded,
@@ -113,6 +117,14 @@ int mh_marlin_vk_bytes(uint64_t pk, uint8_t* out, size_t cap, size_t* len_out);
  * the flat ToBytes-layout proof (9 commitments, 4 evaluations, 2 opening proofs; 2143 bytes). */
 int mh_marlin_prove(uint64_t pk, const uint64_t* instance_mont, const uint64_t* witness_mont, const uint8_t* zk_seed32,
                     int zk_chacha_rounds, uint8_t* proof_out, size_t cap, size_t* len_out);
+
+/* Multi-GPU (one process per GPU): shard every MSM of mh_marlin_prove by points over `world` ranks.  The
+ * library is transport-agnostic: `allgather` must gather `bytes` bytes from every rank into recv
+ * (rank-major, world * bytes) -- in this repo torch.distributed.all_gather over RCCL/xGMI (marlin_amd/dist.py).
+ * Every rank must hold the full SRS and prover key and call mh_marlin_prove with identical arguments. */
+typedef int (*mh_allgather_fn)(const void* send, size_t bytes, void* recv, void* user);
+int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* user);
+int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv);   /* runs the callback once (host only) */
 
 /* Coefficients (Montgomery Fr) of a prover / indexer polynomial of the last proof made with this key, by the
  * reference's label ("w","z_a","z_b","mask_poly","t","g_1","h_1","g_2","h_2","row","col","a_val","b_val",

@@ -35,12 +35,15 @@ SYMBOLS = {
     "mh_msm": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "mh_msm_dev": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "mh_g1_to_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "mh_g1_sum": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mh_marlin_index": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u64p]),
     "mh_marlin_pk_free": (C.c_int, [C.c_uint64]),
     "mh_marlin_pk_info": (C.c_int, [C.c_uint64, _u64p]),
     "mh_marlin_vk_bytes": (C.c_int, [C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mh_marlin_prove": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t,
                                   C.POINTER(C.c_size_t)]),
+    "mh_marlin_set_shard": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mh_marlin_test_allgather": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mh_marlin_get_poly": (C.c_int, [C.c_uint64, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mh_prof_enable": (C.c_int, [C.c_int]),
     "mh_prof_reset": (C.c_int, []),

@@ -523,6 +523,20 @@ int mh_g1_to_affine(const uint64_t* xyz, uint64_t* xy_out, int* inf_out) {
   return MH_OK;
 }
 
+// sum of n Jacobian points (host; needs no device): combines the per-GPU partial MSM results that the
+// ranks exchange with all_gather (elliptic-curve addition is not an RCCL reduction operator).
+int mh_g1_sum(const uint64_t* xyz_points, size_t n, uint64_t* out_xyz) {
+  if ((!xyz_points && n) || !out_xyz) return fail(MH_EINVAL, "mh_g1_sum: null pointer");
+  HG1 acc = HG1::identity();
+  for (size_t i = 0; i < n; i++) {
+    HG1 p;
+    memcpy(p.X.v, xyz_points + 18 * i, 48); memcpy(p.Y.v, xyz_points + 18 * i + 6, 48); memcpy(p.Z.v, xyz_points + 18 * i + 12, 48);
+    acc = acc.add(p);
+  }
+  memcpy(out_xyz, acc.X.v, 48); memcpy(out_xyz + 6, acc.Y.v, 48); memcpy(out_xyz + 12, acc.Z.v, 48);
+  return MH_OK;
+}
+
 int mh_prof_enable(int on) {
   LOCKED_CTX();
   c.prof_on = on != 0;

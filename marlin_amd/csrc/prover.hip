@@ -193,6 +193,27 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
   return MH_OK;
 }
 
+// ---- multi-GPU: MSM point sharding ---------------------------------------------------
+// Every rank runs the whole prover (AHP rounds replicated) but multiplies only its slice of each
+// coefficient vector; the caller-supplied all_gather (torch.distributed over RCCL/xGMI) exchanges the
+// 144-byte partial points and every rank adds them, so all ranks see identical commitments.
+struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; } g_shard;
+
+HG1 jac_from(const uint64_t* xyz);
+int sharded_msm(Context& c, const char* d_bases, const Fr* d_scalars, uint64_t n, uint64_t* out_xyz) {
+  if (g_shard.world <= 1) return msm_device(c, d_bases, d_scalars, 1, n, out_xyz);
+  uint64_t lo = (n * (uint64_t)g_shard.rank) / g_shard.world, hi = (n * (uint64_t)(g_shard.rank + 1)) / g_shard.world;
+  uint64_t part[18];
+  MH_TRY(msm_device(c, d_bases + lo * 96, d_scalars + lo, 1, hi - lo, part));
+  std::vector<uint64_t> all((size_t)18 * g_shard.world);
+  if (!g_shard.cb) return fail(MH_EINVAL, "sharded prove: no all_gather callback registered");
+  if (g_shard.cb(part, sizeof(part), all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather callback failed");
+  HG1 acc = HG1::identity();
+  for (int g = 0; g < g_shard.world; g++) acc = acc.add(jac_from(all.data() + 18 * g));
+  memcpy(out_xyz, acc.X.v, 48); memcpy(out_xyz + 6, acc.Y.v, 48); memcpy(out_xyz + 12, acc.Z.v, 48);
+  return MH_OK;
+}
+
 // affine normalisation of an MSM result
 HG1 jac_from(const uint64_t* xyz) { HG1 p; memcpy(p.X.v, xyz, 48); memcpy(p.Y.v, xyz + 6, 48); memcpy(p.Z.v, xyz + 12, 48); return p; }
 
@@ -280,7 +301,7 @@ int kzg_commit(Context& c, ProverKey& pk, const Fr* d_poly, uint64_t len, uint64
   if (it == c.bases.end()) return fail(MH_EINVAL, "prover key refers to a freed SRS handle");
   if (offset + len > it->second.n) return fail(MH_EINVAL, "polynomial degree exceeds the SRS");
   uint64_t xyz[18];
-  MH_TRY(msm_device(c, (const char*)it->second.d_points + offset * 96, d_poly, 1, len, xyz));
+  MH_TRY(sharded_msm(c, (const char*)it->second.d_points + offset * 96, d_poly, len, xyz));
   HG1 comm = jac_from(xyz);
   rand_out->blind.clear();
   if (hiding) {
@@ -327,6 +348,18 @@ int ensure_twiddles_public(Context& c, uint32_t log_n);
   if (!c.inited) return fail(MH_ENOINIT, "mh_init has not been called")
 
 extern "C" {
+
+int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* user) {
+  if (world < 1 || rank < 0 || rank >= world) return fail(MH_EINVAL, "mh_marlin_set_shard: bad rank/world");
+  if (world > 1 && !allgather) return fail(MH_EINVAL, "mh_marlin_set_shard: all_gather callback required for world > 1");
+  g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
+  return MH_OK;
+}
+// host-only hook: runs the registered all_gather once (used by the CPU gloo test of the callback plumbing)
+int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv) {
+  if (!g_shard.cb) return fail(MH_EINVAL, "no all_gather callback registered");
+  return g_shard.cb(send, bytes, recv, g_shard.user);
+}
 
 int mh_marlin_pk_free(uint64_t pk_handle) {
   LOCKED_CTX();
@@ -778,7 +811,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
                                        {pk.t.fr(), H, xi_pow(3)}, {pk.zb.fr(), za_len, xi_pow(4)}}));
     MH_TRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));
     uint64_t xyz[18];
-    MH_TRY(msm_device(c, srs_pts, S[1], 1, mask_len - 1, xyz));
+    MH_TRY(sharded_msm(c, srs_pts, S[1], mask_len - 1, xyz));
     HG1 wacc = jac_from(xyz);
     // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b)
     std::vector<HFr> r;
@@ -793,7 +826,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     // degree-bounded g_1: shifted witness
     MH_TRY(div_linear(c, S[3], pk.g1.fr(), g1_len, beta, S[2]));
     MH_TRY(lincomb(c, S[4], g1_len - 1, {{S[3], g1_len - 1, xi_pow(1)}}));
-    MH_TRY(msm_device(c, srs_pts + (pk.srs_max_degree - (H - 2)) * 96, S[4], 1, g1_len - 1, xyz));
+    MH_TRY(sharded_msm(c, srs_pts + (pk.srs_max_degree - (H - 2)) * 96, S[4], g1_len - 1, xyz));
     HG1 sw = jac_from(xyz);
     // open_with_witness_polynomial(shifted_powers, point, shifted_r, shifted_w, Some(shifted_r_witness)):
     // the hiding witness is always Some(..) on this path, so random_v is always Some(shifted_r(point))
@@ -813,11 +846,11 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     MH_TRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(2)}}));
     MH_TRY(div_linear(c, S[1], S[0], K, gamma, S[2]));
     uint64_t xyz[18];
-    MH_TRY(msm_device(c, srs_pts, S[1], 1, K - 1, xyz));
+    MH_TRY(sharded_msm(c, srs_pts, S[1], K - 1, xyz));
     HG1 wacc = jac_from(xyz);
     MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
     MH_TRY(lincomb(c, S[4], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
-    MH_TRY(msm_device(c, srs_pts + (pk.srs_max_degree - (K - 2)) * 96, S[4], 1, g2_len - 1, xyz));
+    MH_TRY(sharded_msm(c, srs_pts + (pk.srs_max_degree - (K - 2)) * 96, S[4], g2_len - 1, xyz));
     wacc = wacc.add(jac_from(xyz));
     w_gamma = wacc.to_affine();
   }

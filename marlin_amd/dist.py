@@ -1,0 +1,90 @@
+"""Multi-GPU sharding of the MSM (one process per GPU, torch.distributed; backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests).
+
+Rank g multiplies scalars/bases [lo_g, hi_g) of every MSM; the per-rank partial results (one Jacobian
+point, 144 bytes) are exchanged with ONE all_gather per batch of MSMs and summed on every rank, so all
+ranks derive the same commitments and the same Fiat-Shamir challenges.  Elliptic-curve addition is not
+an RCCL reduction operator, hence all_gather + local adds instead of all_reduce.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+
+
+def shard_range(n, rank, world):
+    """contiguous, balanced split of n (scalar, base) pairs."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def g1_sum(points_xyz):
+    """sum of Jacobian points ((k,18) uint64 Montgomery) on the host."""
+    pts = np.ascontiguousarray(points_xyz, dtype=np.uint64).reshape(-1, 18)
+    out = np.zeros(18, dtype=np.uint64)
+    _lib.check(_lib.load().mh_g1_sum(pts.ctypes.data, pts.shape[0], out.ctypes.data), "mh_g1_sum")
+    return out
+
+
+def allgather_partials(partials_xyz, dist, device=None):
+    """partials_xyz: (m,18) uint64 = this rank's partial result of m MSMs.  Returns (world, m, 18)."""
+    import torch
+    local = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 18)
+    t = torch.from_numpy(local.view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return np.stack([o.cpu().numpy().view(np.uint64) for o in out])
+
+
+def combine_partials(gathered):
+    """(world, m, 18) -> (m, 18): per MSM, the sum over ranks."""
+    g = np.asarray(gathered, dtype=np.uint64)
+    return np.stack([g1_sum(g[:, j, :]) for j in range(g.shape[1])])
+
+
+def msm_sharded(bases_shard, d_scalars_shard, counts, dist, device=None, msm_dev=None):
+    """Run this rank's share of a batch of MSMs and combine across ranks.
+    counts[j] = number of local pairs of MSM j (prefix of the local shard)."""
+    from .api import msm_dev as _msm_dev
+    f = msm_dev or _msm_dev
+    partials = np.stack([f(bases_shard, d_scalars_shard, int(cnt)) for cnt in counts])
+    if dist is None or dist.get_world_size() == 1:
+        return partials
+    return combine_partials(allgather_partials(partials, dist, device))
+
+
+# ---- sharded Marlin::prove: register torch.distributed's all_gather as the library's exchange step ----
+_ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+_keepalive = {}
+
+
+def enable_sharded_prove(dist, device=None):
+    """After this call mh_marlin_prove multiplies only this rank's slice of every MSM and combines the
+    partial points across ranks (mh_marlin_set_shard)."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def _cb(send, nbytes, recv, _user):
+        try:
+            src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+            t = torch.from_numpy(src.copy())
+            if device is not None:
+                t = t.to(device)
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+            for g, o in enumerate(out):
+                dst[g * nbytes:(g + 1) * nbytes] = o.cpu().numpy()
+            return 0
+        except Exception as e:      # never unwind into C
+            import sys
+            print("all_gather callback failed:", e, file=sys.stderr)
+            return -1
+    cb = _ALLGATHER_T(_cb)
+    _keepalive["cb"] = cb
+    _lib.check(_lib.load().mh_marlin_set_shard(rank, world, C.cast(cb, C.c_void_p), None), "mh_marlin_set_shard")
+
+
+def disable_sharded_prove():
+    _lib.check(_lib.load().mh_marlin_set_shard(0, 1, None, None), "mh_marlin_set_shard")
+    _keepalive.clear()
