@@ -4,6 +4,8 @@
 #include "ff.cuh"
 #include "g1.cuh"
 #include "msm.cuh"
+#include "msm_tree.cuh"
+#include <cstdlib>
 #include "ntt.cuh"
 #include "srs.cuh"
 #include "host_ff.h"
@@ -150,6 +152,71 @@ static HG1 combine_windows(const std::vector<uint64_t>& win, const msm::Plan& pl
   return acc;
 }
 
+// Pair-tree accumulation (msm_tree.cuh): leaves one XYZZ point per (window, bucket) in c.msm_buckets.
+static int msm_tree_accumulate(Context& c, const void* d_bases, size_t n, const msm::Plan& p) {
+  namespace T = msmtree;
+  hipStream_t s = c.stream;
+  const u64 NB = (u64)p.W * p.nb;
+  const u64 WN = (u64)p.W * n;
+  MH_TRY(c.tr_off[0].ensure((NB + 1) * 4)); MH_TRY(c.tr_off[1].ensure((NB + 1) * 4)); MH_TRY(c.tr_off[2].ensure((NB + 1) * 4));
+  MH_TRY(c.tr_cnt[0].ensure(NB * 4)); MH_TRY(c.tr_cnt[1].ensure(NB * 4));
+  MH_TRY(c.tr_sums.ensure((NB / 1024 + 8) * 4 + 64));
+  const u64 E1max = WN / 2 + NB + 1, E2max = WN / 4 + NB + 1;
+  MH_TRY(c.tr_p[0].ensure(E1max * 96)); MH_TRY(c.tr_p[1].ensure(E2max * 96));
+  MH_TRY(c.tr_ob.ensure(E1max * 4)); MH_TRY(c.tr_pre.ensure(E1max * 48));
+  u32* d_scal = (u32*)((char*)c.tr_sums.ptr + (NB / 1024 + 8) * 4);       // [0] scan total, [1] max bucket size
+  MH_HIP(hipMemsetAsync(d_scal, 0, 16, s));
+  u32* ioff = (u32*)c.tr_off[2].ptr;
+  hipLaunchKernelGGL(T::init_kernel, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, ioff, (const u32*)c.msm_base.ptr,
+                     (const u32*)c.msm_tot.ptr, (u64)n, p.nb, NB, d_scal + 1);
+  u32 maxcnt = 0;
+  MH_HIP(hipMemcpyAsync(&maxcnt, d_scal + 1, 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(hipStreamSynchronize(s));
+  const u32* icnt = (const u32*)c.msm_tot.ptr;
+  const G1Affine* pin = nullptr;
+  int rounds = 0;
+  while ((1u << rounds) < maxcnt) rounds++;
+  for (int r = 0; r < rounds; r++) {
+    u32* ocnt = (u32*)c.tr_cnt[r & 1].ptr;
+    u32* ooff = (u32*)c.tr_off[r & 1].ptr;
+    u32* sums = (u32*)c.tr_sums.ptr;
+    const u64 nblk = (NB + 1023) / 1024;
+    hipLaunchKernelGGL(T::next_counts_kernel, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, ocnt, icnt, NB);
+    hipLaunchKernelGGL(T::scan_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const u32*)ocnt, sums, NB);
+    hipLaunchKernelGGL(T::scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nblk, d_scal);
+    hipLaunchKernelGGL(T::scan_apply_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const u32*)ocnt, (const u32*)sums, ooff, NB,
+                       (const u32*)d_scal);
+    u32 E = 0;
+    MH_HIP(hipMemcpyAsync(&E, d_scal, 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    if (E == 0) break;
+    T::Round rd;
+    rd.bases = (const G1Affine*)d_bases; rd.sorted = (const u32*)c.msm_sorted.ptr; rd.pin = pin;
+    rd.ioff = ioff; rd.icnt = icnt; rd.ooff = ooff; rd.NB = NB; rd.E = E; rd.first = (r == 0);
+    u64 ch = E / (256 * 1024); if (ch < 1) ch = 1; if (ch > 32) ch = 32;
+    rd.T = (E + ch - 1) / ch;
+    MH_TRY(c.tr_prod.ensure(rd.T * 48)); MH_TRY(c.tr_scr.ensure(rd.T * 48));
+    G1Affine* pout = (G1Affine*)c.tr_p[r & 1].ptr;
+    if ((u64)E * 96 > c.tr_p[r & 1].cap) return fail(MH_ENOMEM, "msm tree: output buffer too small");
+    unsigned g = (unsigned)((rd.T + T::TPB - 1) / T::TPB);
+    hipLaunchKernelGGL(T::fwd_kernel, dim3(g), dim3(T::TPB), 0, s, rd, (u32*)c.tr_ob.ptr, (Fq*)c.tr_pre.ptr, (Fq*)c.tr_prod.ptr);
+    hipLaunchKernelGGL(T::inv_kernel, dim3((unsigned)((rd.T + T::INV_CH * 64 - 1) / (T::INV_CH * 64))), dim3(64), 0, s,
+                       (Fq*)c.tr_prod.ptr, (Fq*)c.tr_scr.ptr, rd.T);
+    hipLaunchKernelGGL(T::bwd_kernel, dim3(g), dim3(T::TPB), 0, s, rd, (const u32*)c.tr_ob.ptr, (const Fq*)c.tr_pre.ptr,
+                       (const Fq*)c.tr_prod.ptr, pout);
+    MH_HIP(hipGetLastError());
+    ioff = ooff; icnt = ocnt; pin = pout;
+  }
+  if (pin)
+    hipLaunchKernelGGL(T::to_buckets_kernel, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, (G1Xyzz*)c.msm_buckets.ptr, pin,
+                       (const u32*)ioff, icnt, NB);
+  else
+    hipLaunchKernelGGL(T::to_buckets0_kernel, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, (G1Xyzz*)c.msm_buckets.ptr,
+                       (const G1Affine*)d_bases, (const u32*)c.msm_sorted.ptr, (const u32*)ioff, icnt, NB);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mont, size_t n, uint64_t* out_xyz) {
   if (n == 0) {
     HG1 id = HG1::identity();
@@ -159,6 +226,10 @@ int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mo
   if (n >= (1ull << 31)) return fail(MH_EINVAL, "msm: n must be < 2^31");
   MH_TRY(msm_set_attrs());
   msm::Plan p = msm::make_plan(n);
+  // accumulate algorithm: XYZZ thread-per-bucket by default; the pair tree when bucket sizes are badly skewed
+  // (e.g. many equal scalars), where a thread-per-bucket loop would serialise.  MH_MSM_ALGO=xyzz|tree forces one.
+  static const int forced = [] { const char* e = getenv("MH_MSM_ALGO"); return !e ? 0 : (std::string(e) == "tree" ? 2 : 1); }();
+  bool use_tree = forced == 2;
   const size_t WN = (size_t)p.W * n;
   const size_t WB = (size_t)p.W * p.nb;
   MH_TRY(c.msm_dig.ensure(WN * 4));
@@ -166,6 +237,7 @@ int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mo
   MH_TRY(c.msm_bh.ensure((size_t)p.W * p.ntiles * p.nb * 4));
   MH_TRY(c.msm_tot.ensure(WB * 4));
   MH_TRY(c.msm_base.ensure(WB * 4));
+  MH_TRY(c.msm_pend.ensure(WB * 4));
   MH_TRY(c.msm_buckets.ensure(WB * sizeof(G1Xyzz)));
   MH_TRY(c.msm_seg.ensure((size_t)p.W * p.nseg * sizeof(G1Xyzz)));
   MH_TRY(c.msm_win.ensure((size_t)p.W * sizeof(G1Xyzz)));
@@ -184,11 +256,31 @@ int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mo
     hipLaunchKernelGGL(msm::scatter_kernel, dim3(p.ntiles, p.W), dim3(msm::HIST_THREADS), lds, s,
                        (const u32*)c.msm_dig.ptr, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr,
                        (u32*)c.msm_sorted.ptr, (u64)n, p.nb, p.tile, p.ntiles);
-    {
-      ProfScope pa(c, PF_MSM_ACCUM);
-      hipLaunchKernelGGL(msm::accum_kernel, dim3((unsigned)((WB + 127) / 128)), dim3(128), 0, s, (const G1Affine*)d_bases,
-                         (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr,
+    if (forced == 0) {
+      // largest bucket vs the average load decides (one 4-byte read-back)
+      MH_TRY(c.tr_sums.ensure(64));
+      u32* d_max = (u32*)c.tr_sums.ptr;
+      MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
+      hipLaunchKernelGGL(msm::max_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, s, (const u32*)c.msm_tot.ptr, (u64)WB, d_max);
+      u32 mx = 0;
+      MH_HIP(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s));
+      MH_HIP(hipStreamSynchronize(s));
+      u64 avg = WN / WB + 1;
+      use_tree = mx > 4096 && (u64)mx > 32 * avg;
+    }
+    if (!use_tree) {
+      {
+        ProfScope pa(c, PF_MSM_ACCUM);
+        hipLaunchKernelGGL(msm::accum_kernel, dim3((unsigned)((WB + 127) / 128)), dim3(128), 0, s, (const G1Affine*)d_bases,
+                           (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr,
+                           (G1Xyzz*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, (u64)n, p.nb, p.W);
+      }
+      hipLaunchKernelGGL(msm::fixup_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, (const G1Affine*)d_bases,
+                         (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr,
                          (G1Xyzz*)c.msm_buckets.ptr, (u64)n, p.nb, p.W);
+    } else {
+      ProfScope pa(c, PF_MSM_ACCUM);
+      MH_TRY(msm_tree_accumulate(c, d_bases, n, p));
     }
     hipLaunchKernelGGL(msm::reduce1_kernel, dim3((p.W * p.nseg + 63) / 64), dim3(64), 0, s,
                        (const G1Xyzz*)c.msm_buckets.ptr, (G1Xyzz*)c.msm_seg.ptr, p.nb, p.nseg, p.W);
@@ -305,7 +397,9 @@ int mh_shutdown(void) {
   c.tw = nullptr; c.tw_log = 0;
   c.ntt_tmp[0].release(); c.ntt_tmp[1].release(); c.io.release();
   c.msm_dig.release(); c.msm_sorted.release(); c.msm_bh.release(); c.msm_tot.release(); c.msm_base.release();
-  c.msm_buckets.release(); c.msm_seg.release(); c.msm_win.release();
+  c.msm_buckets.release(); c.msm_seg.release(); c.msm_win.release(); c.msm_pend.release();
+  for (auto& b : c.tr_off) b.release(); for (auto& b : c.tr_cnt) b.release(); for (auto& b : c.tr_p) b.release();
+  c.tr_sums.release(); c.tr_ob.release(); c.tr_pre.release(); c.tr_prod.release(); c.tr_scr.release();
   for (auto& kv : c.bases) if (kv.second.d_points) (void)hipFree(kv.second.d_points);
   c.bases.clear();
   if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }

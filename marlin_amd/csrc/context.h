@@ -79,7 +79,8 @@ struct Context {
   // MSM
   std::map<uint64_t, BaseSet> bases;
   uint64_t next_handle = 1;
-  Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win;
+  Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win, msm_pend;
+  Scratch tr_off[3], tr_cnt[2], tr_p[2], tr_sums, tr_ob, tr_pre, tr_prod, tr_scr;   // pair-tree accumulation
 
   // profiling
   bool prof_on = false;

@@ -112,3 +112,21 @@ def test_msm_empty_and_errors(gpu, bases4k):
         gpu.msm(B, fr_to_np([1] * 9))                      # more scalars than bases
     with pytest.raises(gpu.MarlinHipError):
         gpu.msm(B, fr_to_np([1] * 4), base_offset=6)
+
+
+def test_msm_skewed_buckets_use_pair_tree(gpu, bases4k):
+    """2^16 points, only 3 distinct scalars: a handful of buckets hold ~all points (the thread-per-bucket loop would
+    serialise tens of thousands of additions; the driver switches to the pair-tree accumulation)."""
+    import time
+    pts, dl = bases4k
+    n = 1 << 16
+    big = np.tile(points_to_np(pts), (n // 4096, 1))
+    B = gpu.Bases(big)
+    vals = rand_fr(3, 31)
+    sc = [vals[i % 3] for i in range(n)]
+    t0 = time.time()
+    out = gpu.msm(B, fr_to_np(sc))
+    dt = time.time() - t0
+    k = sum(s * dl[i % 4096] for i, s in enumerate(sc)) % F.R_MOD
+    assert jac_np_to_affine(out) == EC.scalar_mul(EC.G1_GEN, k)
+    assert dt < 5.0
