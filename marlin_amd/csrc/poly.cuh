@@ -189,8 +189,36 @@ __global__ __launch_bounds__(TPB) void divvan_partial_kernel(Fr* __restrict__ pa
   }
   ff_store(partial + t, acc);
 }
-// phase 2: per column, partial[chunk] <- sum of partials of LATER chunks (exclusive suffix)
+// phase 2: per column, partial[chunk] <- sum of partials of LATER chunks (exclusive suffix).
+// One block per column: each thread scans a contiguous run of chunks, the 256 run totals are scanned in LDS.
 __global__ __launch_bounds__(TPB) void divvan_scan_kernel(Fr* __restrict__ partial, u64 n, u64 nchunks) {
+  __shared__ uint4 sh[TPB * 2];
+  Fr* s = reinterpret_cast<Fr*>(sh);
+  const u64 col = blockIdx.x;
+  const u64 per = (nchunks + TPB - 1) / TPB;
+  // thread t owns chunks [lo, hi) counted from the TOP: reversed index rc = nchunks - 1 - c
+  const u64 lo = threadIdx.x * per;
+  u64 hi = lo + per; if (hi > nchunks) hi = nchunks;
+  Fr tot = Fr::zero();
+  for (u64 rc = lo; rc < hi; rc++) tot = ff_add(tot, ff_load(partial + (nchunks - 1 - rc) * n + col));
+  s[threadIdx.x] = tot;
+  __syncthreads();
+  for (int off = 1; off < TPB; off <<= 1) {      // inclusive scan of run totals
+    Fr v = (int)threadIdx.x >= off ? s[threadIdx.x - off] : Fr::zero();
+    __syncthreads();
+    s[threadIdx.x] = ff_add(s[threadIdx.x], v);
+    __syncthreads();
+  }
+  Fr run = ff_sub(s[threadIdx.x], tot);            // sum of the runs above this one
+  for (u64 rc = lo; rc < hi; rc++) {
+    u64 idx = (nchunks - 1 - rc) * n + col;
+    Fr v = ff_load(partial + idx);
+    ff_store(partial + idx, run);
+    run = ff_add(run, v);
+  }
+}
+// same, one thread per column (many columns, few chunks)
+__global__ __launch_bounds__(TPB) void divvan_scan_simple_kernel(Fr* __restrict__ partial, u64 n, u64 nchunks) {
   u64 col = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= n) return;
   Fr run = Fr::zero();
@@ -343,7 +371,7 @@ __global__ __launch_bounds__(TPB) void t_items_kernel(Fr* __restrict__ partial, 
   Fr eta = it.m == 0 ? eta_a.v : (it.m == 1 ? eta_b.v : eta_c.v);
   ff_store(partial + t, ff_mul(acc, eta));
 }
-// out[k] = sum of partial[item_ptr[k] .. item_ptr[k+1])
+// out[k] = sum of partial[item_ptr[k] .. item_ptr[k+1])   (used at two levels so no thread sums more than ~128 values)
 __global__ __launch_bounds__(TPB) void t_sum_kernel(Fr* __restrict__ out, const Fr* __restrict__ partial,
                                                     const u64* __restrict__ item_ptr, u64 H) {
   u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;

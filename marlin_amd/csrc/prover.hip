@@ -64,8 +64,8 @@ struct ProverKey {
   DBuf ev_row, ev_col, ev_row_col, ev_val_a, ev_val_b, ev_val_c;       // evals on K
   DBuf p_row, p_col, p_a_val, p_b_val, p_c_val, p_row_col;            // coefficient form (K each)
   Csr A, B;
-  DBuf t_items, t_erow, t_ecoef, t_item_ptr;
-  uint64_t t_nitems = 0; bool t_has_coef = false;
+  DBuf t_items, t_erow, t_ecoef, t_item_ptr, t_group_ptr;
+  uint64_t t_nitems = 0, t_ngroups = 0; bool t_has_coef = false;
   std::vector<fsh::Commitment> index_comms;
   std::vector<uint8_t> vk_bytes;
   // persistent polynomials of one proof + scratch
@@ -76,7 +76,7 @@ struct ProverKey {
   std::map<std::string, std::pair<const Fr*, uint64_t>> last_polys;   // prover oracles of the last proof (label -> ptr, len)
   void free_all() {
     DBuf* all[] = {&ev_row, &ev_col, &ev_row_col, &ev_val_a, &ev_val_b, &ev_val_c, &p_row, &p_col, &p_a_val, &p_b_val, &p_c_val,
-                   &p_row_col, &A.row_ptr, &A.col, &A.val, &B.row_ptr, &B.col, &B.val, &t_items, &t_erow, &t_ecoef, &t_item_ptr,
+                   &p_row_col, &A.row_ptr, &A.col, &A.val, &B.row_ptr, &B.col, &B.val, &t_items, &t_erow, &t_ecoef, &t_item_ptr, &t_group_ptr,
                    &z, &za_ev, &zb_ev, &xpoly, &w, &za, &zb, &mask, &t, &g1, &h1, &g2, &h2, &outer, &inner, &small, &scal};
     for (auto* b : all) b->release();
     for (auto& s : S) s.release();
@@ -152,7 +152,10 @@ int div_vanishing(Context& c, Fr* q, const Fr* p, uint64_t len, uint64_t n, Fr* 
   uint64_t nchunks = (nrows - 1 + poly::DIV_ROWS - 1) / poly::DIV_ROWS;
   ProfScope ps(c, PF_GLUE);
   KLAUNCH(poly::divvan_partial_kernel, n * nchunks, scratch, p, (u64)len, (u64)n, (u64)nchunks);
-  KLAUNCH(poly::divvan_scan_kernel, n, scratch, (u64)n, (u64)nchunks);
+  if (nchunks > 64 && n <= 65536)
+    hipLaunchKernelGGL(poly::divvan_scan_kernel, dim3((unsigned)n), dim3(poly::TPB), 0, c.stream, scratch, (u64)n, (u64)nchunks);
+  else
+    KLAUNCH(poly::divvan_scan_simple_kernel, n, scratch, (u64)n, (u64)nchunks);
   KLAUNCH(poly::divvan_final_kernel, n * nchunks, q, (const Fr*)scratch, p, (u64)len, (u64)n, (u64)nchunks);
   MH_HIP(hipGetLastError());
   return MH_OK;
@@ -176,7 +179,7 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
     HFr m = M.back();
     for (int i = 0; i < 6; i++) m = m.sqr();     // ^64
     A.push_back(v); L.push_back(nch); M.push_back(m);
-    if (nch <= 2048) break;
+    if (nch <= 64) break;
   }
   // top: carries into the chunks of the last A_j (j = A.size()-2) from A_{j+1} = V.back()
   int top = (int)V.size() - 1;
@@ -512,10 +515,12 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
           if (pk.t_has_coef) { if (m->val[q]) memcpy(&ecoef[4 * pos], m->val[q] + 4 * e, 32); else memcpy(&ecoef[4 * pos], HFr::one().v, 32); }
         }
     std::vector<poly::TItem> items;
-    std::vector<uint64_t> item_ptr(H + 1, 0);
-    const uint32_t ITEM = 128;
+    // two-level grouping: items (<= 128 entries) -> groups (<= 128 items) -> output k
+    std::vector<uint64_t> group_ptr, item_ptr(H + 1, 0);     // group_ptr: item ranges; item_ptr: group ranges per k
+    const uint32_t ITEM = 128, GROUP = 128;
     for (uint64_t k = 0; k < H; k++) {
-      item_ptr[k] = items.size();
+      item_ptr[k] = group_ptr.size();
+      uint64_t first_item = items.size();
       for (int q = 0; q < 3; q++) {
         uint64_t lo = cnt[3 * k + q], hi = cnt[3 * k + q + 1];
         for (uint64_t s = lo; s < hi; s += ITEM) {
@@ -523,13 +528,17 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
           items.push_back(it);
         }
       }
+      for (uint64_t g = first_item; g < items.size(); g += GROUP) group_ptr.push_back(g);
     }
-    item_ptr[H] = items.size();
+    item_ptr[H] = group_ptr.size();
+    pk.t_ngroups = group_ptr.size();
+    group_ptr.push_back(items.size());
     pk.t_nitems = items.size();
     MH_TRY(pk.t_items.alloc(items.size() * sizeof(poly::TItem))); MH_TRY(h2d(c, pk.t_items.p, items.data(), items.size() * sizeof(poly::TItem)));
     MH_TRY(pk.t_erow.alloc(total * 4)); MH_TRY(h2d(c, pk.t_erow.p, erow.data(), total * 4));
     if (pk.t_has_coef) { MH_TRY(pk.t_ecoef.alloc(total * 32)); MH_TRY(h2d(c, pk.t_ecoef.p, ecoef.data(), total * 32)); }
     MH_TRY(pk.t_item_ptr.alloc((H + 1) * 8)); MH_TRY(h2d(c, pk.t_item_ptr.p, item_ptr.data(), (H + 1) * 8));
+    MH_TRY(pk.t_group_ptr.alloc(group_ptr.size() * 8)); MH_TRY(h2d(c, pk.t_group_ptr.p, group_ptr.data(), group_ptr.size() * 8));
     MH_HIP(hipStreamSynchronize(c.stream));
   }
   // ---- workspace ------------------------------------------------------------------------------------------------
@@ -539,7 +548,7 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
   MH_TRY(pk.mask.alloc((3 * H + 8) * 32)); MH_TRY(pk.t.alloc(H * 32)); MH_TRY(pk.g1.alloc(H * 32)); MH_TRY(pk.h1.alloc((3 * H + 8) * 32));
   MH_TRY(pk.g2.alloc(K * 32)); MH_TRY(pk.h2.alloc(K * 32)); MH_TRY(pk.outer.alloc((3 * H + 8) * 32)); MH_TRY(pk.inner.alloc(K * 32));
   for (auto& s : pk.S) MH_TRY(s.alloc(big * 32));
-  MH_TRY(pk.small.alloc((big / 8 + pk.t_nitems + 4096) * 32));
+  MH_TRY(pk.small.alloc((big / 8 + pk.t_nitems + pk.t_ngroups + 4096) * 32));
   MH_TRY(pk.scal.alloc(256));
   MH_TRY(ensure_twiddles_public(c, std::max(pk.logK + 1, pk.logH + 2)));
   MH_HIP(hipStreamSynchronize(c.stream));
@@ -700,7 +709,9 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     Fr* partial = pk.small.fr();
     KLAUNCH(poly::t_items_kernel, pk.t_nitems, partial, (const poly::TItem*)pk.t_items.p, (u64)pk.t_nitems, (const u32*)pk.t_erow.p,
             pk.t_has_coef ? (const Fr*)pk.t_ecoef.p : (const Fr*)nullptr, (const Fr*)S[4], arg(eta_a), arg(eta_b), arg(eta_c));
-    KLAUNCH(poly::t_sum_kernel, H, S[6], (const Fr*)partial, (const u64*)pk.t_item_ptr.p, (u64)H); }
+    Fr* partial2 = partial + pk.t_nitems;
+    KLAUNCH(poly::t_sum_kernel, pk.t_ngroups, partial2, (const Fr*)partial, (const u64*)pk.t_group_ptr.p, (u64)pk.t_ngroups);
+    KLAUNCH(poly::t_sum_kernel, H, S[6], (const Fr*)partial2, (const u64*)pk.t_item_ptr.p, (u64)H); }
   MH_TRY(ntt_device(c, S[6], pk.t.fr(), lgH, 1));
   // z = w * v_X + x  (prover.rs:503-516)
   const uint64_t z_len = w_len + X;
