@@ -119,7 +119,7 @@ class MarlinProve:
         return self.proof
 
 
-def cpu_baseline(log_n_sample=13):
+def cpu_baseline(log_n_sample=16):
     """The C restatement (oracle/c/ref_hotpath.c, kind "port") timed on this host's cores on the
     hot-path inventory of a 2^log_n_sample-constraint prove."""
     from oracle import cref
@@ -228,6 +228,13 @@ def main():
             traffic = json.load(open(pmc)).get("msm_accum_bytes_per_launch")
         except Exception:
             traffic = None
+    # secondary view: the kernel's real bound is the integer multiplier.  One mixed addition = 10 Fq multiplications
+    # = 2880 v_mad_u64_u32; the window plan issues W additions per input pair.
+    W_windows = 16
+    madds_per_s = (msm_pairs_rank * W_windows * args.steps) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
+    valu = {"bound": "valu-int32-mad", "achieved": round(madds_per_s * 2880 / 1e12, 3), "peak": VALU_MAD_PEAK_TOPS, "unit": "T v_mad_u64_u32/s",
+            "frac": round(madds_per_s * 2880 / 1e12 / VALU_MAD_PEAK_TOPS, 4), "mixed_adds_per_s": round(madds_per_s / 1e9, 3),
+            "note": "peak = measured v_mad_u64_u32 issue rate (profiles/r01_microbench.txt); Fq-mul-limited ceiling is 60 Gmul/s = 5.7 G mixed adds/s"}
     roofline = {"bound": "hbm", "kernel": "msm::accum_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_launch_ms, 4),
@@ -251,6 +258,7 @@ def main():
                                   "msm_accum": round(acc_ms / args.steps, 3), "glue": round(glue_ms / args.steps, 3),
                                   "host_and_other": round(ms_per_step - (ntt_ms + msm_ms + glue_ms) / args.steps, 3)},
         "roofline": roofline,
+        "roofline_valu": valu,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -200,14 +200,42 @@ __global__ __launch_bounds__(HIST_THREADS) void scatter_kernel(const u32* __rest
 // front of the bucket's own list and handled by fixup_kernel with the complete group law.  Keeping the
 // slow path (and any call) out of this loop takes the kernel from 248 VGPRs + 304 B of scratch per lane
 // to 166 VGPRs and no scratch (3 waves per SIMD).
-__global__ __launch_bounds__(128) void accum_kernel(const G1Affine* __restrict__ bases, u32* __restrict__ sorted,
-                                                    const u32* __restrict__ base, const u32* __restrict__ tot,
-                                                    G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u64 n, u32 nb,
-                                                    u32 W) {
-  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (u64)W * nb) return;
-  u32 w = (u32)(gid / nb);
-  u32* lst = sorted + (u64)w * n + base[gid];
+//
+// Scheduling: Fq multiplication throughput saturates at 2 waves per SIMD (profiles/r01_occupancy.txt), so what
+// is left to win is idle lanes: bucket sizes are Poisson (sigma ~ 11 at load 128) and a wave runs as long as its
+// largest bucket.  Each block therefore sorts the sizes of its ACC_TPB consecutive buckets in LDS (bitonic, key =
+// size << 8 | index) and thread t takes the t-th largest, so the 64 lanes of a wave get near-equal trip counts.
+// (A persistent variant that handed buckets to lanes dynamically was slower: lanes refilling a bucket stall the
+// lanes that are adding, through the dependent loads of the refill path.)
+constexpr int ACC_TPB = 256;
+__global__ __launch_bounds__(ACC_TPB) void accum_kernel(const G1Affine* __restrict__ bases, u32* __restrict__ sorted,
+                                                        const u32* __restrict__ base, const u32* __restrict__ tot,
+                                                        G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u64 n, u32 nb,
+                                                        u64 WB) {
+  __shared__ u32 keys[ACC_TPB];
+  const u64 lo = (u64)blockIdx.x * ACC_TPB;
+  {
+    u64 g = lo + threadIdx.x;
+    u32 c = g < WB ? tot[g] : 0;
+    if (c > 0xffffffu) c = 0xffffffu;
+    keys[threadIdx.x] = (c << 8) | threadIdx.x;
+  }
+  __syncthreads();
+  for (u32 sz = 2; sz <= ACC_TPB; sz <<= 1) {
+    for (u32 st = sz >> 1; st > 0; st >>= 1) {
+      if (threadIdx.x < ACC_TPB / 2) {
+        u32 i = threadIdx.x;
+        u32 a = 2 * i - (i & (st - 1)), b = a + st;
+        bool desc = ((a & sz) == 0);
+        u32 ka = keys[a], kb = keys[b];
+        if ((ka < kb) == desc) { keys[a] = kb; keys[b] = ka; }
+      }
+      __syncthreads();
+    }
+  }
+  const u64 gid = lo + (keys[threadIdx.x] & 255u);
+  if (gid >= WB) return;
+  u32* lst = sorted + (gid / nb) * n + base[gid];
   const u32 cnt = tot[gid];
   if (cnt == 0) { g1_store_xyzz(buckets + gid, G1Xyzz::identity()); pend[gid] = 0; return; }
   G1Xyzz acc;
