@@ -216,9 +216,8 @@ def main():
     msm_ms, _ = M.prof_get(1)
     glue_ms, _ = M.prof_get(3)
     msm_pairs_rank = sum((n * (rank + 1)) // world - (n * rank) // world for n, _ in wl.msms)
-    if workload == "marlin-prove":      # 6 index-independent launches fewer/more never happen: 15 MSMs per prove
-        acc_launches = max(acc_launches, 1)
-    bytes_per_launch = 128.0 * msm_pairs_rank / len(wl.msms)
+    # the MSMs of a commit round run as one batched launch: bytes per launch = all pairs of the step / launches of the step
+    bytes_per_launch = 128.0 * msm_pairs_rank * args.steps / max(1, acc_launches)
     avg_launch_ms = acc_ms / max(1, acc_launches)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     traffic = None

@@ -85,6 +85,11 @@ int mh_msm(uint64_t bases_handle, size_t base_offset, const uint64_t* scalars, i
            size_t n, uint64_t* out_xyz_mont);
 int mh_msm_dev(uint64_t bases_handle, size_t base_offset, const void* d_scalars, int scalars_are_montgomery,
                size_t n, uint64_t* out_xyz_mont);
+/* Several independent MSMs through one launch sequence (the polynomials of one PC::commit call,
+ * src/lib.rs:172,193,213): job j multiplies ns[j] scalars at d_scalars[j] with bases (handles[j], base_offsets[j]).
+ * out_xyz: njobs x 18 limbs. */
+int mh_msm_batch_dev(size_t njobs, const uint64_t* bases_handles, const size_t* base_offsets, const void* const* d_scalars,
+                     const size_t* ns, int scalars_are_montgomery, uint64_t* out_xyz_mont);
 /* Jacobian -> affine x||y (Montgomery) + infinity flag, on the host (GroupProjective::into_affine) */
 int mh_g1_to_affine(const uint64_t* xyz_mont, uint64_t* xy_mont_out, int* is_infinity_out);
 

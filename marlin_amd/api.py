@@ -165,6 +165,19 @@ def msm_dev(bases, d_scalars, n, base_offset=0, montgomery=True):
     return out
 
 
+def msm_batch_dev(jobs, montgomery=True):
+    """jobs: [(Bases, base_offset, DeviceBuffer or device pointer, n)] -> (len(jobs), 18) uint64 Jacobian results,
+    computed by one batched launch sequence (mh_msm_batch_dev)."""
+    k = len(jobs)
+    handles = (C.c_uint64 * k)(*[j[0].handle for j in jobs])
+    offs = (C.c_size_t * k)(*[int(j[1]) for j in jobs])
+    ptrs = (C.c_void_p * k)(*[(j[2].ptr if isinstance(j[2], DeviceBuffer) else int(j[2])) for j in jobs])
+    ns = (C.c_size_t * k)(*[int(j[3]) for j in jobs])
+    out = np.zeros((k, 18), dtype=np.uint64)
+    _lib.check(_L().mh_msm_batch_dev(k, handles, offs, ptrs, ns, 1 if montgomery else 0, out.ctypes.data), "mh_msm_batch_dev")
+    return out
+
+
 def g1_to_affine(xyz):
     """GroupProjective::into_affine on the host: returns ((12,) uint64 x||y Montgomery, is_infinity)."""
     xyz = np.ascontiguousarray(xyz, dtype=np.uint64)

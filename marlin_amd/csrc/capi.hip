@@ -152,12 +152,12 @@ static HG1 combine_windows(const std::vector<uint64_t>& win, const msm::Plan& pl
   return acc;
 }
 
-// Pair-tree accumulation (msm_tree.cuh): leaves one XYZZ point per (window, bucket) in c.msm_buckets.
-static int msm_tree_accumulate(Context& c, const void* d_bases, size_t n, const msm::Plan& p) {
+// Pair-tree accumulation (msm_tree.cuh): leaves one XYZZ point per (job, window, bucket) in c.msm_buckets.
+static int msm_tree_accumulate(Context& c, const msm::Jobs& jobs, u64 WN, const msm::Plan& p) {
   namespace T = msmtree;
   hipStream_t s = c.stream;
-  const u64 NB = (u64)p.W * p.nb;
-  const u64 WN = (u64)p.W * n;
+  const u32 WT = p.W * jobs.njobs;
+  const u64 NB = (u64)WT * p.nb;
   MH_TRY(c.tr_off[0].ensure((NB + 1) * 4)); MH_TRY(c.tr_off[1].ensure((NB + 1) * 4)); MH_TRY(c.tr_off[2].ensure((NB + 1) * 4));
   MH_TRY(c.tr_cnt[0].ensure(NB * 4)); MH_TRY(c.tr_cnt[1].ensure(NB * 4));
   MH_TRY(c.tr_sums.ensure((NB / 1024 + 8) * 4 + 64));
@@ -168,7 +168,7 @@ static int msm_tree_accumulate(Context& c, const void* d_bases, size_t n, const 
   MH_HIP(hipMemsetAsync(d_scal, 0, 16, s));
   u32* ioff = (u32*)c.tr_off[2].ptr;
   hipLaunchKernelGGL(T::init_kernel, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, ioff, (const u32*)c.msm_base.ptr,
-                     (const u32*)c.msm_tot.ptr, (u64)n, p.nb, NB, d_scal + 1);
+                     (const u32*)c.msm_tot.ptr, jobs, p.nb, p.W, NB, d_scal + 1);
   u32 maxcnt = 0;
   MH_HIP(hipMemcpyAsync(&maxcnt, d_scal + 1, 4, hipMemcpyDeviceToHost, s));
   MH_HIP(hipStreamSynchronize(s));
@@ -191,7 +191,7 @@ static int msm_tree_accumulate(Context& c, const void* d_bases, size_t n, const 
     MH_HIP(hipStreamSynchronize(s));
     if (E == 0) break;
     T::Round rd;
-    rd.bases = (const G1Affine*)d_bases; rd.sorted = (const u32*)c.msm_sorted.ptr; rd.pin = pin;
+    rd.jobs = jobs; rd.wnb = p.W * p.nb; rd.sorted = (const u32*)c.msm_sorted.ptr; rd.pin = pin;
     rd.ioff = ioff; rd.icnt = icnt; rd.ooff = ooff; rd.NB = NB; rd.E = E; rd.first = (r == 0);
     u64 ch = E / (256 * 1024); if (ch < 1) ch = 1; if (ch > 32) ch = 32;
     rd.T = (E + ch - 1) / ch;
@@ -212,91 +212,120 @@ static int msm_tree_accumulate(Context& c, const void* d_bases, size_t n, const 
                        (const u32*)ioff, icnt, NB);
   else
     hipLaunchKernelGGL(T::to_buckets0_kernel, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, (G1Xyzz*)c.msm_buckets.ptr,
-                       (const G1Affine*)d_bases, (const u32*)c.msm_sorted.ptr, (const u32*)ioff, icnt, NB);
+                       jobs, p.W * p.nb, (const u32*)c.msm_sorted.ptr, (const u32*)ioff, icnt, NB);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
 
-int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mont, size_t n, uint64_t* out_xyz) {
-  if (n == 0) {
-    HG1 id = HG1::identity();
-    memcpy(out_xyz, id.X.v, 48); memcpy(out_xyz + 6, id.Y.v, 48); memcpy(out_xyz + 12, id.Z.v, 48);
-    return MH_OK;
-  }
-  if (n >= (1ull << 31)) return fail(MH_EINVAL, "msm: n must be < 2^31");
+// A batch of independent MSMs through one launch sequence.  d_bases[j]: G1Affine[n_j]; d_scalars[j]: Fr[n_j];
+// out_xyz: njobs x 18 limbs (Jacobian).  Jobs with n_j == 0 yield the identity.
+int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const void* const* d_scalars, const size_t* ns,
+                     int is_mont, uint64_t* out_xyz) {
+  HG1 id = HG1::identity();
+  for (int j = 0; j < njobs_in; j++) { memcpy(out_xyz + 18 * j, id.X.v, 48); memcpy(out_xyz + 18 * j + 6, id.Y.v, 48); memcpy(out_xyz + 18 * j + 12, id.Z.v, 48); }
+  // process in groups of at most MAX_JOBS non-empty jobs
+  std::vector<int> live;
+  for (int j = 0; j < njobs_in; j++) if (ns[j]) { if (ns[j] >= (1ull << 31)) return fail(MH_EINVAL, "msm: n must be < 2^31"); live.push_back(j); }
   MH_TRY(msm_set_attrs());
-  msm::Plan p = msm::make_plan(n);
-  // accumulate algorithm: XYZZ thread-per-bucket by default; the pair tree when bucket sizes are badly skewed
-  // (e.g. many equal scalars), where a thread-per-bucket loop would serialise.  MH_MSM_ALGO=xyzz|tree forces one.
-  static const int forced = [] { const char* e = getenv("MH_MSM_ALGO"); return !e ? 0 : (std::string(e) == "tree" ? 2 : 1); }();
-  bool use_tree = forced == 2;
-  const size_t WN = (size_t)p.W * n;
-  const size_t WB = (size_t)p.W * p.nb;
-  MH_TRY(c.msm_dig.ensure(WN * 4));
-  MH_TRY(c.msm_sorted.ensure(WN * 4));
-  MH_TRY(c.msm_bh.ensure((size_t)p.W * p.ntiles * p.nb * 4));
-  MH_TRY(c.msm_tot.ensure(WB * 4));
-  MH_TRY(c.msm_base.ensure(WB * 4));
-  MH_TRY(c.msm_pend.ensure(WB * 4));
-  MH_TRY(c.msm_buckets.ensure(WB * sizeof(G1Xyzz)));
-  MH_TRY(c.msm_seg.ensure((size_t)p.W * p.nseg * sizeof(G1Xyzz)));
-  MH_TRY(c.msm_win.ensure((size_t)p.W * sizeof(G1Xyzz)));
   hipStream_t s = c.stream;
-  {
-    ProfScope ps(c, PF_MSM);
-    hipLaunchKernelGGL(msm::digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const Fr*)d_scalars,
-                       (u32*)c.msm_dig.ptr, (u64)n, p.W, p.win, is_mont);
-    size_t lds = (size_t)p.nb * 4;
-    hipLaunchKernelGGL(msm::hist_kernel, dim3(p.ntiles, p.W), dim3(msm::HIST_THREADS), lds, s, (const u32*)c.msm_dig.ptr,
-                       (u32*)c.msm_bh.ptr, (u64)n, p.nb, p.tile, p.ntiles);
-    hipLaunchKernelGGL(msm::colscan_kernel, dim3((p.nb + 255) / 256, p.W), dim3(256), 0, s, (u32*)c.msm_bh.ptr,
-                       (u32*)c.msm_tot.ptr, p.nb, p.ntiles);
-    hipLaunchKernelGGL(msm::binscan_kernel, dim3(p.W), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr,
-                       (u32*)c.msm_base.ptr, p.nb);
-    hipLaunchKernelGGL(msm::scatter_kernel, dim3(p.ntiles, p.W), dim3(msm::HIST_THREADS), lds, s,
-                       (const u32*)c.msm_dig.ptr, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr,
-                       (u32*)c.msm_sorted.ptr, (u64)n, p.nb, p.tile, p.ntiles);
-    if (forced == 0) {
-      // largest bucket vs the average load decides (one 4-byte read-back)
-      MH_TRY(c.tr_sums.ensure(64));
-      u32* d_max = (u32*)c.tr_sums.ptr;
-      MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
-      hipLaunchKernelGGL(msm::max_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, s, (const u32*)c.msm_tot.ptr, (u64)WB, d_max);
-      u32 mx = 0;
-      MH_HIP(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s));
-      MH_HIP(hipStreamSynchronize(s));
-      u64 avg = WN / WB + 1;
-      use_tree = mx > 4096 && (u64)mx > 32 * avg;
+  static const int forced = [] { const char* e = getenv("MH_MSM_ALGO"); return !e ? 0 : (std::string(e) == "tree" ? 2 : 1); }();
+  for (size_t g0 = 0; g0 < live.size(); g0 += msm::MAX_JOBS) {
+    const int nj = (int)std::min<size_t>(msm::MAX_JOBS, live.size() - g0);
+    size_t nmax = 0, nsum = 0;
+    for (int k = 0; k < nj; k++) { size_t n = ns[live[g0 + k]]; nmax = std::max(nmax, n); nsum += n; }
+    msm::Plan p = msm::make_plan(nmax);
+    // tiles: aim for ~1024 (window, tile) blocks over the whole batch
+    {
+      u64 t = (nsum * p.W + 1023) / 1024;
+      if (t < 4096) t = 4096;
+      if (t > 65536) t = 65536;
+      p.tile = (u32)t;
     }
-    if (!use_tree) {
-      {
-        ProfScope pa(c, PF_MSM_ACCUM);
-        // (forcing 2 resident blocks per CU to make the block count an integral number of rounds was measured
-        //  and is not faster than letting 3 reside: 15.3 vs 14.6 ms at 2^22)
-        const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
-        hipLaunchKernelGGL(msm::accum_kernel, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s,
-                           (const G1Affine*)d_bases, (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr,
-                           (G1Xyzz*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, (u64)n, p.nb, (u64)WB);
+    msm::Jobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    jobs.njobs = nj;
+    u64 ent = 0, bho = 0; u32 max_tiles = 0;
+    for (int k = 0; k < nj; k++) {
+      int j = live[g0 + k];
+      jobs.bases[k] = (const G1Affine*)d_bases[j]; jobs.scalars[k] = (const Fr*)d_scalars[j]; jobs.n[k] = ns[j];
+      jobs.ent_off[k] = ent; ent += (u64)p.W * ns[j];
+      jobs.ntiles[k] = (u32)((ns[j] + p.tile - 1) / p.tile);
+      jobs.bh_off[k] = bho; bho += (u64)p.W * jobs.ntiles[k] * p.nb;
+      max_tiles = std::max(max_tiles, jobs.ntiles[k]);
+    }
+    if (ent >= (1ull << 32)) return fail(MH_EINVAL, "msm batch too large for 32-bit entry offsets");
+    const u64 WN = ent;
+    const u32 WT = p.W * nj;
+    const size_t WB = (size_t)WT * p.nb;
+    MH_TRY(c.msm_dig.ensure(WN * 4)); MH_TRY(c.msm_sorted.ensure(WN * 4)); MH_TRY(c.msm_bh.ensure(bho * 4));
+    MH_TRY(c.msm_tot.ensure(WB * 4)); MH_TRY(c.msm_base.ensure(WB * 4)); MH_TRY(c.msm_pend.ensure(WB * 4));
+    MH_TRY(c.msm_buckets.ensure(WB * sizeof(G1Xyzz)));
+    MH_TRY(c.msm_seg.ensure((size_t)WT * p.nseg * sizeof(G1Xyzz)));
+    MH_TRY(c.msm_win.ensure((size_t)WT * sizeof(G1Xyzz)));
+    {
+      ProfScope ps(c, PF_MSM);
+      hipLaunchKernelGGL(msm::digits_kernel, dim3((unsigned)((nmax + 255) / 256), nj), dim3(256), 0, s, jobs, (u32*)c.msm_dig.ptr,
+                         p.W, p.win, is_mont);
+      size_t lds = (size_t)p.nb * 4;
+      hipLaunchKernelGGL(msm::hist_kernel, dim3(max_tiles, p.W, nj), dim3(msm::HIST_THREADS), lds, s, jobs, (const u32*)c.msm_dig.ptr,
+                         (u32*)c.msm_bh.ptr, p.nb, p.tile);
+      hipLaunchKernelGGL(msm::colscan_kernel, dim3((p.nb + 255) / 256, p.W, nj), dim3(256), 0, s, jobs, (u32*)c.msm_bh.ptr,
+                         (u32*)c.msm_tot.ptr, p.nb, p.W);
+      hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, p.nb);
+      hipLaunchKernelGGL(msm::scatter_kernel, dim3(max_tiles, p.W, nj), dim3(msm::HIST_THREADS), lds, s, jobs,
+                         (const u32*)c.msm_dig.ptr, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr,
+                         p.nb, p.tile, p.W);
+      // accumulate algorithm: XYZZ thread-per-bucket by default; the pair tree when bucket sizes are badly skewed
+      // (e.g. many equal scalars), where a thread-per-bucket loop would serialise.  MH_MSM_ALGO=xyzz|tree forces one.
+      bool use_tree = forced == 2;
+      if (forced == 0) {
+        MH_TRY(c.tr_sums.ensure(64));
+        u32* d_max = (u32*)c.tr_sums.ptr;
+        MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
+        hipLaunchKernelGGL(msm::max_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, s, (const u32*)c.msm_tot.ptr, (u64)WB, d_max);
+        u32 mx = 0;
+        MH_HIP(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipStreamSynchronize(s));
+        u64 avg = WN / WB + 1;
+        use_tree = mx > 4096 && (u64)mx > 32 * avg;
       }
-      hipLaunchKernelGGL(msm::fixup_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, (const G1Affine*)d_bases,
-                         (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr,
-                         (G1Xyzz*)c.msm_buckets.ptr, (u64)n, p.nb, p.W);
-    } else {
-      ProfScope pa(c, PF_MSM_ACCUM);
-      MH_TRY(msm_tree_accumulate(c, d_bases, n, p));
+      if (!use_tree) {
+        {
+          ProfScope pa(c, PF_MSM_ACCUM);
+          // (forcing 2 resident blocks per CU to make the block count an integral number of rounds was measured
+          //  and is not faster than letting 3 reside: 15.3 vs 14.6 ms at 2^22)
+          const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
+          hipLaunchKernelGGL(msm::accum_kernel, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, jobs, (u32*)c.msm_sorted.ptr,
+                             (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (G1Xyzz*)c.msm_buckets.ptr,
+                             (u32*)c.msm_pend.ptr, p.nb, p.W, (u64)WB);
+        }
+        hipLaunchKernelGGL(msm::fixup_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, jobs, (const u32*)c.msm_sorted.ptr,
+                           (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr, (G1Xyzz*)c.msm_buckets.ptr, p.nb, p.W, (u64)WB);
+      } else {
+        ProfScope pa(c, PF_MSM_ACCUM);
+        MH_TRY(msm_tree_accumulate(c, jobs, WN, p));
+      }
+      hipLaunchKernelGGL(msm::reduce1_kernel, dim3((WT * p.nseg + 63) / 64), dim3(64), 0, s, (const G1Xyzz*)c.msm_buckets.ptr,
+                         (G1Xyzz*)c.msm_seg.ptr, p.nb, p.nseg, WT);
+      hipLaunchKernelGGL(msm::reduce2_kernel, dim3(WT), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr, (G1Xyzz*)c.msm_win.ptr, p.nseg);
+      MH_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(msm::reduce1_kernel, dim3((p.W * p.nseg + 63) / 64), dim3(64), 0, s,
-                       (const G1Xyzz*)c.msm_buckets.ptr, (G1Xyzz*)c.msm_seg.ptr, p.nb, p.nseg, p.W);
-    hipLaunchKernelGGL(msm::reduce2_kernel, dim3(p.W), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr,
-                       (G1Xyzz*)c.msm_win.ptr, p.nseg);
-    MH_HIP(hipGetLastError());
+    std::vector<uint64_t> win((size_t)WT * 24);
+    MH_HIP(hipMemcpyAsync(win.data(), c.msm_win.ptr, win.size() * 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < nj; k++) {
+      std::vector<uint64_t> wj(win.begin() + (size_t)k * p.W * 24, win.begin() + (size_t)(k + 1) * p.W * 24);
+      HG1 r = combine_windows(wj, p);
+      uint64_t* o = out_xyz + 18 * live[g0 + k];
+      memcpy(o, r.X.v, 48); memcpy(o + 6, r.Y.v, 48); memcpy(o + 12, r.Z.v, 48);
+    }
   }
-  std::vector<uint64_t> win((size_t)p.W * 24);
-  MH_HIP(hipMemcpyAsync(win.data(), c.msm_win.ptr, win.size() * 8, hipMemcpyDeviceToHost, s));
-  MH_HIP(hipStreamSynchronize(s));
-  HG1 r = combine_windows(win, p);
-  memcpy(out_xyz, r.X.v, 48); memcpy(out_xyz + 6, r.Y.v, 48); memcpy(out_xyz + 12, r.Z.v, 48);
   return MH_OK;
+}
+
+int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mont, size_t n, uint64_t* out_xyz) {
+  const void* b[1] = {d_bases}; const void* sc[1] = {d_scalars}; size_t ns[1] = {n};
+  return msm_batch_device(c, 1, b, sc, ns, is_mont, out_xyz);
 }
 
 // --------------------------------------------------------------------------------
@@ -599,6 +628,23 @@ int mh_msm_dev(uint64_t handle, size_t base_offset, const void* d_scalars, int i
     return fail(MH_EINVAL, "mh_msm: base_offset + n exceeds the uploaded base set");
   if (n && !d_scalars) return fail(MH_EINVAL, "mh_msm: null scalars");
   return msm_device(c, (const char*)it->second.d_points + base_offset * 96, d_scalars, is_mont, n, out_xyz);
+}
+
+int mh_msm_batch_dev(size_t njobs, const uint64_t* handles, const size_t* base_offsets, const void* const* d_scalars,
+                     const size_t* ns, int is_mont, uint64_t* out_xyz) {
+  LOCKED_CTX();
+  if (njobs && (!handles || !base_offsets || !d_scalars || !ns || !out_xyz)) return fail(MH_EINVAL, "mh_msm_batch_dev: null pointer");
+  std::vector<const void*> b(njobs), sc(njobs);
+  for (size_t j = 0; j < njobs; j++) {
+    auto it = c.bases.find(handles[j]);
+    if (it == c.bases.end()) return fail(MH_EINVAL, "mh_msm_batch_dev: unknown bases handle");
+    if (base_offsets[j] > it->second.n || ns[j] > it->second.n - base_offsets[j])
+      return fail(MH_EINVAL, "mh_msm_batch_dev: base_offset + n exceeds the uploaded base set");
+    if (ns[j] && !d_scalars[j]) return fail(MH_EINVAL, "mh_msm_batch_dev: null scalars");
+    b[j] = (const char*)it->second.d_points + base_offsets[j] * 96;
+    sc[j] = d_scalars[j];
+  }
+  return msm_batch_device(c, (int)njobs, b.data(), sc.data(), ns, is_mont, out_xyz);
 }
 
 int mh_msm(uint64_t handle, size_t base_offset, const uint64_t* scalars, int is_mont, size_t n, uint64_t* out_xyz) {

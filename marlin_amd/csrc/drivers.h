@@ -7,6 +7,9 @@ namespace mh {
 int ntt_device(Context& c, const void* d_in, void* d_out, uint32_t log_n, int inverse);
 // MSM: d_bases = G1Affine[n] (Montgomery), d_scalars = Fr[n]; out = Jacobian X||Y||Z (18 u64, Montgomery).
 int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mont, size_t n, uint64_t* out_xyz);
+// a batch of independent MSMs through one launch sequence; out_xyz: njobs x 18 limbs
+int msm_batch_device(Context& c, int njobs, const void* const* d_bases, const void* const* d_scalars, const size_t* ns, int is_mont,
+                     uint64_t* out_xyz);
 // twiddle table (tw[2^(l-1) + e] = omega_{2^l}^e) covering at least log_n levels
 int ensure_twiddles_public(Context& c, uint32_t log_n);
 }  // namespace mh

@@ -55,6 +55,20 @@ struct Plan {
   Windows win;
 };
 
+// A batch of MSMs that share one window plan and run through every stage together (the MSMs of one
+// PC::commit call are independent: src/lib.rs:172,193,213; batching them fills the GPU during the
+// latency-bound sort and reduction stages).  Window index space: gw = job * W + w.
+constexpr int MAX_JOBS = 8;
+struct Jobs {
+  const G1Affine* bases[MAX_JOBS];
+  const Fr* scalars[MAX_JOBS];
+  u64 n[MAX_JOBS];
+  u64 ent_off[MAX_JOBS];   // first element of the job's region in dig / sorted (W * n[j] elements each)
+  u64 bh_off[MAX_JOBS];    // first element of the job's region in the per-tile histogram array
+  u32 ntiles[MAX_JOBS];
+  u32 njobs;
+};
+
 inline Plan make_plan(u64 n) {
   Plan p;
   u32 lg = 0;
@@ -86,11 +100,13 @@ inline Plan make_plan(u64 n) {
 }
 
 // ---- 1. digits -----------------------------------------------------------------
-__global__ __launch_bounds__(256) void digits_kernel(const Fr* __restrict__ scalars, u32* __restrict__ dig,
-                                                     u64 n, u32 W, Windows win, int is_mont) {
+__global__ __launch_bounds__(256) void digits_kernel(Jobs jobs, u32* __restrict__ dig_all, u32 W, Windows win, int is_mont) {
+  const u32 job = blockIdx.y;
+  const u64 n = jobs.n[job];
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fr s = ff_load(scalars + i);
+  u32* dig = dig_all + jobs.ent_off[job];
+  Fr s = ff_load(jobs.scalars[job] + i);
   if (is_mont) s = ff_from_mont(s);
   u32 carry = 0;
   for (u32 w = 0; w < W; w++) {
@@ -110,10 +126,15 @@ __global__ __launch_bounds__(256) void digits_kernel(const Fr* __restrict__ scal
 
 // ---- 2. hist ---------------------------------------------------------------------
 // grid (ntiles, W); LDS: nb u32 counters
-__global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const u32* __restrict__ dig, u32* __restrict__ bh,
-                                                            u64 n, u32 nb, u32 tile, u32 ntiles) {
+__global__ __launch_bounds__(HIST_THREADS) void hist_kernel(Jobs jobs, const u32* __restrict__ dig_all, u32* __restrict__ bh_all,
+                                                            u32 nb, u32 tile) {
   extern __shared__ __attribute__((aligned(16))) u32 h[];
-  const u32 w = blockIdx.y, tb = blockIdx.x;
+  const u32 w = blockIdx.y, tb = blockIdx.x, job = blockIdx.z;
+  const u32 ntiles = jobs.ntiles[job];
+  if (tb >= ntiles) return;
+  const u64 n = jobs.n[job];
+  const u32* dig = dig_all + jobs.ent_off[job];
+  u32* bh = bh_all + jobs.bh_off[job];
   for (u32 b = threadIdx.x; b < nb; b += blockDim.x) h[b] = 0;
   __syncthreads();
   const u64 lo = (u64)tb * tile;
@@ -129,11 +150,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const u32* __restric
 }
 
 // ---- 3. colscan: thread per (w, bucket): exclusive prefix over tiles ----------
-__global__ __launch_bounds__(256) void colscan_kernel(u32* __restrict__ bh, u32* __restrict__ tot, u32 nb,
-                                                      u32 ntiles) {
+__global__ __launch_bounds__(256) void colscan_kernel(Jobs jobs, u32* __restrict__ bh_all, u32* __restrict__ tot_all, u32 nb, u32 W) {
   u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 w = blockIdx.y;
+  u32 w = blockIdx.y, job = blockIdx.z;
   if (b >= nb) return;
+  const u32 ntiles = jobs.ntiles[job];
+  u32* bh = bh_all + jobs.bh_off[job];
+  u32* tot = tot_all + (u64)job * W * nb;
   u32 run = 0;
   u32* p = bh + (u64)w * ntiles * nb + b;
   for (u32 t = 0; t < ntiles; t++) {
@@ -169,11 +192,18 @@ __global__ __launch_bounds__(1024) void binscan_kernel(const u32* __restrict__ t
 }
 
 // ---- 5. scatter -------------------------------------------------------------------
-__global__ __launch_bounds__(HIST_THREADS) void scatter_kernel(const u32* __restrict__ dig, const u32* __restrict__ bh,
-                                                               const u32* __restrict__ base, u32* __restrict__ sorted,
-                                                               u64 n, u32 nb, u32 tile, u32 ntiles) {
+__global__ __launch_bounds__(HIST_THREADS) void scatter_kernel(Jobs jobs, const u32* __restrict__ dig_all, const u32* __restrict__ bh_all,
+                                                               const u32* __restrict__ base_all, u32* __restrict__ sorted_all,
+                                                               u32 nb, u32 tile, u32 W) {
   extern __shared__ __attribute__((aligned(16))) u32 h[];
-  const u32 w = blockIdx.y, tb = blockIdx.x;
+  const u32 w = blockIdx.y, tb = blockIdx.x, job = blockIdx.z;
+  const u32 ntiles = jobs.ntiles[job];
+  if (tb >= ntiles) return;
+  const u64 n = jobs.n[job];
+  const u32* dig = dig_all + jobs.ent_off[job];
+  const u32* bh = bh_all + jobs.bh_off[job];
+  const u32* base = base_all + (u64)job * W * nb;
+  u32* sorted = sorted_all + jobs.ent_off[job];
   const u32* pre = bh + ((u64)w * ntiles + tb) * nb;
   const u32* bs = base + (u64)w * nb;
   for (u32 b = threadIdx.x; b < nb; b += blockDim.x) h[b] = bs[b] + pre[b];
@@ -208,9 +238,9 @@ __global__ __launch_bounds__(HIST_THREADS) void scatter_kernel(const u32* __rest
 // (A persistent variant that handed buckets to lanes dynamically was slower: lanes refilling a bucket stall the
 // lanes that are adding, through the dependent loads of the refill path.)
 constexpr int ACC_TPB = 256;
-__global__ __launch_bounds__(ACC_TPB) void accum_kernel(const G1Affine* __restrict__ bases, u32* __restrict__ sorted,
+__global__ __launch_bounds__(ACC_TPB) void accum_kernel(Jobs jobs, u32* __restrict__ sorted_all,
                                                         const u32* __restrict__ base, const u32* __restrict__ tot,
-                                                        G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u64 n, u32 nb,
+                                                        G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u32 nb, u32 W,
                                                         u64 WB) {
   __shared__ u32 keys[ACC_TPB];
   const u64 lo = (u64)blockIdx.x * ACC_TPB;
@@ -235,7 +265,10 @@ __global__ __launch_bounds__(ACC_TPB) void accum_kernel(const G1Affine* __restri
   }
   const u64 gid = lo + (keys[threadIdx.x] & 255u);
   if (gid >= WB) return;
-  u32* lst = sorted + (gid / nb) * n + base[gid];
+  const u32 job = (u32)(gid / ((u64)W * nb));
+  const u32 w = (u32)((gid / nb) % W);
+  const G1Affine* __restrict__ bases = jobs.bases[job];
+  u32* lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
   const u32 cnt = tot[gid];
   if (cnt == 0) { g1_store_xyzz(buckets + gid, G1Xyzz::identity()); pend[gid] = 0; return; }
   G1Xyzz acc;
@@ -268,15 +301,17 @@ __global__ __launch_bounds__(ACC_TPB) void accum_kernel(const G1Affine* __restri
 }
 
 // deferred entries (see accum_kernel): full group law, one thread per bucket that has any
-__global__ __launch_bounds__(64) void fixup_kernel(const G1Affine* __restrict__ bases, const u32* __restrict__ sorted,
+__global__ __launch_bounds__(64) void fixup_kernel(Jobs jobs, const u32* __restrict__ sorted_all,
                                                    const u32* __restrict__ base, const u32* __restrict__ pend,
-                                                   G1Xyzz* __restrict__ buckets, u64 n, u32 nb, u32 W) {
+                                                   G1Xyzz* __restrict__ buckets, u32 nb, u32 W, u64 WB) {
   u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (u64)W * nb) return;
+  if (gid >= WB) return;
   const u32 np = pend[gid];
   if (np == 0) return;
-  u32 w = (u32)(gid / nb);
-  const u32* lst = sorted + (u64)w * n + base[gid];
+  const u32 job = (u32)(gid / ((u64)W * nb));
+  const u32 w = (u32)((gid / nb) % W);
+  const G1Affine* __restrict__ bases = jobs.bases[job];
+  const u32* lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
   G1Xyzz acc = g1_load_xyzz(buckets + gid);
   for (u32 k = 0; k < np; k++) {
     u32 e = lst[k];

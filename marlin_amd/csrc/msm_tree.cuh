@@ -21,6 +21,7 @@
 // infinity is stored as (0, 0), which is not on y^2 = x^3 + 4.
 #pragma once
 #include "g1.cuh"
+#include "msm.cuh"
 
 namespace msmtree {
 
@@ -76,10 +77,14 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const u32* __restrict__
 
 // round 0 bookkeeping: ioff[B] = w*n + base[B], icnt = tot; also the maximum bucket size (for the round count)
 __global__ __launch_bounds__(256) void init_kernel(u32* __restrict__ ioff, const u32* __restrict__ base, const u32* __restrict__ tot,
-                                                   u64 n, u32 nb, u64 NB, u32* __restrict__ maxcnt) {
+                                                   msm::Jobs jobs, u32 nb, u32 W, u64 NB, u32* __restrict__ maxcnt) {
   u64 B = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u32 m = 0;
-  if (B < NB) { ioff[B] = (u32)((B / nb) * n) + base[B]; m = tot[B]; }
+  if (B < NB) {
+    u32 job = (u32)(B / ((u64)W * nb)), w = (u32)((B / nb) % W);
+    ioff[B] = (u32)(jobs.ent_off[job] + (u64)w * jobs.n[job]) + base[B];
+    m = tot[B];
+  }
   // block max -> one atomic per wave
   for (int off = 32; off > 0; off >>= 1) { u32 o = __shfl_down(m, off); m = o > m ? o : m; }
   if ((threadIdx.x & 63) == 0 && m) atomicMax(maxcnt, m);
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(256) void next_counts_kernel(u32* __restrict__ ocnt
 }
 
 struct Round {
-  const G1Affine* bases;   // round 0: SRS points
+  msm::Jobs jobs;          // round 0: SRS points per job
+  u32 wnb;                 // W * nb (buckets per job)
   const u32* sorted;       // round 0: entries (index | sign << 31)
   const G1Affine* pin;     // rounds >= 1: input points
   const u32* ioff;         // [NB] first input element of bucket B
@@ -104,10 +110,10 @@ struct Round {
 
 __device__ __forceinline__ bool is_inf(const G1Affine& p) { return p.x.is_zero() && p.y.is_zero(); }
 
-__device__ __forceinline__ G1Affine load_in(const Round& r, u64 idx) {
+__device__ __forceinline__ G1Affine load_in(const Round& r, u64 idx, u32 B) {
   if (r.first) {
     u32 e = r.sorted[idx];
-    G1Affine p = g1_load_affine(r.bases + (e & 0x7fffffffu));
+    G1Affine p = g1_load_affine(r.jobs.bases[B / r.wnb] + (e & 0x7fffffffu));
     if (e & 0x80000000u) p.y = ff_neg(p.y);
     return p;
   }
@@ -144,9 +150,9 @@ __global__ __launch_bounds__(TPB) void fwd_kernel(Round r, u32* __restrict__ ob,
     u32 j = (u32)o - r.ooff[B];
     u64 i0 = (u64)r.ioff[B] + 2ull * j;
     bool has2 = 2 * j + 1 < r.icnt[B];
-    G1Affine a = load_in(r, i0);
+    G1Affine a = load_in(r, i0, B);
     G1Affine b = a;
-    if (has2) b = load_in(r, i0 + 1);
+    if (has2) b = load_in(r, i0 + 1, B);
     Fq d;
     int kind = classify(a, b, has2, d);
     ff_store(pre + o, run);
@@ -184,9 +190,9 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(Round r, const u32* __restrict
     u32 j = (u32)o - r.ooff[B];
     u64 i0 = (u64)r.ioff[B] + 2ull * j;
     bool has2 = 2 * j + 1 < r.icnt[B];
-    G1Affine a = load_in(r, i0);
+    G1Affine a = load_in(r, i0, B);
     G1Affine b = a;
-    if (has2) b = load_in(r, i0 + 1);
+    if (has2) b = load_in(r, i0 + 1, B);
     Fq d;
     int kind = classify(a, b, has2, d);
     G1Affine res;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256) void to_buckets_kernel(G1Xyzz* __restrict__ bu
   g1_store_xyzz(buckets + B, r);
 }
 // same when no round ran at all (every bucket has <= 1 entry): read straight from the sorted lists
-__global__ __launch_bounds__(256) void to_buckets0_kernel(G1Xyzz* __restrict__ buckets, const G1Affine* __restrict__ bases,
+__global__ __launch_bounds__(256) void to_buckets0_kernel(G1Xyzz* __restrict__ buckets, msm::Jobs jobs, u32 wnb,
                                                           const u32* __restrict__ sorted, const u32* __restrict__ ioff,
                                                           const u32* __restrict__ cnt, u64 NB) {
   u64 B = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void to_buckets0_kernel(G1Xyzz* __restrict__ b
   G1Xyzz r = G1Xyzz::identity();
   if (cnt[B]) {
     u32 e = sorted[ioff[B]];
-    G1Affine p = g1_load_affine(bases + (e & 0x7fffffffu));
+    G1Affine p = g1_load_affine(jobs.bases[B / wnb] + (e & 0x7fffffffu));
     if (e & 0x80000000u) p.y = ff_neg(p.y);
     r.x = p.x; r.y = p.y; r.zz = Fq::one(); r.zzz = Fq::one();
   }

@@ -203,17 +203,27 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
 struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; } g_shard;
 
 HG1 jac_from(const uint64_t* xyz);
-int sharded_msm(Context& c, const char* d_bases, const Fr* d_scalars, uint64_t n, uint64_t* out_xyz) {
-  if (g_shard.world <= 1) return msm_device(c, d_bases, d_scalars, 1, n, out_xyz);
-  uint64_t lo = (n * (uint64_t)g_shard.rank) / g_shard.world, hi = (n * (uint64_t)(g_shard.rank + 1)) / g_shard.world;
-  uint64_t part[18];
-  MH_TRY(msm_device(c, d_bases + lo * 96, d_scalars + lo, 1, hi - lo, part));
-  std::vector<uint64_t> all((size_t)18 * g_shard.world);
+struct MsmJob { const char* bases; const Fr* scalars; uint64_t n; };
+// all jobs in one launch sequence (msm_batch_device); with sharding, every rank takes slice [lo, hi) of every job and
+// ONE all_gather moves all partial points
+int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<HG1>& out) {
+  const int nj = (int)jobs.size();
+  out.assign(nj, HG1::identity());
+  if (nj == 0) return MH_OK;
+  std::vector<const void*> b(nj), sc(nj); std::vector<size_t> ns(nj);
+  for (int j = 0; j < nj; j++) {
+    uint64_t lo = 0, hi = jobs[j].n;
+    if (g_shard.world > 1) { lo = (jobs[j].n * (uint64_t)g_shard.rank) / g_shard.world; hi = (jobs[j].n * (uint64_t)(g_shard.rank + 1)) / g_shard.world; }
+    b[j] = jobs[j].bases + lo * 96; sc[j] = jobs[j].scalars + lo; ns[j] = hi - lo;
+  }
+  std::vector<uint64_t> part((size_t)18 * nj);
+  MH_TRY(msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), 1, part.data()));
+  if (g_shard.world <= 1) { for (int j = 0; j < nj; j++) out[j] = jac_from(part.data() + 18 * j); return MH_OK; }
   if (!g_shard.cb) return fail(MH_EINVAL, "sharded prove: no all_gather callback registered");
-  if (g_shard.cb(part, sizeof(part), all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather callback failed");
-  HG1 acc = HG1::identity();
-  for (int g = 0; g < g_shard.world; g++) acc = acc.add(jac_from(all.data() + 18 * g));
-  memcpy(out_xyz, acc.X.v, 48); memcpy(out_xyz + 6, acc.Y.v, 48); memcpy(out_xyz + 12, acc.Z.v, 48);
+  std::vector<uint64_t> all(part.size() * g_shard.world);
+  if (g_shard.cb(part.data(), part.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather callback failed");
+  for (int j = 0; j < nj; j++)
+    for (int g = 0; g < g_shard.world; g++) out[j] = out[j].add(jac_from(all.data() + (size_t)g * part.size() + 18 * j));
   return MH_OK;
 }
 
@@ -295,36 +305,47 @@ struct Trace {
   }
 };
 
-// KZG10::commit (ark-poly-commit kzg10 [SURVEY B-3]): MSM over powers_of_g[offset..] plus, when hiding,
-// a fresh 3-coefficient blinding polynomial committed on powers_of_gamma_g.
+// MarlinKZG10::commit for a list of labeled polynomials (ark-poly-commit marlin_pc / kzg10 [SURVEY B-3, B-4]).
+// Per polynomial, in order: KZG10::commit on powers_of_g (drawing a fresh 3-coefficient blinding polynomial from the
+// rng when hiding), then, if degree-bounded, a second KZG10::commit on the shifted powers (fresh draws again).
+// The rng order equals the reference's sequential loop because the MSMs consume no randomness; all the MSMs of the
+// call run as ONE batch.
+struct CommitReq { const Fr* poly; uint64_t len; bool has_bound; uint64_t bound; bool hiding; };
 template <class Rng>
-int kzg_commit(Context& c, ProverKey& pk, const Fr* d_poly, uint64_t len, uint64_t offset, bool hiding, Rng* rng,
-               HG1Affine* out, HidingRand* rand_out) {
+int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs, Rng* rng, std::vector<fsh::Commitment>& comms,
+                  std::vector<PolyRand>& rands) {
   auto it = c.bases.find(pk.srs_g);
   if (it == c.bases.end()) return fail(MH_EINVAL, "prover key refers to a freed SRS handle");
-  if (offset + len > it->second.n) return fail(MH_EINVAL, "polynomial degree exceeds the SRS");
-  uint64_t xyz[18];
-  MH_TRY(sharded_msm(c, (const char*)it->second.d_points + offset * 96, d_poly, len, xyz));
-  HG1 comm = jac_from(xyz);
-  rand_out->blind.clear();
-  if (hiding) {
-    for (int i = 0; i < 3; i++) rand_out->blind.push_back(fsh::fr_rand(*rng));   // P::rand(hiding_bound + 1), hiding_bound = 1
-    comm = comm.add(small_msm(pk.gamma_g, rand_out->blind));
+  const char* pts = (const char*)it->second.d_points;
+  std::vector<MsmJob> jobs;
+  comms.assign(reqs.size(), fsh::Commitment());
+  rands.assign(reqs.size(), PolyRand());
+  for (size_t i = 0; i < reqs.size(); i++) {
+    const CommitReq& q = reqs[i];
+    if (q.len > it->second.n) return fail(MH_EINVAL, "polynomial degree exceeds the SRS");
+    jobs.push_back({pts, q.poly, q.len});
+    if (q.hiding) for (int k = 0; k < 3; k++) rands[i].rand.blind.push_back(fsh::fr_rand(*rng));   // P::rand(hiding_bound + 1)
+    comms[i].has_shifted = q.has_bound; rands[i].has_shifted = q.has_bound;
+    if (q.has_bound) {
+      if (q.len > q.bound + 1) return fail(MH_EINVAL, "polynomial exceeds its degree bound");
+      uint64_t off = pk.srs_max_degree - q.bound;
+      if (off + q.len > it->second.n) return fail(MH_EINVAL, "shifted powers exceed the SRS");
+      jobs.push_back({pts + off * 96, q.poly, q.len});
+      if (q.hiding) for (int k = 0; k < 3; k++) rands[i].shifted.blind.push_back(fsh::fr_rand(*rng));
+    }
   }
-  *out = comm.to_affine();
-  return MH_OK;
-}
-
-// MarlinKZG10::commit for one labeled polynomial [SURVEY B-4]
-template <class Rng>
-int marlin_commit(Context& c, ProverKey& pk, const Fr* d_poly, uint64_t len, bool has_bound, uint64_t bound, bool hiding,
-                  Rng* rng, fsh::Commitment* comm, PolyRand* rand) {
-  MH_TRY(kzg_commit(c, pk, d_poly, len, 0, hiding, rng, &comm->comm, &rand->rand));
-  comm->has_shifted = has_bound;
-  rand->has_shifted = has_bound;
-  if (has_bound) {
-    if (len > bound + 1) return fail(MH_EINVAL, "polynomial exceeds its degree bound");
-    MH_TRY(kzg_commit(c, pk, d_poly, len, pk.srs_max_degree - bound, hiding, rng, &comm->shifted, &rand->shifted));
+  std::vector<HG1> res;
+  MH_TRY(sharded_msm_batch(c, jobs, res));
+  size_t j = 0;
+  for (size_t i = 0; i < reqs.size(); i++) {
+    HG1 cm = res[j++];
+    if (reqs[i].hiding) cm = cm.add(small_msm(pk.gamma_g, rands[i].rand.blind));
+    comms[i].comm = cm.to_affine();
+    if (reqs[i].has_bound) {
+      HG1 sh = res[j++];
+      if (reqs[i].hiding) sh = sh.add(small_msm(pk.gamma_g, rands[i].shifted.blind));
+      comms[i].shifted = sh.to_affine();
+    }
   }
   return MH_OK;
 }
@@ -671,11 +692,11 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   hipLaunchKernelGGL(rng::mask_fix_kernel, dim3(1), dim3(1), 0, c.stream, pk.mask.fr(), (u64)H, (u64)mask_len);
   tr.mark("AHP::Prover::FirstRound (w, z_A, z_B, mask polys)");
   // PC::commit first round (lib.rs:172): w, z_a, z_b hiding 1; mask none
-  fsh::Commitment c_w, c_za, c_zb, c_mask; PolyRand rd_w, rd_za, rd_zb, rd_mask;
-  MH_TRY(marlin_commit(c, pk, pk.w.fr(), w_len, false, 0, true, &zk, &c_w, &rd_w));
-  MH_TRY(marlin_commit(c, pk, pk.za.fr(), za_len, false, 0, true, &zk, &c_za, &rd_za));
-  MH_TRY(marlin_commit(c, pk, pk.zb.fr(), za_len, false, 0, true, &zk, &c_zb, &rd_zb));
-  MH_TRY(marlin_commit(c, pk, pk.mask.fr(), mask_len, false, 0, false, &zk, &c_mask, &rd_mask));
+  std::vector<fsh::Commitment> cm1; std::vector<PolyRand> rd1;
+  MH_TRY(marlin_commit(c, pk, {{pk.w.fr(), w_len, false, 0, true}, {pk.za.fr(), za_len, false, 0, true},
+                               {pk.zb.fr(), za_len, false, 0, true}, {pk.mask.fr(), mask_len, false, 0, false}}, &zk, cm1, rd1));
+  fsh::Commitment &c_w = cm1[0], &c_za = cm1[1], &c_zb = cm1[2], &c_mask = cm1[3];
+  PolyRand &rd_w = rd1[0], &rd_za = rd1[1], &rd_zb = rd1[2];
   {
     std::vector<uint8_t> b;
     fsh::put_commitment(b, c_w); fsh::put_commitment(b, c_za); fsh::put_commitment(b, c_zb); fsh::put_commitment(b, c_mask);
@@ -731,10 +752,11 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   MH_TRY(d2d(c, pk.g1.fr(), S[4] + 1, H - 1));
   const uint64_t g1_len = H - 1;
   tr.mark("AHP::Prover::SecondRound");
-  fsh::Commitment c_t, c_g1, c_h1; PolyRand rd_t, rd_g1, rd_h1;
-  MH_TRY(marlin_commit(c, pk, pk.t.fr(), H, false, 0, false, &zk, &c_t, &rd_t));
-  MH_TRY(marlin_commit(c, pk, pk.g1.fr(), g1_len, true, H - 2, true, &zk, &c_g1, &rd_g1));
-  MH_TRY(marlin_commit(c, pk, pk.h1.fr(), h1_len, false, 0, false, &zk, &c_h1, &rd_h1));
+  std::vector<fsh::Commitment> cm2; std::vector<PolyRand> rd2;
+  MH_TRY(marlin_commit(c, pk, {{pk.t.fr(), H, false, 0, false}, {pk.g1.fr(), g1_len, true, H - 2, true},
+                               {pk.h1.fr(), h1_len, false, 0, false}}, &zk, cm2, rd2));
+  fsh::Commitment &c_t = cm2[0], &c_g1 = cm2[1], &c_h1 = cm2[2];
+  PolyRand& rd_g1 = rd2[1];
   {
     std::vector<uint8_t> b;
     fsh::put_commitment(b, c_t); fsh::put_commitment(b, c_g1); fsh::put_commitment(b, c_h1);
@@ -770,9 +792,9 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   MH_TRY(div_vanishing(c, pk.h2.fr(), S[5], K2, K, S[7]));                         // h_2
   const uint64_t h2_len = K - 1;
   tr.mark("AHP::Prover::ThirdRound");
-  fsh::Commitment c_g2, c_h2; PolyRand rd_g2, rd_h2;
-  MH_TRY(marlin_commit(c, pk, pk.g2.fr(), g2_len, true, K - 2, false, &zk, &c_g2, &rd_g2));
-  MH_TRY(marlin_commit(c, pk, pk.h2.fr(), h2_len, false, 0, false, &zk, &c_h2, &rd_h2));
+  std::vector<fsh::Commitment> cm3; std::vector<PolyRand> rd3;
+  MH_TRY(marlin_commit(c, pk, {{pk.g2.fr(), g2_len, true, K - 2, false}, {pk.h2.fr(), h2_len, false, 0, false}}, &zk, cm3, rd3));
+  fsh::Commitment &c_g2 = cm3[0], &c_h2 = cm3[1];
   {
     std::vector<uint8_t> b;
     fsh::put_commitment(b, c_g2); fsh::put_commitment(b, c_h2);
@@ -815,15 +837,24 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   auto sg = c.bases.find(pk.srs_g);
   if (sg == c.bases.end()) return fail(MH_EINVAL, "prover key refers to a freed SRS handle");
   const char* srs_pts = (const char*)sg->second.d_points;
+  // The four MSMs of the two opening proofs (witness + shifted witness at beta and at gamma) run as one batch.
   // --- at beta: labels g_1, outer_sumcheck, t, z_b  -> challenges xi^0 (g_1), xi^1 (g_1 shifted), xi^2, xi^3, xi^4
+  MH_TRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(2)},
+                                     {pk.t.fr(), H, xi_pow(3)}, {pk.zb.fr(), za_len, xi_pow(4)}}));
+  MH_TRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));                         // witness of the combined polynomial
+  MH_TRY(div_linear(c, S[3], pk.g1.fr(), g1_len, beta, S[2]));                     // degree-bounded g_1: shifted witness
+  MH_TRY(lincomb(c, S[4], g1_len - 1, {{S[3], g1_len - 1, xi_pow(1)}}));
+  // --- at gamma: labels g_2, inner_sumcheck -> challenges xi^0 (g_2), xi^1 (g_2 shifted), xi^2
+  MH_TRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(2)}}));
+  MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
+  MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
+  MH_TRY(lincomb(c, S[6], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
+  std::vector<HG1> om;
+  MH_TRY(sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts + (pk.srs_max_degree - (H - 2)) * 96, S[4], g1_len - 1},
+                               {srs_pts, S[5], K - 1}, {srs_pts + (pk.srs_max_degree - (K - 2)) * 96, S[6], g2_len - 1}}, om));
   HG1Affine w_beta; bool has_rv_beta = false; HFr rv_beta = HFr::zero();
   {
-    MH_TRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(2)},
-                                       {pk.t.fr(), H, xi_pow(3)}, {pk.zb.fr(), za_len, xi_pow(4)}}));
-    MH_TRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));
-    uint64_t xyz[18];
-    MH_TRY(sharded_msm(c, srs_pts, S[1], mask_len - 1, xyz));
-    HG1 wacc = jac_from(xyz);
+    HG1 wacc = om[0];
     // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b)
     std::vector<HFr> r;
     host_axpy(r, HFr::one(), rd_g1.rand.blind);
@@ -834,11 +865,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
       wacc = wacc.add(small_msm(pk.gamma_g, host_div_linear(r, beta)));
       rv_beta = host_eval(r, beta); has_rv_beta = true;
     }
-    // degree-bounded g_1: shifted witness
-    MH_TRY(div_linear(c, S[3], pk.g1.fr(), g1_len, beta, S[2]));
-    MH_TRY(lincomb(c, S[4], g1_len - 1, {{S[3], g1_len - 1, xi_pow(1)}}));
-    MH_TRY(sharded_msm(c, srs_pts + (pk.srs_max_degree - (H - 2)) * 96, S[4], g1_len - 1, xyz));
-    HG1 sw = jac_from(xyz);
+    HG1 sw = om[1];
     // open_with_witness_polynomial(shifted_powers, point, shifted_r, shifted_w, Some(shifted_r_witness)):
     // the hiding witness is always Some(..) on this path, so random_v is always Some(shifted_r(point))
     std::vector<HFr> sr; host_axpy(sr, xi_pow(1), rd_g1.shifted.blind);
@@ -848,23 +875,9 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
       HFr srv = host_eval(sr, beta);
       rv_beta = has_rv_beta ? rv_beta + srv : srv; has_rv_beta = true;
     }
-    wacc = wacc.add(sw);
-    w_beta = wacc.to_affine();
+    w_beta = wacc.add(sw).to_affine();
   }
-  // --- at gamma: labels g_2, inner_sumcheck -> challenges xi^0 (g_2), xi^1 (g_2 shifted), xi^2
-  HG1Affine w_gamma;
-  {
-    MH_TRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(2)}}));
-    MH_TRY(div_linear(c, S[1], S[0], K, gamma, S[2]));
-    uint64_t xyz[18];
-    MH_TRY(sharded_msm(c, srs_pts, S[1], K - 1, xyz));
-    HG1 wacc = jac_from(xyz);
-    MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
-    MH_TRY(lincomb(c, S[4], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
-    MH_TRY(sharded_msm(c, srs_pts + (pk.srs_max_degree - (K - 2)) * 96, S[4], g2_len - 1, xyz));
-    wacc = wacc.add(jac_from(xyz));
-    w_gamma = wacc.to_affine();
-  }
+  HG1Affine w_gamma = om[2].add(om[3]).to_affine();
 
   tr.mark("PC::open_combinations");
   pk.last_polys = {{"w", {pk.w.fr(), w_len}}, {"z_a", {pk.za.fr(), za_len}}, {"z_b", {pk.zb.fr(), za_len}},

@@ -130,3 +130,24 @@ def test_msm_skewed_buckets_use_pair_tree(gpu, bases4k):
     k = sum(s * dl[i % 4096] for i, s in enumerate(sc)) % F.R_MOD
     assert jac_np_to_affine(out) == EC.scalar_mul(EC.G1_GEN, k)
     assert dt < 5.0
+
+
+def test_msm_batch_equals_individual(gpu, bases4k):
+    """mh_msm_batch_dev: jobs of very different sizes, offsets and an empty job give the same group elements as
+    one-at-a-time calls (and the known-dlog answer)."""
+    pts, dl = bases4k
+    B = gpu.Bases(points_to_np(pts))
+    sizes = [4096, 3, 0, 1000, 2500, 17, 4000, 1, 333, 2048]          # 10 jobs > MAX_JOBS: exercises the grouping
+    offs = [0, 5, 0, 3096, 100, 4079, 96, 4095, 1, 2048]
+    bufs, jobs, want = [], [], []
+    for k, (n, off) in enumerate(zip(sizes, offs)):
+        sc = rand_fr(n, 1000 + k)
+        buf = gpu.DeviceBuffer.from_numpy(fr_to_np(sc)) if n else gpu.DeviceBuffer(32)
+        bufs.append(buf)
+        jobs.append((B, off, buf, n))
+        want.append(EC.scalar_mul(EC.G1_GEN, sum(s * a for s, a in zip(sc, dl[off:off + n])) % F.R_MOD) if n else None)
+    out = gpu.msm_batch_dev(jobs)
+    for k in range(len(jobs)):
+        assert jac_np_to_affine(out[k]) == want[k], k
+        if sizes[k]:
+            assert jac_np_to_affine(gpu.msm_dev(B, bufs[k], sizes[k], base_offset=offs[k])) == want[k]
