@@ -267,14 +267,14 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
       hipLaunchKernelGGL(msm::digits_kernel, dim3((unsigned)((nmax + 255) / 256), nj), dim3(256), 0, s, jobs, (u32*)c.msm_dig.ptr,
                          p.W, p.win, is_mont);
       size_t lds = (size_t)p.nb * 4;
-      hipLaunchKernelGGL(msm::hist_kernel, dim3(max_tiles, p.W, nj), dim3(msm::HIST_THREADS), lds, s, jobs, (const u32*)c.msm_dig.ptr,
-                         (u32*)c.msm_bh.ptr, p.nb, p.tile);
+      hipLaunchKernelGGL(msm::hist_kernel, dim3(msm::xcd_grid(max_tiles, WT)), dim3(msm::HIST_THREADS), lds, s, jobs,
+                         (const u32*)c.msm_dig.ptr, (u32*)c.msm_bh.ptr, p.nb, p.tile, max_tiles, p.W);
       hipLaunchKernelGGL(msm::colscan_kernel, dim3((p.nb + 255) / 256, p.W, nj), dim3(256), 0, s, jobs, (u32*)c.msm_bh.ptr,
                          (u32*)c.msm_tot.ptr, p.nb, p.W);
       hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, p.nb);
-      hipLaunchKernelGGL(msm::scatter_kernel, dim3(max_tiles, p.W, nj), dim3(msm::HIST_THREADS), lds, s, jobs,
+      hipLaunchKernelGGL(msm::scatter_kernel, dim3(msm::xcd_grid(max_tiles, WT)), dim3(msm::HIST_THREADS), lds, s, jobs,
                          (const u32*)c.msm_dig.ptr, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr,
-                         p.nb, p.tile, p.W);
+                         p.nb, p.tile, p.W, max_tiles);
       // accumulate algorithm: XYZZ thread-per-bucket by default; the pair tree when bucket sizes are badly skewed
       // (e.g. many equal scalars), where a thread-per-bucket loop would serialise.  MH_MSM_ALGO=xyzz|tree forces one.
       bool use_tree = forced == 2;

@@ -126,10 +126,28 @@ __global__ __launch_bounds__(256) void digits_kernel(Jobs jobs, u32* __restrict_
 
 // ---- 2. hist ---------------------------------------------------------------------
 // grid (ntiles, W); LDS: nb u32 counters
+// XCD-aware block -> (window, tile) mapping for the sort kernels.  Workgroup b is observed to run on XCD b % 8
+// (MI355X_MICROARCH.md, dispatch; used for speed only).  All tiles of one global window gw = job * W + w are given
+// block ids of the same residue mod 8 and consecutive quotients, so each XCD works through "its" windows one
+// after another: the scatter's 4-byte writes into that window's 2^(c-1) bucket lists (<= 2 MB of open cache
+// lines) then combine in that XCD's 4 MB L2 instead of being written back line by line.
+__device__ __forceinline__ void xcd_decode(u32 bid, u32 max_tiles, u32 W, u32 njobs, u32& w, u32& tb, u32& job) {
+  const u32 xcd = bid & 7u, k = bid >> 3;
+  const u32 slot = k / max_tiles;            // which of this XCD's windows
+  tb = k % max_tiles;
+  const u32 gw = slot * 8u + xcd;
+  job = gw / W;
+  w = gw % W;
+  (void)njobs;
+}
+inline u32 xcd_grid(u32 max_tiles, u32 WT) { return ((WT + 7) / 8) * max_tiles * 8; }
+
 __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(Jobs jobs, const u32* __restrict__ dig_all, u32* __restrict__ bh_all,
-                                                            u32 nb, u32 tile) {
+                                                            u32 nb, u32 tile, u32 max_tiles, u32 W) {
   extern __shared__ __attribute__((aligned(16))) u32 h[];
-  const u32 w = blockIdx.y, tb = blockIdx.x, job = blockIdx.z;
+  u32 w, tb, job;
+  xcd_decode(blockIdx.x, max_tiles, W, jobs.njobs, w, tb, job);
+  if (job >= jobs.njobs) return;
   const u32 ntiles = jobs.ntiles[job];
   if (tb >= ntiles) return;
   const u64 n = jobs.n[job];
@@ -194,9 +212,11 @@ __global__ __launch_bounds__(1024) void binscan_kernel(const u32* __restrict__ t
 // ---- 5. scatter -------------------------------------------------------------------
 __global__ __launch_bounds__(HIST_THREADS) void scatter_kernel(Jobs jobs, const u32* __restrict__ dig_all, const u32* __restrict__ bh_all,
                                                                const u32* __restrict__ base_all, u32* __restrict__ sorted_all,
-                                                               u32 nb, u32 tile, u32 W) {
+                                                               u32 nb, u32 tile, u32 W, u32 max_tiles) {
   extern __shared__ __attribute__((aligned(16))) u32 h[];
-  const u32 w = blockIdx.y, tb = blockIdx.x, job = blockIdx.z;
+  u32 w, tb, job;
+  xcd_decode(blockIdx.x, max_tiles, W, jobs.njobs, w, tb, job);
+  if (job >= jobs.njobs) return;
   const u32 ntiles = jobs.ntiles[job];
   if (tb >= ntiles) return;
   const u64 n = jobs.n[job];

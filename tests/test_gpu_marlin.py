@@ -82,7 +82,7 @@ def test_proof_matches_fresh_oracle_and_verifies(gpu):
     assert GM.prove(pk, inst, wit, bytes(32)) != proof
 
 
-@pytest.mark.parametrize("log_n", [12, 16, 18, 20])
+@pytest.mark.parametrize("log_n", [12, 16, 18, 20, 22])
 def test_full_size_proof_verifies(gpu, log_n):
     """BASELINE.json sizes (2^18 = configs[1], 2^20 = configs[2]): the proof of DummyCircuit made on the
     device verifies under the oracle's verifier, and a wrong public input / tampered proof is rejected
@@ -143,3 +143,106 @@ def test_sharded_prove_two_ranks_equals_single(gpu, tmp_path):
         assert p.wait(timeout=300) == 0
     for r in range(2):
         assert open(tmp_path / ("proof%d.bin" % r), "rb").read() == want
+
+
+def _random_r1cs(nc, ni_raw, seed):
+    """random satisfiable R1CS with arbitrary coefficients: rows A_i, B_i are random sparse combinations of the
+    variables, C_i = (c_i / z_j) * e_j for a random non-zero variable j.  Returns an oracle R1CS (unpadded)."""
+    import random
+    R = F.R_MOD
+    rng = random.Random(seed)
+    ni = 1
+    while ni < ni_raw:
+        ni *= 2
+    nvars = nc                                   # square already: nc variables in total
+    inst = [1] + [rng.randrange(R) for _ in range(ni_raw - 1)]
+    inst_p = inst + [0] * (ni - ni_raw)
+    wit = [rng.randrange(1, R) for _ in range(nvars - ni)]
+    z = inst_p + wit
+    A, B, C = [], [], []
+    for _ in range(nc):
+        ra = sorted(set(rng.randrange(nvars) for _ in range(rng.randrange(0, 4))))
+        rb = sorted(set(rng.randrange(nvars) for _ in range(rng.randrange(1, 3))))
+        rowa = [(rng.randrange(1, R) if rng.random() < 0.7 else 1, j) for j in ra]
+        rowb = [(rng.randrange(1, R) if rng.random() < 0.7 else 1, j) for j in rb]
+        va = sum(f * z[j] for f, j in rowa) % R
+        vb = sum(f * z[j] for f, j in rowb) % R
+        j = rng.randrange(ni, nvars)             # a witness column (non-zero value)
+        rowc = [(va * vb % R * pow(z[j], -1, R) % R, j)] if va * vb % R else []
+        A.append(rowa); B.append(rowb); C.append(rowc)
+    return AHP.R1CS(inst, wit, A, B, C), ni
+
+
+def _csr(rows, with_vals=True):
+    from tests.util import fr_to_np
+    import numpy as np
+    rp = np.zeros(len(rows) + 1, dtype=np.uint64)
+    cols, vals = [], []
+    for i, r in enumerate(rows):
+        for f, j in r:
+            cols.append(j); vals.append(f)
+        rp[i + 1] = len(cols)
+    v = fr_to_np(vals) if vals else np.zeros((0, 4), dtype=np.uint64)
+    return rp, np.array(cols, dtype=np.uint32), v
+
+
+@pytest.mark.parametrize("nc,ni_raw,seed", [(40, 3, 1), (64, 8, 2), (100, 5, 3)])
+def test_random_r1cs_with_coefficients_matches_oracle(gpu, nc, ni_raw, seed):
+    """General matrices (non-unit coefficients, empty rows, repeated columns across A/B/C, |X| up to 8):
+    byte-identical proof and index commitments vs the oracle."""
+    from tests.util import fr_to_np
+    cs_raw, ni = _random_r1cs(nc, ni_raw, seed)
+    cs = AHP.pad_and_square(cs_raw)
+    assert cs.num_constraints == nc and len(cs.instance) == ni
+    nnz_bound = 3 * 4 * nc
+    srs_o = MR.universal_setup(nc, nc, nnz_bound, TAU, GAMMA)
+    pk_o = MR.marlin_index(srs_o, cs)
+    pr = MR.prove(pk_o, cs, FS.ChaChaRng(SEED, 20))
+    assert MR.verify(pk_o, cs_raw.instance[1:], pr)
+    srs = GM.universal_setup(nc, nc, nnz_bound, TAU, GAMMA)
+    pk = GM.index(srs, nc, ni, [_csr(cs.a), _csr(cs.b), _csr(cs.c)])
+    assert pk.vk_bytes() == MR.vk_bytes(pk_o)
+    proof = GM.prove(pk, fr_to_np(cs.instance), fr_to_np(cs.witness), SEED)
+    assert proof == MR.proof_bytes(pr)
+
+
+def test_index_and_prove_error_paths(gpu):
+    import numpy as np
+    srs = GM.universal_setup(64, 64, 192, TAU, GAMMA)
+    nc, ni, mats, inst, wit = GM.dummy_circuit(3, 5, 10, 64)
+    with pytest.raises(gpu.MarlinHipError, match="power of two"):
+        GM.index(srs, nc, 3, mats)                                    # InvalidPublicInputLength
+    bad = [(m[0], m[1].copy(), m[2]) for m in mats]
+    bad[0][1][0] = 10 ** 6
+    with pytest.raises(gpu.MarlinHipError, match="column index"):
+        GM.index(srs, nc, ni, bad)
+    small = GM.universal_setup(8, 8, 24, TAU, GAMMA)
+    with pytest.raises(gpu.MarlinHipError, match="IndexTooLarge"):
+        GM.index(small, nc, ni, mats)
+    pk = GM.index(srs, nc, ni, mats)
+    with pytest.raises(AssertionError):
+        GM.prove(pk, inst[:1], wit, SEED)
+    from marlin_amd import _lib
+    import ctypes as C
+    out = (C.c_uint8 * 16)(); n = C.c_size_t()
+    rc = _lib.load().mh_marlin_prove(pk.handle, inst.ctypes.data, wit.ctypes.data, SEED, 20, out, 16, C.byref(n))
+    assert rc != 0 and n.value == GM.PROOF_BYTES                      # buffer too small: reports the needed size
+    rc = _lib.load().mh_marlin_prove(pk.handle, inst.ctypes.data, wit.ctypes.data, SEED, 7, out, 16, C.byref(n))
+    assert rc != 0                                                    # unsupported ChaCha round count
+    rc = _lib.load().mh_marlin_prove(12345, inst.ctypes.data, wit.ctypes.data, SEED, 20, out, 16, C.byref(n))
+    assert rc != 0
+
+
+def test_config0_2p10_plumbing(gpu):
+    """BASELINE.json configs[0]: DummyCircuit, 2^10 constraints, MarlinKZG10 -- still within the Python oracle's
+    reach for the verifier; |H| = 2^10, |K| = 2^12, 21 NTTs <= 2^13, MSMs <= 4095 points."""
+    from tests.verify_adapter import oracle_verify
+    rng = FS.test_rng()
+    a, b = FS.fr_rand(rng), FS.fr_rand(rng)
+    n = 1 << 10
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA)
+    ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
+    pk = GM.index(srs, ncp, ni, mats)
+    assert (pk.H, pk.K, pk.X) == (1 << 10, 1 << 12, 2)
+    proof = GM.prove(pk, inst, wit, SEED)
+    assert oracle_verify(pk.vk_bytes(), srs.max_degree, TAU, GAMMA, [a * b % F.R_MOD], proof)
