@@ -36,7 +36,7 @@ VALU_MAD_PEAK_TOPS = 30.0        # measured v_mad_u64_u32 lane-ops/s (profiles/r
 def rand_fr_np(rng, n):
     """n pseudo-random Montgomery-form Fr elements (< 2^254 < r) as (n,4) uint64."""
     x = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
-    x[:, 3] &= np.uint64((1 << 62) - 1)
+    x[:, 3] &= np.uint64((1 << 61) - 1)
     return x
 
 

@@ -43,6 +43,12 @@ extern "C" {
 
 #define MH_FIELD_BLS12_381_FR 0
 #define MH_CURVE_BLS12_381_G1 0
+#define MH_FIELD_BN254_FR 1
+#define MH_CURVE_BN254_G1 1
+/* The curve is a build-time choice: libmarlin_hip.so is BLS12-381 (Fq = 6 limbs); the same sources built with
+ * -DMH_CURVE_BN254 give libmarlin_hip_bn254.so (Fr and Fq = 4 limbs, G1 affine = 8 limbs, Jacobian = 12 limbs,
+ * two-adicity 28) with the identical ABI.  Each library accepts only its own curve / field id. */
+int mh_curve_info(int* curve_id, int* fr_limbs64, int* fq_limbs64, int* fr_two_adicity);
 
 /* ---- lifecycle ---------------------------------------------------------------- */
 int mh_init(int device_id);               /* idempotent for the same device */

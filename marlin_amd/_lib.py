@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmarlin_hip.so")
+# one library per curve (build-time choice, same ABI); the process picks one with MARLIN_AMD_CURVE
+CURVE = os.environ.get("MARLIN_AMD_CURVE", "bls12_381")
+LIB_PATH = os.path.join(_HERE, {"bls12_381": "libmarlin_hip.so", "bn254": "libmarlin_hip_bn254.so"}[CURVE])
 
 # every symbol include/marlin_hip.h declares: (restype, argtypes)
 _u64p = C.POINTER(C.c_uint64)
@@ -18,6 +20,7 @@ SYMBOLS = {
     "mh_set_stream": (C.c_int, [C.c_void_p]),
     "mh_synchronize": (C.c_int, []),
     "mh_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "mh_curve_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "mh_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "mh_free": (C.c_int, [C.c_void_p]),
     "mh_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -74,7 +77,14 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    cid, frl, fql, adic = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    lib.mh_curve_info(C.byref(cid), C.byref(frl), C.byref(fql), C.byref(adic))
+    global CURVE_ID, FQ_LIMBS, FR_TWO_ADICITY
+    CURVE_ID, FQ_LIMBS, FR_TWO_ADICITY = cid.value, fql.value, adic.value
     return lib
+
+
+CURVE_ID, FQ_LIMBS, FR_TWO_ADICITY = 0, 6, 32
 
 
 def check(rc, what=""):

@@ -3,10 +3,20 @@ import ctypes as C
 import numpy as np
 from . import _lib
 
-FIELD_FR = 0
-CURVE_G1 = 0
+_R_MOD = {"bls12_381": 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+          "bn254": 21888242871839275222246405745257275088548364400416034343698204186575808495617}[_lib.CURVE]
 # 2^256 mod r: the Montgomery representation of 1 in Fr
-FR_ONE_MONT = np.array([0x00000001fffffffe, 0x5884b7fa00034802, 0x998c4fefecbc4ff5, 0x1824b159acc5056f], dtype=np.uint64)
+FR_ONE_MONT = np.array([(((1 << 256) % _R_MOD) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def _curve_id():
+    _L()
+    return _lib.CURVE_ID
+
+
+def _fql():
+    _L()
+    return _lib.FQ_LIMBS
 
 
 def _L():
@@ -90,7 +100,7 @@ def ntt(evals_or_coeffs, inverse=False):
     """Host-buffer NTT (GeneralEvaluationDomain::fft / ifft): (n,4) uint64 Montgomery Fr."""
     a = _as_u64(evals_or_coeffs, 4).copy()
     log_n = _log2_exact(a.shape[0])
-    _lib.check(_L().mh_ntt(FIELD_FR, a.ctypes.data, log_n, 1 if inverse else 0), "mh_ntt")
+    _lib.check(_L().mh_ntt(_curve_id(), a.ctypes.data, log_n, 1 if inverse else 0), "mh_ntt")
     return a
 
 
@@ -102,16 +112,16 @@ def ntt_dev(d_in, d_out, log_n, inverse=False):
     """Device-resident NTT; d_in / d_out are DeviceBuffer or raw device pointers."""
     pi = d_in.ptr if isinstance(d_in, DeviceBuffer) else int(d_in)
     po = d_out.ptr if isinstance(d_out, DeviceBuffer) else int(d_out)
-    _lib.check(_L().mh_ntt_dev(FIELD_FR, pi, po, int(log_n), 1 if inverse else 0), "mh_ntt_dev")
+    _lib.check(_L().mh_ntt_dev(_curve_id(), pi, po, int(log_n), 1 if inverse else 0), "mh_ntt_dev")
 
 
 class Bases:
     """An SRS slice resident on the device (KZG10 powers_of_g): mh_bases_upload."""
 
     def __init__(self, xy_mont):
-        a = _as_u64(xy_mont, 12)
+        a = _as_u64(xy_mont, 2 * _fql())
         h = C.c_uint64()
-        _lib.check(_L().mh_bases_upload(CURVE_G1, a.ctypes.data, a.shape[0], C.byref(h)), "mh_bases_upload")
+        _lib.check(_L().mh_bases_upload(_curve_id(), a.ctypes.data, a.shape[0], C.byref(h)), "mh_bases_upload")
         self.handle = h.value
         self.n = a.shape[0]
 
@@ -124,7 +134,7 @@ class Bases:
             scale_mont = FR_ONE_MONT
         sc = np.ascontiguousarray(scale_mont, dtype=np.uint64).reshape(4)
         h = C.c_uint64()
-        _lib.check(_L().mh_srs_powers(CURVE_G1, tau.ctypes.data, sc.ctypes.data, int(first), int(n), C.byref(h)), "mh_srs_powers")
+        _lib.check(_L().mh_srs_powers(_curve_id(), tau.ctypes.data, sc.ctypes.data, int(first), int(n), C.byref(h)), "mh_srs_powers")
         self = cls.__new__(cls)
         self.handle = h.value
         self.n = int(n)
@@ -132,7 +142,7 @@ class Bases:
 
     def download(self, offset=0, n=None):
         n = self.n - offset if n is None else n
-        out = np.zeros((n, 12), dtype=np.uint64)
+        out = np.zeros((n, 2 * _fql()), dtype=np.uint64)
         _lib.check(_L().mh_bases_download(self.handle, int(offset), int(n), out.ctypes.data), "mh_bases_download")
         return out
 
@@ -151,7 +161,7 @@ class Bases:
 def msm(bases, scalars, base_offset=0, montgomery=True):
     """VariableBaseMSM::multi_scalar_mul: returns Jacobian X||Y||Z as (18,) uint64 (Montgomery)."""
     s = _as_u64(scalars, 4)
-    out = np.zeros(18, dtype=np.uint64)
+    out = np.zeros(3 * _fql(), dtype=np.uint64)
     _lib.check(_L().mh_msm(bases.handle, int(base_offset), s.ctypes.data, 1 if montgomery else 0, s.shape[0],
                            out.ctypes.data), "mh_msm")
     return out
@@ -159,7 +169,7 @@ def msm(bases, scalars, base_offset=0, montgomery=True):
 
 def msm_dev(bases, d_scalars, n, base_offset=0, montgomery=True):
     p = d_scalars.ptr if isinstance(d_scalars, DeviceBuffer) else int(d_scalars)
-    out = np.zeros(18, dtype=np.uint64)
+    out = np.zeros(3 * _fql(), dtype=np.uint64)
     _lib.check(_L().mh_msm_dev(bases.handle, int(base_offset), p, 1 if montgomery else 0, int(n), out.ctypes.data),
                "mh_msm_dev")
     return out
@@ -173,7 +183,7 @@ def msm_batch_dev(jobs, montgomery=True):
     offs = (C.c_size_t * k)(*[int(j[1]) for j in jobs])
     ptrs = (C.c_void_p * k)(*[(j[2].ptr if isinstance(j[2], DeviceBuffer) else int(j[2])) for j in jobs])
     ns = (C.c_size_t * k)(*[int(j[3]) for j in jobs])
-    out = np.zeros((k, 18), dtype=np.uint64)
+    out = np.zeros((k, 3 * _fql()), dtype=np.uint64)
     _lib.check(_L().mh_msm_batch_dev(k, handles, offs, ptrs, ns, 1 if montgomery else 0, out.ctypes.data), "mh_msm_batch_dev")
     return out
 
@@ -181,7 +191,7 @@ def msm_batch_dev(jobs, montgomery=True):
 def g1_to_affine(xyz):
     """GroupProjective::into_affine on the host: returns ((12,) uint64 x||y Montgomery, is_infinity)."""
     xyz = np.ascontiguousarray(xyz, dtype=np.uint64)
-    out = np.zeros(12, dtype=np.uint64)
+    out = np.zeros(2 * _fql(), dtype=np.uint64)
     inf = C.c_int()
     _lib.check(_L().mh_g1_to_affine(xyz.ctypes.data, out.ctypes.data, C.byref(inf)), "mh_g1_to_affine")
     return out, bool(inf.value)

@@ -15,6 +15,7 @@ using hostff::HFq;
 using hostff::HFr;
 using hostff::HG1;
 using hostff::HG1Affine;
+using hostff::FQ_L; using hostff::FQ_B; using hostff::PT_B; using hostff::AFF_L; using hostff::XYZ_L; using hostff::XYZZ_L;
 
 namespace mh {
 thread_local std::string g_err;
@@ -86,7 +87,7 @@ static int ntt_set_attrs() {
 
 // d_in may equal d_out.
 int ntt_device(Context& c, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
-  if (log_n > 32) return fail(MH_EINVAL, "log_n > two-adicity (32)");
+  if (log_n > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "log_n exceeds the two-adicity of Fr");
   size_t bytes = (size_t)32 << log_n;
   if (log_n == 0) {
     if (d_in != d_out) MH_HIP(hipMemcpyAsync(d_out, d_in, 32, hipMemcpyDeviceToDevice, c.stream));
@@ -144,9 +145,9 @@ static HG1 combine_windows(const std::vector<uint64_t>& win, const msm::Plan& pl
   for (int w = (int)pl.W - 1; w >= 0; w--) {
     // acc holds sum_{w' > w} 2^(start[w'] - start[w+1]) * S_w'; shift by the width of window w
     for (uint32_t k = 0; k < pl.win.bits[w]; k++) acc = acc.dbl();
-    const uint64_t* p = win.data() + (size_t)w * 24;
+    const uint64_t* p = win.data() + (size_t)w * XYZZ_L;
     HFq X, Y, ZZ, ZZZ;
-    memcpy(X.v, p, 48); memcpy(Y.v, p + 6, 48); memcpy(ZZ.v, p + 12, 48); memcpy(ZZZ.v, p + 18, 48);
+    memcpy(X.v, p, FQ_B); memcpy(Y.v, p + FQ_L, FQ_B); memcpy(ZZ.v, p + 2 * FQ_L, FQ_B); memcpy(ZZZ.v, p + 3 * FQ_L, FQ_B);
     acc = acc.add(HG1::from_xyzz(X, Y, ZZ, ZZZ));
   }
   return acc;
@@ -162,8 +163,8 @@ static int msm_tree_accumulate(Context& c, const msm::Jobs& jobs, u64 WN, const 
   MH_TRY(c.tr_cnt[0].ensure(NB * 4)); MH_TRY(c.tr_cnt[1].ensure(NB * 4));
   MH_TRY(c.tr_sums.ensure((NB / 1024 + 8) * 4 + 64));
   const u64 E1max = WN / 2 + NB + 1, E2max = WN / 4 + NB + 1;
-  MH_TRY(c.tr_p[0].ensure(E1max * 96)); MH_TRY(c.tr_p[1].ensure(E2max * 96));
-  MH_TRY(c.tr_ob.ensure(E1max * 4)); MH_TRY(c.tr_pre.ensure(E1max * 48));
+  MH_TRY(c.tr_p[0].ensure(E1max * PT_B)); MH_TRY(c.tr_p[1].ensure(E2max * PT_B));
+  MH_TRY(c.tr_ob.ensure(E1max * 4)); MH_TRY(c.tr_pre.ensure(E1max * FQ_B));
   u32* d_scal = (u32*)((char*)c.tr_sums.ptr + (NB / 1024 + 8) * 4);       // [0] scan total, [1] max bucket size
   MH_HIP(hipMemsetAsync(d_scal, 0, 16, s));
   u32* ioff = (u32*)c.tr_off[2].ptr;
@@ -195,9 +196,9 @@ static int msm_tree_accumulate(Context& c, const msm::Jobs& jobs, u64 WN, const 
     rd.ioff = ioff; rd.icnt = icnt; rd.ooff = ooff; rd.NB = NB; rd.E = E; rd.first = (r == 0);
     u64 ch = E / (256 * 1024); if (ch < 1) ch = 1; if (ch > 32) ch = 32;
     rd.T = (E + ch - 1) / ch;
-    MH_TRY(c.tr_prod.ensure(rd.T * 48)); MH_TRY(c.tr_scr.ensure(rd.T * 48));
+    MH_TRY(c.tr_prod.ensure(rd.T * FQ_B)); MH_TRY(c.tr_scr.ensure(rd.T * FQ_B));
     G1Affine* pout = (G1Affine*)c.tr_p[r & 1].ptr;
-    if ((u64)E * 96 > c.tr_p[r & 1].cap) return fail(MH_ENOMEM, "msm tree: output buffer too small");
+    if ((u64)E * PT_B > c.tr_p[r & 1].cap) return fail(MH_ENOMEM, "msm tree: output buffer too small");
     unsigned g = (unsigned)((rd.T + T::TPB - 1) / T::TPB);
     hipLaunchKernelGGL(T::fwd_kernel, dim3(g), dim3(T::TPB), 0, s, rd, (u32*)c.tr_ob.ptr, (Fq*)c.tr_pre.ptr, (Fq*)c.tr_prod.ptr);
     hipLaunchKernelGGL(T::inv_kernel, dim3((unsigned)((rd.T + T::INV_CH * 64 - 1) / (T::INV_CH * 64))), dim3(64), 0, s,
@@ -222,7 +223,7 @@ static int msm_tree_accumulate(Context& c, const msm::Jobs& jobs, u64 WN, const 
 int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const void* const* d_scalars, const size_t* ns,
                      int is_mont, uint64_t* out_xyz) {
   HG1 id = HG1::identity();
-  for (int j = 0; j < njobs_in; j++) { memcpy(out_xyz + 18 * j, id.X.v, 48); memcpy(out_xyz + 18 * j + 6, id.Y.v, 48); memcpy(out_xyz + 18 * j + 12, id.Z.v, 48); }
+  for (int j = 0; j < njobs_in; j++) { memcpy(out_xyz + XYZ_L * j, id.X.v, FQ_B); memcpy(out_xyz + XYZ_L * j + FQ_L, id.Y.v, FQ_B); memcpy(out_xyz + XYZ_L * j + 2 * FQ_L, id.Z.v, FQ_B); }
   // process in groups of at most MAX_JOBS non-empty jobs
   std::vector<int> live;
   for (int j = 0; j < njobs_in; j++) if (ns[j]) { if (ns[j] >= (1ull << 31)) return fail(MH_EINVAL, "msm: n must be < 2^31"); live.push_back(j); }
@@ -310,14 +311,14 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
       hipLaunchKernelGGL(msm::reduce2_kernel, dim3(WT), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr, (G1Xyzz*)c.msm_win.ptr, p.nseg);
       MH_HIP(hipGetLastError());
     }
-    std::vector<uint64_t> win((size_t)WT * 24);
+    std::vector<uint64_t> win((size_t)WT * XYZZ_L);
     MH_HIP(hipMemcpyAsync(win.data(), c.msm_win.ptr, win.size() * 8, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     for (int k = 0; k < nj; k++) {
-      std::vector<uint64_t> wj(win.begin() + (size_t)k * p.W * 24, win.begin() + (size_t)(k + 1) * p.W * 24);
+      std::vector<uint64_t> wj(win.begin() + (size_t)k * p.W * XYZZ_L, win.begin() + (size_t)(k + 1) * p.W * XYZZ_L);
       HG1 r = combine_windows(wj, p);
-      uint64_t* o = out_xyz + 18 * live[g0 + k];
-      memcpy(o, r.X.v, 48); memcpy(o + 6, r.Y.v, 48); memcpy(o + 12, r.Z.v, 48);
+      uint64_t* o = out_xyz + XYZ_L * live[g0 + k];
+      memcpy(o, r.X.v, FQ_B); memcpy(o + FQ_L, r.Y.v, FQ_B); memcpy(o + 2 * FQ_L, r.Z.v, FQ_B);
     }
   }
   return MH_OK;
@@ -335,10 +336,8 @@ static void* g_srs_table = nullptr;   // G1Affine[32][256]
 static int ensure_srs_table(Context& c) {
   if (g_srs_table) return MH_OK;
   // T[w][d] = [d * 256^w] G on the host, batch-normalised
-  static const uint64_t gx[6] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull,
-                                 0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull};
-  static const uint64_t gy[6] = {0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull,
-                                 0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+  uint64_t gx[FQ_L], gy[FQ_L];
+  hostff::g1_generator_canonical(gx, gy);
   HG1Affine g; g.x = HFq::from_canonical(gx); g.y = HFq::from_canonical(gy); g.inf = false;
   const int NW = srs::WINDOWS, NT = srs::TABLE;
   std::vector<HG1> jac((size_t)NW * NT);
@@ -354,7 +353,7 @@ static int ensure_srs_table(Context& c) {
   HFq run = HFq::one();
   for (size_t i = 0; i < jac.size(); i++) { if (!jac[i].is_identity()) run = run * jac[i].Z; prod[i] = run; }
   HFq inv = run.inv();
-  std::vector<uint64_t> host(jac.size() * 12, 0);
+  std::vector<uint64_t> host(jac.size() * AFF_L, 0);
   for (size_t i = jac.size(); i-- > 0;) {
     if (jac[i].is_identity()) continue;
     HFq prev = HFq::one();
@@ -363,7 +362,7 @@ static int ensure_srs_table(Context& c) {
     inv = inv * jac[i].Z;
     HFq zi2 = zi.sqr();
     HFq x = jac[i].X * zi2, y = jac[i].Y * zi2 * zi;
-    memcpy(&host[i * 12], x.v, 48); memcpy(&host[i * 12 + 6], y.v, 48);
+    memcpy(&host[i * AFF_L], x.v, FQ_B); memcpy(&host[i * AFF_L + FQ_L], y.v, FQ_B);
   }
   MH_HIP(hipMalloc(&g_srs_table, host.size() * 8));
   MH_HIP(hipMemcpyAsync(g_srs_table, host.data(), host.size() * 8, hipMemcpyHostToDevice, c.stream));
@@ -474,6 +473,14 @@ int mh_device_info(char* name_out, size_t name_cap, int* cu_count, size_t* hbm_b
   return MH_OK;
 }
 
+int mh_curve_info(int* curve_id, int* fr_limbs64, int* fq_limbs64, int* fr_two_adicity) {
+  if (curve_id) *curve_id = hostff::CURVE_ID;
+  if (fr_limbs64) *fr_limbs64 = HFr::N;
+  if (fq_limbs64) *fq_limbs64 = HFq::N;
+  if (fr_two_adicity) *fr_two_adicity = (int)hostff::FR_TWO_ADICITY_H;
+  return MH_OK;
+}
+
 int mh_alloc(size_t bytes, void** dptr_out) {
   LOCKED_CTX();
   if (!dptr_out) return fail(MH_EINVAL, "mh_alloc: null out pointer");
@@ -518,16 +525,16 @@ int mh_memset(void* dst, int byte, size_t bytes) {
 
 int mh_ntt_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
   LOCKED_CTX();
-  if (field != MH_FIELD_BLS12_381_FR) return fail(MH_EINVAL, "mh_ntt: unsupported field");
+  if (field != hostff::CURVE_ID) return fail(MH_EINVAL, "mh_ntt: unsupported field");
   if (!d_in || !d_out) return fail(MH_EINVAL, "mh_ntt_dev: null pointer");
   return ntt_device(c, d_in, d_out, log_n, inverse);
 }
 
 int mh_ntt(int field, uint64_t* data, uint32_t log_n, int inverse) {
   LOCKED_CTX();
-  if (field != MH_FIELD_BLS12_381_FR) return fail(MH_EINVAL, "mh_ntt: unsupported field");
+  if (field != hostff::CURVE_ID) return fail(MH_EINVAL, "mh_ntt: unsupported field");
   if (!data) return fail(MH_EINVAL, "mh_ntt: null pointer");
-  if (log_n > 32) return fail(MH_EINVAL, "log_n > two-adicity (32)");
+  if (log_n > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "log_n exceeds the two-adicity of Fr");
   size_t bytes = (size_t)32 << log_n;
   MH_TRY(c.io.ensure(bytes));
   MH_HIP(hipMemcpyAsync(c.io.ptr, data, bytes, hipMemcpyHostToDevice, c.stream));
@@ -539,13 +546,13 @@ int mh_ntt(int field, uint64_t* data, uint32_t log_n, int inverse) {
 
 int mh_bases_upload(int curve, const uint64_t* xy, size_t n, uint64_t* handle_out) {
   LOCKED_CTX();
-  if (curve != MH_CURVE_BLS12_381_G1) return fail(MH_EINVAL, "unsupported curve");
+  if (curve != hostff::CURVE_ID) return fail(MH_EINVAL, "unsupported curve");
   if (!handle_out || (!xy && n)) return fail(MH_EINVAL, "mh_bases_upload: null pointer");
   BaseSet b;
   b.n = n;
   if (n) {
-    MH_HIP(hipMalloc(&b.d_points, n * 96));
-    MH_HIP(hipMemcpyAsync(b.d_points, xy, n * 96, hipMemcpyHostToDevice, c.stream));
+    MH_HIP(hipMalloc(&b.d_points, n * PT_B));
+    MH_HIP(hipMemcpyAsync(b.d_points, xy, n * PT_B, hipMemcpyHostToDevice, c.stream));
     MH_HIP(hipStreamSynchronize(c.stream));
   }
   uint64_t h = c.next_handle++;
@@ -556,13 +563,13 @@ int mh_bases_upload(int curve, const uint64_t* xy, size_t n, uint64_t* handle_ou
 
 int mh_bases_from_dev(int curve, const void* d_xy, size_t n, uint64_t* handle_out) {
   LOCKED_CTX();
-  if (curve != MH_CURVE_BLS12_381_G1) return fail(MH_EINVAL, "unsupported curve");
+  if (curve != hostff::CURVE_ID) return fail(MH_EINVAL, "unsupported curve");
   if (!handle_out || (!d_xy && n)) return fail(MH_EINVAL, "mh_bases_from_dev: null pointer");
   BaseSet b;
   b.n = n;
   if (n) {
-    MH_HIP(hipMalloc(&b.d_points, n * 96));
-    MH_HIP(hipMemcpyAsync(b.d_points, d_xy, n * 96, hipMemcpyDeviceToDevice, c.stream));
+    MH_HIP(hipMalloc(&b.d_points, n * PT_B));
+    MH_HIP(hipMemcpyAsync(b.d_points, d_xy, n * PT_B, hipMemcpyDeviceToDevice, c.stream));
     MH_HIP(hipStreamSynchronize(c.stream));
   }
   uint64_t h = c.next_handle++;
@@ -574,12 +581,12 @@ int mh_bases_from_dev(int curve, const void* d_xy, size_t n, uint64_t* handle_ou
 int mh_srs_powers(int curve, const uint64_t* tau_mont, const uint64_t* scale_mont, size_t first, size_t n,
                   uint64_t* handle_out) {
   LOCKED_CTX();
-  if (curve != MH_CURVE_BLS12_381_G1) return fail(MH_EINVAL, "unsupported curve");
+  if (curve != hostff::CURVE_ID) return fail(MH_EINVAL, "unsupported curve");
   if (!tau_mont || !scale_mont || !handle_out) return fail(MH_EINVAL, "mh_srs_powers: null pointer");
   BaseSet b;
   b.n = n;
   if (n) {
-    MH_HIP(hipMalloc(&b.d_points, n * 96));
+    MH_HIP(hipMalloc(&b.d_points, n * PT_B));
     int rc = srs_powers_device(c, tau_mont, scale_mont, n, first, b.d_points);
     if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
     MH_HIP(hipStreamSynchronize(c.stream));
@@ -596,7 +603,7 @@ int mh_bases_download(uint64_t handle, size_t offset, size_t n, uint64_t* xy_out
   if (it == c.bases.end()) return fail(MH_EINVAL, "mh_bases_download: unknown handle");
   if (offset > it->second.n || n > it->second.n - offset) return fail(MH_EINVAL, "mh_bases_download: out of range");
   if (n == 0) return MH_OK;
-  MH_HIP(hipMemcpyAsync(xy_out, (const char*)it->second.d_points + offset * 96, n * 96, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipMemcpyAsync(xy_out, (const char*)it->second.d_points + offset * PT_B, n * PT_B, hipMemcpyDeviceToHost, c.stream));
   MH_HIP(hipStreamSynchronize(c.stream));
   return MH_OK;
 }
@@ -627,7 +634,7 @@ int mh_msm_dev(uint64_t handle, size_t base_offset, const void* d_scalars, int i
   if (base_offset > it->second.n || n > it->second.n - base_offset)
     return fail(MH_EINVAL, "mh_msm: base_offset + n exceeds the uploaded base set");
   if (n && !d_scalars) return fail(MH_EINVAL, "mh_msm: null scalars");
-  return msm_device(c, (const char*)it->second.d_points + base_offset * 96, d_scalars, is_mont, n, out_xyz);
+  return msm_device(c, (const char*)it->second.d_points + base_offset * PT_B, d_scalars, is_mont, n, out_xyz);
 }
 
 int mh_msm_batch_dev(size_t njobs, const uint64_t* handles, const size_t* base_offsets, const void* const* d_scalars,
@@ -641,7 +648,7 @@ int mh_msm_batch_dev(size_t njobs, const uint64_t* handles, const size_t* base_o
     if (base_offsets[j] > it->second.n || ns[j] > it->second.n - base_offsets[j])
       return fail(MH_EINVAL, "mh_msm_batch_dev: base_offset + n exceeds the uploaded base set");
     if (ns[j] && !d_scalars[j]) return fail(MH_EINVAL, "mh_msm_batch_dev: null scalars");
-    b[j] = (const char*)it->second.d_points + base_offsets[j] * 96;
+    b[j] = (const char*)it->second.d_points + base_offsets[j] * PT_B;
     sc[j] = d_scalars[j];
   }
   return msm_batch_device(c, (int)njobs, b.data(), sc.data(), ns, is_mont, out_xyz);
@@ -658,10 +665,10 @@ int mh_msm(uint64_t handle, size_t base_offset, const uint64_t* scalars, int is_
 int mh_g1_to_affine(const uint64_t* xyz, uint64_t* xy_out, int* inf_out) {
   if (!xyz || !xy_out) return fail(MH_EINVAL, "mh_g1_to_affine: null pointer");
   HG1 p;
-  memcpy(p.X.v, xyz, 48); memcpy(p.Y.v, xyz + 6, 48); memcpy(p.Z.v, xyz + 12, 48);
+  memcpy(p.X.v, xyz, FQ_B); memcpy(p.Y.v, xyz + FQ_L, FQ_B); memcpy(p.Z.v, xyz + 2 * FQ_L, FQ_B);
   HG1Affine a = p.to_affine();
   if (a.inf) { a.x = HFq::zero(); a.y = HFq::one(); }   // arkworks GroupAffine::zero() = (0, 1, true)
-  memcpy(xy_out, a.x.v, 48); memcpy(xy_out + 6, a.y.v, 48);
+  memcpy(xy_out, a.x.v, FQ_B); memcpy(xy_out + FQ_L, a.y.v, FQ_B);
   if (inf_out) *inf_out = a.inf ? 1 : 0;
   return MH_OK;
 }
@@ -673,10 +680,10 @@ int mh_g1_sum(const uint64_t* xyz_points, size_t n, uint64_t* out_xyz) {
   HG1 acc = HG1::identity();
   for (size_t i = 0; i < n; i++) {
     HG1 p;
-    memcpy(p.X.v, xyz_points + 18 * i, 48); memcpy(p.Y.v, xyz_points + 18 * i + 6, 48); memcpy(p.Z.v, xyz_points + 18 * i + 12, 48);
+    memcpy(p.X.v, xyz_points + XYZ_L * i, FQ_B); memcpy(p.Y.v, xyz_points + XYZ_L * i + FQ_L, FQ_B); memcpy(p.Z.v, xyz_points + XYZ_L * i + 2 * FQ_L, FQ_B);
     acc = acc.add(p);
   }
-  memcpy(out_xyz, acc.X.v, 48); memcpy(out_xyz + 6, acc.Y.v, 48); memcpy(out_xyz + 12, acc.Z.v, 48);
+  memcpy(out_xyz, acc.X.v, FQ_B); memcpy(out_xyz + FQ_L, acc.Y.v, FQ_B); memcpy(out_xyz + 2 * FQ_L, acc.Z.v, FQ_B);
   return MH_OK;
 }
 

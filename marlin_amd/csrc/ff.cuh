@@ -44,6 +44,22 @@ struct FqParams {
                                  0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
 };
 
+// BN254 (second curve, BASELINE.json configs[4]; ark-bn254 public parameters): r and q are both 254-bit, 8 x u32.
+struct Bn254FrParams {
+  static constexpr int N = 8;
+  static constexpr u32 MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr u32 INV = 0xefffffffu;
+  static constexpr u32 ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr u32 R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+};
+struct Bn254FqParams {
+  static constexpr int N = 8;
+  static constexpr u32 MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr u32 INV = 0xe4866389u;
+  static constexpr u32 ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr u32 R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+};
+
 // ---------------------------------------------------------------------------------
 // generic limb helpers
 // ---------------------------------------------------------------------------------
@@ -215,8 +231,21 @@ __device__ __noinline__ Fp<P> ff_inv(const Fp<P>& a) {
   return acc;
 }
 
-typedef Fp<FrParams> Fr;
-typedef Fp<FqParams> Fq;
+// The curve is a build-time choice: the same sources compile into libmarlin_hip.so (BLS12-381, default) and,
+// with -DMH_CURVE_BN254, into libmarlin_hip_bn254.so.
+#ifdef MH_CURVE_BN254
+typedef Bn254FrParams CurveFrParams;
+typedef Bn254FqParams CurveFqParams;
+constexpr u32 FR_TWO_ADICITY = 28;
+constexpr u32 FR_SHAVE_MASK_TOP32 = 0x3fffffffu;      // REPR_SHAVE_BITS = 2
+#else
+typedef FrParams CurveFrParams;
+typedef FqParams CurveFqParams;
+constexpr u32 FR_TWO_ADICITY = 32;
+constexpr u32 FR_SHAVE_MASK_TOP32 = 0x7fffffffu;      // REPR_SHAVE_BITS = 1
+#endif
+typedef Fp<CurveFrParams> Fr;
+typedef Fp<CurveFqParams> Fq;
 
 // 16-byte vector load/store of a field element (element arrays are 32-B / 48-B
 // strided and at least 16-B aligned).

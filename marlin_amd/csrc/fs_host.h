@@ -109,7 +109,7 @@ static inline hostff::HFr fr_rand(Rng& rng) {
   for (;;) {
     hostff::HFr x;
     for (int i = 0; i < 4; i++) x.v[i] = rng.next_u64();
-    x.v[3] &= 0x7fffffffffffffffull;
+    x.v[3] &= hostff::FR_SHAVE_MASK_TOP64;
     if (!hostff::HFr::geq_mod(x.v)) return x;
   }
 }
@@ -120,8 +120,8 @@ static inline void put_fr(std::vector<uint8_t>& out, const hostff::HFr& x) {
   const uint8_t* p = (const uint8_t*)c; out.insert(out.end(), p, p + 32);
 }
 static inline void put_fq(std::vector<uint8_t>& out, const hostff::HFq& x) {
-  uint64_t c[6]; x.to_canonical(c);
-  const uint8_t* p = (const uint8_t*)c; out.insert(out.end(), p, p + 48);
+  uint64_t c[hostff::FQ_L]; x.to_canonical(c);
+  const uint8_t* p = (const uint8_t*)c; out.insert(out.end(), p, p + hostff::FQ_B);
 }
 static inline void put_u64(std::vector<uint8_t>& out, uint64_t v) { const uint8_t* p = (const uint8_t*)&v; out.insert(out.end(), p, p + 8); }
 // GroupAffine::write: x || y || infinity; the identity is (0, 1, true)

@@ -112,14 +112,58 @@ struct FqP {
   static constexpr uint64_t R2[6] = {0xf4df1f341c341746ull, 0x0a76e6a609d104f1ull, 0x8de5476c4c95b6d5ull,
                                      0x67eb88a9939d83c0ull, 0x9a793e85b519952dull, 0x11988fe592cae3aaull};
 };
+struct Bn254FrP {
+  static constexpr int N = 4;
+  static constexpr uint64_t MOD[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+  static constexpr uint64_t INV = 0xc2e1f593efffffffull;
+  static constexpr uint64_t ONE[4] = {0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full};
+  static constexpr uint64_t R2[4] = {0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull};
+};
+struct Bn254FqP {
+  static constexpr int N = 4;
+  static constexpr uint64_t MOD[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+  static constexpr uint64_t INV = 0x87d20782e4866389ull;
+  static constexpr uint64_t ONE[4] = {0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full};
+  static constexpr uint64_t R2[4] = {0xf32cfc5b538afa89ull, 0xb5e71911d44501fbull, 0x47ab1eff0a417ff6ull, 0x06d89f71cab8351full};
+};
+
+// build-time curve choice (see ff.cuh)
+#ifdef MH_CURVE_BN254
+typedef HFp<Bn254FrP> HFr;
+typedef HFp<Bn254FqP> HFq;
+constexpr int CURVE_ID = 1;
+constexpr uint32_t FR_TWO_ADICITY_H = 28;
+constexpr uint64_t FR_SHAVE_MASK_TOP64 = 0x3fffffffffffffffull;
+// 2^28-th root of unity of Fr (5^((r-1)/2^28)), Montgomery form
+static inline HFr fr_two_adic_root() {
+  static const uint64_t c[4] = {0x9bd61b6e725b19f0ull, 0x402d111e41112ed4ull, 0x00e0a7eb8ef62abcull, 0x2a3c09f0a58a7e85ull};
+  return HFr::from_canonical(c);
+}
+static inline void g1_generator_canonical(uint64_t* gx, uint64_t* gy) { memset(gx, 0, 32); memset(gy, 0, 32); gx[0] = 1; gy[0] = 2; }
+#else
 typedef HFp<FrP> HFr;
 typedef HFp<FqP> HFq;
-
+constexpr int CURVE_ID = 0;
+constexpr uint32_t FR_TWO_ADICITY_H = 32;
+constexpr uint64_t FR_SHAVE_MASK_TOP64 = 0x7fffffffffffffffull;
 // 2^32-th root of unity of Fr (7^((r-1)/2^32)), Montgomery form
 static inline HFr fr_two_adic_root() {
   static const uint64_t c[4] = {0x3829971f439f0d2bull, 0xb63683508c2280b9ull, 0xd09b681922c813b4ull, 0x16a2a19edfe81f20ull};
   return HFr::from_canonical(c);
 }
+static inline void g1_generator_canonical(uint64_t* gx, uint64_t* gy) {
+  static const uint64_t x[6] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull,
+                                0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull};
+  static const uint64_t y[6] = {0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull,
+                                0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+  memcpy(gx, x, 48); memcpy(gy, y, 48);
+}
+#endif
+// sizes that depend on the curve (64-bit limbs / bytes)
+constexpr int FQ_L = HFq::N;                 // limbs per Fq
+constexpr size_t FQ_B = 8 * HFq::N;          // bytes per Fq
+constexpr size_t PT_B = 2 * FQ_B;            // bytes per affine point
+constexpr int AFF_L = 2 * FQ_L, XYZ_L = 3 * FQ_L, XYZZ_L = 4 * FQ_L;
 
 // ---- G1 (Jacobian X,Y,Z; x = X/Z^2, y = Y/Z^3; Z = 0 identity) -- the layout of
 // arkworks' G1Projective.

@@ -44,7 +44,7 @@ __device__ __forceinline__ void lds_store(uint4* s, int idx, const Fr& r) {
 
 // tw table builder: entry i in [1, 2^max_log) : level l = floor(log2 i)+1, e = i - 2^(l-1)
 // value = omega_{2^l}^e, omega_{2^l} = root32 ^ (2^(32-l)).
-__global__ void build_twiddles(Fr* tw, u32 max_log, Fr root32) {
+__global__ void build_twiddles(Fr* tw, u32 max_log, Fr root32 /* the 2^FR_TWO_ADICITY-th root */) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 n = 1ull << max_log;
   if (i >= n) return;
@@ -52,7 +52,7 @@ __global__ void build_twiddles(Fr* tw, u32 max_log, Fr root32) {
   u32 l = 64 - __clzll(i);            // level: 2^(l-1) <= i < 2^l
   u64 e = i - (1ull << (l - 1));
   // omega_{2^l}^e = root32^(e * 2^(32-l)); e < 2^(l-1) so the exponent < 2^31
-  Fr r = ff_pow(root32, e << (32 - l));
+  Fr r = ff_pow(root32, e << (FR_TWO_ADICITY - l));
   ff_store(tw + i, r);
 }
 

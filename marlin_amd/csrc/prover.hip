@@ -27,6 +27,7 @@ using hostff::HFr;
 using hostff::HG1;
 using hostff::HG1Affine;
 using poly::FrArg;
+using hostff::FQ_L; using hostff::FQ_B; using hostff::PT_B; using hostff::AFF_L; using hostff::XYZ_L;
 
 namespace {
 
@@ -214,21 +215,21 @@ int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<H
   for (int j = 0; j < nj; j++) {
     uint64_t lo = 0, hi = jobs[j].n;
     if (g_shard.world > 1) { lo = (jobs[j].n * (uint64_t)g_shard.rank) / g_shard.world; hi = (jobs[j].n * (uint64_t)(g_shard.rank + 1)) / g_shard.world; }
-    b[j] = jobs[j].bases + lo * 96; sc[j] = jobs[j].scalars + lo; ns[j] = hi - lo;
+    b[j] = jobs[j].bases + lo * PT_B; sc[j] = jobs[j].scalars + lo; ns[j] = hi - lo;
   }
-  std::vector<uint64_t> part((size_t)18 * nj);
+  std::vector<uint64_t> part((size_t)XYZ_L * nj);
   MH_TRY(msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), 1, part.data()));
-  if (g_shard.world <= 1) { for (int j = 0; j < nj; j++) out[j] = jac_from(part.data() + 18 * j); return MH_OK; }
+  if (g_shard.world <= 1) { for (int j = 0; j < nj; j++) out[j] = jac_from(part.data() + XYZ_L * j); return MH_OK; }
   if (!g_shard.cb) return fail(MH_EINVAL, "sharded prove: no all_gather callback registered");
   std::vector<uint64_t> all(part.size() * g_shard.world);
   if (g_shard.cb(part.data(), part.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather callback failed");
   for (int j = 0; j < nj; j++)
-    for (int g = 0; g < g_shard.world; g++) out[j] = out[j].add(jac_from(all.data() + (size_t)g * part.size() + 18 * j));
+    for (int g = 0; g < g_shard.world; g++) out[j] = out[j].add(jac_from(all.data() + (size_t)g * part.size() + XYZ_L * j));
   return MH_OK;
 }
 
 // affine normalisation of an MSM result
-HG1 jac_from(const uint64_t* xyz) { HG1 p; memcpy(p.X.v, xyz, 48); memcpy(p.Y.v, xyz + 6, 48); memcpy(p.Z.v, xyz + 12, 48); return p; }
+HG1 jac_from(const uint64_t* xyz) { HG1 p; memcpy(p.X.v, xyz, FQ_B); memcpy(p.Y.v, xyz + FQ_L, FQ_B); memcpy(p.Z.v, xyz + 2 * FQ_L, FQ_B); return p; }
 
 HG1 small_msm(const HG1Affine* bases, const std::vector<HFr>& scalars) {
   HG1 acc = HG1::identity();
@@ -330,7 +331,7 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
       if (q.len > q.bound + 1) return fail(MH_EINVAL, "polynomial exceeds its degree bound");
       uint64_t off = pk.srs_max_degree - q.bound;
       if (off + q.len > it->second.n) return fail(MH_EINVAL, "shifted powers exceed the SRS");
-      jobs.push_back({pts + off * 96, q.poly, q.len});
+      jobs.push_back({pts + off * PT_B, q.poly, q.len});
       if (q.hiding) for (int k = 0; k < 3; k++) rands[i].shifted.blind.push_back(fsh::fr_rand(*rng));
     }
   }
@@ -413,9 +414,9 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
   pk.nc = nc; pk.ni = ni;
   pk.srs_g = srs_g; pk.srs_max_degree = sg->second.n - 1;
   {
-    uint64_t gg[36];
-    MH_HIP(hipMemcpy(gg, sgg->second.d_points, 3 * 96, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 3; i++) { memcpy(pk.gamma_g[i].x.v, gg + 12 * i, 48); memcpy(pk.gamma_g[i].y.v, gg + 12 * i + 6, 48); pk.gamma_g[i].inf = false; }
+    uint64_t gg[3 * AFF_L];
+    MH_HIP(hipMemcpy(gg, sgg->second.d_points, 3 * PT_B, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; i++) { memcpy(pk.gamma_g[i].x.v, gg + AFF_L * i, FQ_B); memcpy(pk.gamma_g[i].y.v, gg + AFF_L * i + FQ_L, FQ_B); pk.gamma_g[i].inf = false; }
   }
   // ---- joint matrix (indexer.rs:83-102): per row, sorted union of the column sets --------------------
   std::vector<uint64_t> jptr(nc + 1, 0);
@@ -436,7 +437,7 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
   pk.H = np2(nc); pk.K = np2(pk.nnz); pk.X = ni;
   pk.logH = log2u(pk.H); pk.logK = log2u(pk.K); pk.logX = log2u(pk.X);
   const uint64_t H = pk.H, K = pk.K, X = pk.X;
-  if (pk.logK + 1 > 32) return fail(MH_EINVAL, "PolynomialDegreeTooLarge");
+  if (pk.logK + 1 > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "PolynomialDegreeTooLarge");
   // AHPForR1CS::max_degree (mod.rs:71-93)
   pk.index_max_degree = std::max(std::max(2 * H + 1 - 2, 3 * H + 2 - 3), std::max(H, K - 1));
   if (pk.srs_max_degree < pk.index_max_degree) return fail(MH_EINVAL, "IndexTooLarge: SRS max degree below the index's");
@@ -447,7 +448,7 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
   std::vector<HFr> elems(H);
   {
     HFr w = hostff::fr_two_adic_root();
-    for (uint32_t i = pk.logH; i < 32; i++) w = w.sqr();
+    for (uint32_t i = pk.logH; i < hostff::FR_TWO_ADICITY_H; i++) w = w.sqr();
     HFr x = HFr::one();
     for (uint64_t i = 0; i < H; i++) { elems[i] = x; x = x * w; }
   }
@@ -496,7 +497,7 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
   // ---- index commitments: PC::commit(ck, index.iter(), None) (lib.rs:123-126) ----------------------------
   pk.index_comms.resize(6);
   for (int q = 0; q < 6; q++) {
-    uint64_t xyz[18];
+    uint64_t xyz[XYZ_L];
     MH_TRY(msm_device(c, sg->second.d_points, pls[q]->p, 1, K, xyz));
     pk.index_comms[q].comm = jac_from(xyz).to_affine();
     pk.index_comms[q].has_shifted = false;
@@ -850,8 +851,8 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
   MH_TRY(lincomb(c, S[6], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
   std::vector<HG1> om;
-  MH_TRY(sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts + (pk.srs_max_degree - (H - 2)) * 96, S[4], g1_len - 1},
-                               {srs_pts, S[5], K - 1}, {srs_pts + (pk.srs_max_degree - (K - 2)) * 96, S[6], g2_len - 1}}, om));
+  MH_TRY(sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts + (pk.srs_max_degree - (H - 2)) * PT_B, S[4], g1_len - 1},
+                               {srs_pts, S[5], K - 1}, {srs_pts + (pk.srs_max_degree - (K - 2)) * PT_B, S[6], g2_len - 1}}, om));
   HG1Affine w_beta; bool has_rv_beta = false; HFr rv_beta = HFr::zero();
   {
     HG1 wacc = om[0];

@@ -43,11 +43,11 @@ __global__ __launch_bounds__(256) void candidates_kernel(Fr* __restrict__ cand, 
     Fr x;
 #pragma unroll
     for (int i = 0; i < 8; i++) x.v[i] = w[8 * h + i];
-    x.v[7] &= 0x7fffffffu;                                  // REPR_SHAVE_BITS = 1
+    x.v[7] &= FR_SHAVE_MASK_TOP32;                          // clear the REPR_SHAVE_BITS top bits
     // accept iff x < r
     u32 borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { u64 d = (u64)x.v[i] - FrParams::MOD[i] - borrow; borrow = (u32)(d >> 63); }
+    for (int i = 0; i < 8; i++) { u64 d = (u64)x.v[i] - CurveFrParams::MOD[i] - borrow; borrow = (u32)(d >> 63); }
     ff_store(cand + (j - c0), x);
     flag[j - c0] = borrow;                                  // 1 = accepted
   }

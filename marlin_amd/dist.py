@@ -18,8 +18,10 @@ def shard_range(n, rank, world):
 
 def g1_sum(points_xyz):
     """sum of Jacobian points ((k,18) uint64 Montgomery) on the host."""
-    pts = np.ascontiguousarray(points_xyz, dtype=np.uint64).reshape(-1, 18)
-    out = np.zeros(18, dtype=np.uint64)
+    _lib.load()
+    L = 3 * _lib.FQ_LIMBS
+    pts = np.ascontiguousarray(points_xyz, dtype=np.uint64).reshape(-1, L)
+    out = np.zeros(L, dtype=np.uint64)
     _lib.check(_lib.load().mh_g1_sum(pts.ctypes.data, pts.shape[0], out.ctypes.data), "mh_g1_sum")
     return out
 
@@ -27,7 +29,8 @@ def g1_sum(points_xyz):
 def allgather_partials(partials_xyz, dist, device=None):
     """partials_xyz: (m,18) uint64 = this rank's partial result of m MSMs.  Returns (world, m, 18)."""
     import torch
-    local = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 18)
+    _lib.load()
+    local = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 3 * _lib.FQ_LIMBS)
     t = torch.from_numpy(local.view(np.int64).copy())
     if device is not None:
         t = t.to(device)

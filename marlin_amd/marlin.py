@@ -7,7 +7,7 @@ import numpy as np
 from . import _lib
 from .api import Bases, FR_ONE_MONT
 
-R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+from .api import _R_MOD as R_MOD
 _MONT_R = (1 << 256) % R_MOD
 
 
@@ -112,7 +112,14 @@ def index(srs, num_constraints, num_instance, matrices):
     return pk
 
 
-PROOF_BYTES = 2143
+def proof_bytes_len(pc="marlin"):
+    """length of the flat proof: G1 = 2 * Fq bytes + 1; Marlin commitment = 2 G1 + 1; Sonic commitment = 1 G1."""
+    g1 = 2 * 8 * _lib.FQ_LIMBS + 1
+    comm = (2 * g1 + 1) if pc == "marlin" else g1
+    return 9 * comm + 4 * 32 + 2 * (g1 + 1 + 32)
+
+
+PROOF_BYTES = 2143        # BLS12-381, MarlinKZG10
 
 
 def prove(pk, instance_mont, witness_mont, zk_seed, zk_rounds=20):

@@ -8,7 +8,7 @@ Blake2s comes from hashlib (RFC 7693, 32-byte digest == blake2 0.9 `Blake2s`).
 """
 import hashlib
 import struct
-from .fields import R_MOD, FR_MONT_RINV
+from .fields import R_MOD, FR_MONT_RINV, FR_REPR_SHAVE_BITS
 
 MASK32 = 0xFFFFFFFF
 
@@ -86,7 +86,7 @@ def fr_rand(rng):
     < r; the accepted limbs ARE the Montgomery representation.  Returns the canonical value."""
     while True:
         limbs = [rng.next_u64() for _ in range(4)]
-        limbs[3] &= (1 << 63) - 1
+        limbs[3] &= (1 << (64 - FR_REPR_SHAVE_BITS)) - 1
         x = limbs[0] | (limbs[1] << 64) | (limbs[2] << 128) | (limbs[3] << 192)
         if x < R_MOD:
             return x * FR_MONT_RINV % R_MOD

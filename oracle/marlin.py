@@ -6,7 +6,7 @@ behaviour of ark-poly-commit 0.3 `kzg10` / `marlin_pc` (third-party, absent; SUR
 B-3, B-4, B-6 [UPSTREAM-RECALLED]).  Pairing checks are replaced by the known-tau identity
 (C - [v]G - [rv]gammaG == [tau - z]W), which is what e(.,.) verifies when tau is known.
 """
-from .fields import R_MOD as R, Q_MOD
+from .fields import R_MOD as R, Q_MOD, FQ_BYTES
 from . import curve as EC
 from . import ahp as AHP
 from .poly import trim, poly_eval, divide_by_linear, degree
@@ -36,8 +36,8 @@ def g1_bytes(pt):
     """ToBytes of GroupAffine: x || y (48 B LE canonical each) || infinity byte [B-6].
     The identity is (0, 1, true)."""
     if pt is None:
-        return (0).to_bytes(48, "little") + (1).to_bytes(48, "little") + b"\x01"
-    return pt[0].to_bytes(48, "little") + pt[1].to_bytes(48, "little") + b"\x00"
+        return (0).to_bytes(FQ_BYTES, "little") + (1).to_bytes(FQ_BYTES, "little") + b"\x01"
+    return pt[0].to_bytes(FQ_BYTES, "little") + pt[1].to_bytes(FQ_BYTES, "little") + b"\x00"
 
 
 def commitment_bytes(c):

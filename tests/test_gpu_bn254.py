@@ -1,0 +1,24 @@
+"""Second curve (BASELINE.json configs[4]): the same sources built with -DMH_CURVE_BN254
+(libmarlin_hip_bn254.so) pass the same kernel-level parity tests against the oracle restated over BN254
+(y^2 = x^3 + 3, generator (1, 2), 254-bit r and q, two-adicity 28).  The curve is selected per process
+(MARLIN_AMD_CURVE / ORACLE_CURVE), so the suite runs in a subprocess."""
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(files, extra=()):
+    env = dict(os.environ, MARLIN_AMD_CURVE="bn254", ORACLE_CURVE="bn254")
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + list(extra) + files
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_bn254_ntt_msm_srs_parity():
+    out = _run(["tests/test_gpu_ntt.py", "tests/test_gpu_msm.py", "tests/test_gpu_srs.py"])
+    assert " passed" in out

@@ -30,30 +30,32 @@ def np_to_fr(arr, montgomery=True):
 
 def fq_to_limbs(x):
     x = F.fq_to_mont(x % F.Q_MOD)
-    return [(x >> (64 * k)) & MASK64 for k in range(6)]
+    return [(x >> (64 * k)) & MASK64 for k in range(F.FQ_LIMBS64)]
 
 
 def limbs_to_fq(limbs):
     x = 0
-    for k in range(6):
+    for k in range(F.FQ_LIMBS64):
         x |= int(limbs[k]) << (64 * k)
     return F.fq_from_mont(x)
 
 
 def points_to_np(points):
     """list of affine (x, y) ints -> (n,12) uint64 x||y Montgomery."""
-    out = np.zeros((len(points), 12), dtype=np.uint64)
+    L = F.FQ_LIMBS64
+    out = np.zeros((len(points), 2 * L), dtype=np.uint64)
     for i, (x, y) in enumerate(points):
-        out[i, :6] = fq_to_limbs(x)
-        out[i, 6:] = fq_to_limbs(y)
+        out[i, :L] = fq_to_limbs(x)
+        out[i, L:] = fq_to_limbs(y)
     return out
 
 
 def jac_np_to_affine(xyz):
     """(18,) uint64 Jacobian Montgomery -> oracle affine point (or None)."""
-    X = limbs_to_fq(xyz[0:6])
-    Y = limbs_to_fq(xyz[6:12])
-    Z = limbs_to_fq(xyz[12:18])
+    L = F.FQ_LIMBS64
+    X = limbs_to_fq(xyz[0:L])
+    Y = limbs_to_fq(xyz[L:2 * L])
+    Z = limbs_to_fq(xyz[2 * L:3 * L])
     return EC.jac_to_affine((X, Y, Z))
 
 

@@ -10,7 +10,7 @@ rng = np.random.default_rng(0)
 
 def rand_fr(n):
     x = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
-    x[:, 3] &= np.uint64((1 << 62) - 1)
+    x[:, 3] &= np.uint64((1 << 61) - 1)
     return x
 
 M.prof_enable(True)
