@@ -118,6 +118,10 @@ typedef struct {
 } mh_r1cs_matrices;
 /* srs_g: bases handle holding powers_of_g[0..=max_degree]; srs_gamma_g: >= 3 powers_of_gamma_g. */
 int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamma_g, uint64_t* pk_out);
+/* same with the polynomial-commitment scheme chosen: pc = 0 MarlinKZG10 (src/test.rs:123), pc = 1 SonicKZG10
+ * (benches/bench.rs:81; needs powers_of_gamma_g[0..=max_degree+1] in srs_gamma_g).  A Sonic proof is 9 G1 commitments,
+ * 4 evaluations and 2 openings (1261 bytes on BLS12-381). */
+int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamma_g, int pc, uint64_t* pk_out);
 int mh_marlin_pk_free(uint64_t pk);
 /* info8: |H|, |K|, |X|, num_non_zero, index max_degree, srs max_degree, num_constraints, num_instance */
 int mh_marlin_pk_info(uint64_t pk, uint64_t* info8);

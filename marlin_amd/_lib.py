@@ -41,6 +41,7 @@ SYMBOLS = {
     "mh_g1_to_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mh_g1_sum": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mh_marlin_index": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u64p]),
+    "mh_marlin_index_pc": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, _u64p]),
     "mh_marlin_pk_free": (C.c_int, [C.c_uint64]),
     "mh_marlin_pk_info": (C.c_int, [C.c_uint64, _u64p]),
     "mh_marlin_vk_bytes": (C.c_int, [C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

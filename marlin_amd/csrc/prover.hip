@@ -60,7 +60,9 @@ struct ProverKey {
   uint64_t H = 0, K = 0, X = 0;
   uint32_t logH = 0, logK = 0, logX = 0;
   uint64_t srs_g = 0, srs_max_degree = 0, index_max_degree = 0;
-  HG1Affine gamma_g[3];
+  int pc = 0;                      // 0 = MarlinKZG10 (src/test.rs:123), 1 = SonicKZG10 (benches/bench.rs:81)
+  HG1Affine gamma_g[3];            // powers_of_gamma_g[0..3)
+  HG1Affine gamma_g_h[3], gamma_g_k[3];   // Sonic: shifted_powers_of_gamma_g for the bounds |H|-2 and |K|-2
   // index (device)
   DBuf ev_row, ev_col, ev_row_col, ev_val_a, ev_val_b, ev_val_c;       // evals on K
   DBuf p_row, p_col, p_a_val, p_b_val, p_c_val, p_row_col;            // coefficient form (K each)
@@ -306,6 +308,12 @@ struct Trace {
   }
 };
 
+// transcript / proof bytes of a commitment: marlin_pc::Commitment (comm, presence byte, shifted or identity) or, for
+// SonicKZG10, the bare kzg10::Commitment
+inline void put_comm(std::vector<uint8_t>& out, const fsh::Commitment& cm, int pc) {
+  if (pc == 1) fsh::put_g1(out, cm.comm); else fsh::put_commitment(out, cm);
+}
+
 // MarlinKZG10::commit for a list of labeled polynomials (ark-poly-commit marlin_pc / kzg10 [SURVEY B-3, B-4]).
 // Per polynomial, in order: KZG10::commit on powers_of_g (drawing a fresh 3-coefficient blinding polynomial from the
 // rng when hiding), then, if degree-bounded, a second KZG10::commit on the shifted powers (fresh draws again).
@@ -321,6 +329,30 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
   std::vector<MsmJob> jobs;
   comms.assign(reqs.size(), fsh::Commitment());
   rands.assign(reqs.size(), PolyRand());
+  if (pk.pc == 1) {
+    // SonicKZG10::commit [SURVEY B-5]: one KZG10::commit per polynomial; a degree-bounded one goes against the
+    // shifted powers powers_of_g[max_degree - d ..] and its blinding against powers_of_gamma_g[max_degree - d + i]
+    for (size_t i = 0; i < reqs.size(); i++) {
+      const CommitReq& q = reqs[i];
+      uint64_t off = q.has_bound ? pk.srs_max_degree - q.bound : 0;
+      if (q.has_bound && q.len > q.bound + 1) return fail(MH_EINVAL, "polynomial exceeds its degree bound");
+      if (off + q.len > it->second.n) return fail(MH_EINVAL, "polynomial degree exceeds the SRS");
+      jobs.push_back({pts + off * PT_B, q.poly, q.len});
+      if (q.hiding) for (int k = 0; k < 3; k++) rands[i].rand.blind.push_back(fsh::fr_rand(*rng));
+    }
+    std::vector<HG1> res;
+    MH_TRY(sharded_msm_batch(c, jobs, res));
+    for (size_t i = 0; i < reqs.size(); i++) {
+      HG1 cm = res[i];
+      if (reqs[i].hiding) {
+        const HG1Affine* gp = !reqs[i].has_bound ? pk.gamma_g : (reqs[i].bound == pk.H - 2 ? pk.gamma_g_h : pk.gamma_g_k);
+        cm = cm.add(small_msm(gp, rands[i].rand.blind));
+      }
+      comms[i].comm = cm.to_affine();
+      comms[i].has_shifted = false;
+    }
+    return MH_OK;
+  }
   for (size_t i = 0; i < reqs.size(); i++) {
     const CommitReq& q = reqs[i];
     if (q.len > it->second.n) return fail(MH_EINVAL, "polynomial degree exceeds the SRS");
@@ -397,8 +429,14 @@ int mh_marlin_pk_free(uint64_t pk_handle) {
 }
 
 // Marlin::index (lib.rs:100-148)
+int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamma_g, int pc, uint64_t* pk_out);
 int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamma_g, uint64_t* pk_out) {
+  return mh_marlin_index_pc(m, srs_g, srs_gamma_g, 0, pk_out);
+}
+
+int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamma_g, int pc, uint64_t* pk_out) {
   LOCKED_CTX();
+  if (pc != 0 && pc != 1) return fail(MH_EINVAL, "mh_marlin_index: pc must be 0 (MarlinKZG10) or 1 (SonicKZG10)");
   if (!m || !pk_out) return fail(MH_EINVAL, "mh_marlin_index: null pointer");
   const uint64_t nc = m->num_constraints, ni = m->num_instance;
   if (nc == 0 || ni == 0 || (ni & (ni - 1)) != 0 || ni > nc)
@@ -411,7 +449,7 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
 
   std::unique_ptr<ProverKey> pkp(new ProverKey());
   ProverKey& pk = *pkp;
-  pk.nc = nc; pk.ni = ni;
+  pk.nc = nc; pk.ni = ni; pk.pc = pc;
   pk.srs_g = srs_g; pk.srs_max_degree = sg->second.n - 1;
   {
     uint64_t gg[3 * AFF_L];
@@ -442,6 +480,18 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
   pk.index_max_degree = std::max(std::max(2 * H + 1 - 2, 3 * H + 2 - 3), std::max(H, K - 1));
   if (pk.srs_max_degree < pk.index_max_degree) return fail(MH_EINVAL, "IndexTooLarge: SRS max degree below the index's");
   if (K - 2 > pk.srs_max_degree) return fail(MH_EINVAL, "IndexTooLarge");
+  if (pc == 1) {
+    // SonicKZG10::trim: shifted_powers_of_gamma_g[d] = powers_of_gamma_g[max_degree - d + i], i = 0..2
+    auto fetch = [&](uint64_t off, HG1Affine* out3) -> int {
+      if (off + 3 > sgg->second.n) return fail(MH_EINVAL, "SonicKZG10 needs powers_of_gamma_g up to max_degree + 1");
+      uint64_t gg[3 * AFF_L];
+      MH_HIP(hipMemcpy(gg, (const char*)sgg->second.d_points + off * PT_B, 3 * PT_B, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 3; i++) { memcpy(out3[i].x.v, gg + AFF_L * i, FQ_B); memcpy(out3[i].y.v, gg + AFF_L * i + FQ_L, FQ_B); out3[i].inf = false; }
+      return MH_OK;
+    };
+    MH_TRY(fetch(pk.srs_max_degree - (H - 2), pk.gamma_g_h));
+    MH_TRY(fetch(pk.srs_max_degree - (K - 2), pk.gamma_g_k));
+  }
 
   // ---- arithmetize_matrix (constraint_systems.rs:125-262) on the host ---------------------------------
   // val_M(k) = M[r][i] * u_H(col_val, col_val)^-1 = M[r][i] * col_val / |H|   (col_val^|H| = 1)
@@ -504,7 +554,7 @@ int mh_marlin_index(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_gamm
   }
   // IndexVerifierKey::write (data_structures.rs:36-43)
   fsh::put_u64(pk.vk_bytes, nc); fsh::put_u64(pk.vk_bytes, nc); fsh::put_u64(pk.vk_bytes, pk.nnz);
-  for (auto& cm : pk.index_comms) fsh::put_commitment(pk.vk_bytes, cm);
+  for (auto& cm : pk.index_comms) put_comm(pk.vk_bytes, cm, pk.pc);
 
   // ---- matrices on the device: CSR A, B for z_A, z_B (prover.rs:256-276) -------------------------------
   Csr* cs[2] = {&pk.A, &pk.B};
@@ -700,7 +750,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   PolyRand &rd_w = rd1[0], &rd_za = rd1[1], &rd_zb = rd1[2];
   {
     std::vector<uint8_t> b;
-    fsh::put_commitment(b, c_w); fsh::put_commitment(b, c_za); fsh::put_commitment(b, c_zb); fsh::put_commitment(b, c_mask);
+    put_comm(b, c_w, pk.pc); put_comm(b, c_za, pk.pc); put_comm(b, c_zb, pk.pc); put_comm(b, c_mask, pk.pc);
     fs.absorb(b);                                                            // lib.rs:180
   }
   tr.mark("Committing to first round polys");
@@ -760,7 +810,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   PolyRand& rd_g1 = rd2[1];
   {
     std::vector<uint8_t> b;
-    fsh::put_commitment(b, c_t); fsh::put_commitment(b, c_g1); fsh::put_commitment(b, c_h1);
+    put_comm(b, c_t, pk.pc); put_comm(b, c_g1, pk.pc); put_comm(b, c_h1, pk.pc);
     fs.absorb(b);                                                               // lib.rs:201
   }
   tr.mark("Committing to second round polys");
@@ -798,7 +848,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   fsh::Commitment &c_g2 = cm3[0], &c_h2 = cm3[1];
   {
     std::vector<uint8_t> b;
-    fsh::put_commitment(b, c_g2); fsh::put_commitment(b, c_h2);
+    put_comm(b, c_g2, pk.pc); put_comm(b, c_h2, pk.pc);
     fs.absorb(b);                                                                // lib.rs:221
   }
   tr.mark("Committing to third round polys");
@@ -838,6 +888,30 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   auto sg = c.bases.find(pk.srs_g);
   if (sg == c.bases.end()) return fail(MH_EINVAL, "prover key refers to a freed SRS handle");
   const char* srs_pts = (const char*)sg->second.d_points;
+  HG1Affine w_beta, w_gamma; bool has_rv_beta = false, has_rv_gamma = false; HFr rv_beta = HFr::zero();
+  if (pk.pc == 1) {
+    // SonicKZG10::open [SURVEY B-5]: per point ONE combined polynomial sum_i xi^i p_i (labels in BTreeSet order) and one
+    // KZG10::open on the unshifted powers.  beta: g_1, outer_sumcheck, t, z_b; gamma: g_2, inner_sumcheck.
+    MH_TRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(1)},
+                                       {pk.t.fr(), H, xi_pow(2)}, {pk.zb.fr(), za_len, xi_pow(3)}}));
+    MH_TRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));
+    MH_TRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(1)}}));
+    MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
+    std::vector<HG1> om;
+    MH_TRY(sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts, S[5], K - 1}}, om));
+    HG1 wacc = om[0];
+    std::vector<HFr> r;
+    host_axpy(r, HFr::one(), rd_g1.rand.blind);
+    std::vector<HFr> r_outer; host_axpy(r_outer, c_za_lc, rd_za.rand.blind); host_axpy(r_outer, c_w_lc, rd_w.rand.blind);
+    host_axpy(r, xi_pow(1), r_outer);
+    host_axpy(r, xi_pow(3), rd_zb.rand.blind);
+    if (!host_is_zero(r)) {
+      wacc = wacc.add(small_msm(pk.gamma_g, host_div_linear(r, beta)));
+      rv_beta = host_eval(r, beta); has_rv_beta = true;
+    }
+    w_beta = wacc.to_affine();
+    w_gamma = om[1].to_affine();          // nothing hiding at gamma: random_v = None
+  } else {
   // The four MSMs of the two opening proofs (witness + shifted witness at beta and at gamma) run as one batch.
   // --- at beta: labels g_1, outer_sumcheck, t, z_b  -> challenges xi^0 (g_1), xi^1 (g_1 shifted), xi^2, xi^3, xi^4
   MH_TRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(2)},
@@ -853,7 +927,6 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   std::vector<HG1> om;
   MH_TRY(sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts + (pk.srs_max_degree - (H - 2)) * PT_B, S[4], g1_len - 1},
                                {srs_pts, S[5], K - 1}, {srs_pts + (pk.srs_max_degree - (K - 2)) * PT_B, S[6], g2_len - 1}}, om));
-  HG1Affine w_beta; bool has_rv_beta = false; HFr rv_beta = HFr::zero();
   {
     HG1 wacc = om[0];
     // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b)
@@ -878,7 +951,11 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     }
     w_beta = wacc.add(sw).to_affine();
   }
-  HG1Affine w_gamma = om[2].add(om[3]).to_affine();
+  w_gamma = om[2].add(om[3]).to_affine();
+  // at gamma nothing is hiding, but the degree-bounded g_2 goes through open_with_witness_polynomial with
+  // Some(empty witness): random_v = Some(0) [ark-poly-commit marlin_pc::open, SURVEY B-4]
+  has_rv_gamma = true;
+  }
 
   tr.mark("PC::open_combinations");
   pk.last_polys = {{"w", {pk.w.fr(), w_len}}, {"z_a", {pk.za.fr(), za_len}}, {"z_b", {pk.zb.fr(), za_len}},
@@ -889,14 +966,12 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   // ---------------- Proof (lib.rs:305-310), flat ToBytes layout ------------------------------------------------
   std::vector<uint8_t> out;
   fsh::Commitment* all[9] = {&c_w, &c_za, &c_zb, &c_mask, &c_t, &c_g1, &c_h1, &c_g2, &c_h2};
-  for (auto* cm : all) fsh::put_commitment(out, *cm);
+  for (auto* cm : all) put_comm(out, *cm, pk.pc);
   fsh::put_fr(out, g1_beta); fsh::put_fr(out, g2_gamma); fsh::put_fr(out, t_beta); fsh::put_fr(out, zb_beta);
   fsh::put_g1(out, w_beta);
   out.push_back(has_rv_beta ? 1 : 0); fsh::put_fr(out, has_rv_beta ? rv_beta : HFr::zero());
   fsh::put_g1(out, w_gamma);
-  // at gamma nothing is hiding, but the degree-bounded g_2 goes through open_with_witness_polynomial with
-  // Some(empty witness): random_v = Some(0) [ark-poly-commit marlin_pc::open, SURVEY B-4]
-  out.push_back(1); fsh::put_fr(out, HFr::zero());
+  out.push_back(has_rv_gamma ? 1 : 0); fsh::put_fr(out, HFr::zero());
   if (len_out) *len_out = out.size();
   if (cap < out.size()) return fail(MH_EINVAL, "mh_marlin_prove: proof buffer too small");
   memcpy(proof_out, out.data(), out.size());

@@ -37,16 +37,18 @@ def max_degree(num_constraints, num_variables, num_non_zero):
 class UniversalSRS:
     """KZG10 universal parameters for a known (test) tau: powers_of_g and powers_of_gamma_g on the device."""
 
-    def __init__(self, max_deg, tau, gamma):
+    def __init__(self, max_deg, tau, gamma, full_gamma=False):
         self.max_degree = int(max_deg)
         self.tau, self.gamma = int(tau) % R_MOD, int(gamma) % R_MOD
         self.powers_of_g = Bases.srs_powers(fr_mont(self.tau), self.max_degree + 1)
-        self.powers_of_gamma_g = Bases.srs_powers(fr_mont(self.tau), 3, scale_mont=fr_mont(self.gamma))
+        # MarlinKZG10::trim keeps powers_of_gamma_g[0..3); SonicKZG10 also needs them at max_degree - bound + i
+        self.powers_of_gamma_g = Bases.srs_powers(fr_mont(self.tau), self.max_degree + 2 if full_gamma else 3,
+                                                  scale_mont=fr_mont(self.gamma))
 
 
-def universal_setup(num_constraints, num_variables, num_non_zero, tau, gamma):
+def universal_setup(num_constraints, num_variables, num_non_zero, tau, gamma, pc="marlin"):
     """Marlin::universal_setup (src/lib.rs:79-96) with a caller-chosen tau (test/bench SRS)."""
-    return UniversalSRS(max_degree(num_constraints, num_variables, num_non_zero), tau, gamma)
+    return UniversalSRS(max_degree(num_constraints, num_variables, num_non_zero), tau, gamma, full_gamma=(pc == "sonic"))
 
 
 class IndexProverKey:
@@ -85,7 +87,7 @@ class IndexProverKey:
             pass
 
 
-def index(srs, num_constraints, num_instance, matrices):
+def index(srs, num_constraints, num_instance, matrices, pc="marlin"):
     """Marlin::index (src/lib.rs:100-148).  matrices = [(row_ptr uint64[nc+1], col uint32[nnz], val (nnz,4) uint64
     Montgomery or None for all-ones)] for A, B, C -- already padded and square."""
     keep = []
@@ -105,8 +107,8 @@ def index(srs, num_constraints, num_instance, matrices):
         else:
             m.val[k] = None
     h = C.c_uint64()
-    _lib.check(_lib.load().mh_marlin_index(C.byref(m), srs.powers_of_g.handle, srs.powers_of_gamma_g.handle, C.byref(h)),
-               "mh_marlin_index")
+    _lib.check(_lib.load().mh_marlin_index_pc(C.byref(m), srs.powers_of_g.handle, srs.powers_of_gamma_g.handle,
+                                              {"marlin": 0, "sonic": 1}[pc], C.byref(h)), "mh_marlin_index_pc")
     pk = IndexProverKey(h.value)
     pk.srs = srs
     return pk

@@ -18,6 +18,21 @@ PROTOCOL_NAME = b"MARLIN-2019"
 # ----------------------------------------------------------------------------------
 # SRS / keys (KZG10::setup + MarlinKZG10::trim with a known tau)
 # ----------------------------------------------------------------------------------
+class _GammaPowers:
+    """powers_of_gamma_g[i] = [gamma tau^i]G on demand (KZG10::setup keeps max_degree + 2 of them; MarlinKZG10::trim
+    keeps the first 3, SonicKZG10::trim additionally 3 per enforced degree bound at index max_degree - d + i)."""
+
+    def __init__(self, tau, gamma_g):
+        self.tau, self.gamma_g, self.cache = tau, gamma_g, {}
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(1 << 62))]
+        if i not in self.cache:
+            self.cache[i] = EC.scalar_mul(self.gamma_g, pow(self.tau, i, R))
+        return self.cache[i]
+
+
 class SRS:
     def __init__(self, max_degree, tau, gamma, g=EC.G1_GEN):
         self.max_degree = max_degree
@@ -25,7 +40,8 @@ class SRS:
         self.g = g
         self.powers_of_g = EC.srs_powers(tau, max_degree + 1, g)
         self.gamma_g = EC.scalar_mul(g, gamma)
-        self.powers_of_gamma_g = EC.srs_powers(tau, 3, self.gamma_g)   # hiding_bound + 2 = 3 kept by trim
+        self.all_gamma = _GammaPowers(self.tau, self.gamma_g)
+        self.powers_of_gamma_g = [self.all_gamma[i] for i in range(3)]   # hiding_bound + 2 = 3 kept by trim
 
 
 def universal_setup(num_constraints, num_variables, num_non_zero, tau, gamma):
@@ -41,7 +57,10 @@ def g1_bytes(pt):
 
 
 def commitment_bytes(c):
-    """marlin_pc::Commitment::write: comm || shifted_exists || (shifted_comm or empty) [B-6]."""
+    """marlin_pc::Commitment::write: comm || shifted_exists || (shifted_comm or empty) [B-6];
+    a sonic_pc commitment is a bare kzg10::Commitment = one G1Affine."""
+    if c[1] == "sonic":
+        return g1_bytes(c[0])
     comm, shifted = c
     return g1_bytes(comm) + (b"\x01" if shifted is not None else b"\x00") + g1_bytes(shifted[0] if shifted is not None else None)
 
@@ -77,6 +96,42 @@ def marlin_commit(srs, polys, rng):
         else:
             comms.append((c, None)); rands.append((r, None))
     return comms, rands
+
+
+def sonic_commit(srs, polys, rng):
+    """SonicKZG10::commit [SURVEY B-5, UPSTREAM-RECALLED]: ONE KZG10::commit per polynomial, against the shifted powers
+    (powers_of_g[max_degree - d ..] and powers_of_gamma_g[max_degree - d + i]) when it has a degree bound d."""
+    comms, rands = [], []
+    for label, p, db, hb in polys:
+        off = 0 if db is None else srs.max_degree - db
+        comm = msm(srs, off, p)
+        blind = []
+        if hb is not None:
+            blind = trim([fr_rand(rng) for _ in range(hb + 2)])
+            comm = EC.add(comm, EC.msm_naive([srs.all_gamma[off + i] for i in range(len(blind))], blind))
+        comms.append((comm, "sonic")); rands.append((blind, None))
+    return comms, rands
+
+
+def sonic_open(srs, polys, rands, point, xi):
+    """SonicKZG10::open_individual_opening_challenges [B-5]: one combined polynomial (challenge xi^i for the i-th
+    polynomial), one KZG10::open on the unshifted powers."""
+    p, r = [], []
+    for i, ((label, poly, db, hb), (rand, _)) in enumerate(zip(polys, rands)):
+        ch = pow(xi, i, R)
+        p = _axpy(p, ch, poly)
+        r = _axpy(r, ch, rand)
+    w = msm(srs, 0, divide_by_linear(p, point))
+    random_v = None
+    if trim(r):
+        w = EC.add(w, EC.msm_naive(srs.powers_of_gamma_g, divide_by_linear(r, point)))
+        random_v = poly_eval(r, point)
+    return w, random_v
+
+
+def pc_commit(pk_or_pc, srs, polys, rng):
+    pc = pk_or_pc if isinstance(pk_or_pc, str) else pk_or_pc.pc
+    return sonic_commit(srs, polys, rng) if pc == "sonic" else marlin_commit(srs, polys, rng)
 
 
 def _axpy(acc, f, p):
@@ -130,17 +185,19 @@ class IndexKeys:
     pass
 
 
-def marlin_index(srs, cs):
-    """src/lib.rs:100-148: cs already padded/squared (AHP.pad_and_square)."""
+def marlin_index(srs, cs, pc="marlin"):
+    """src/lib.rs:100-148: cs already padded/squared (AHP.pad_and_square).  pc: "marlin" = MarlinKZG10
+    (src/test.rs:123), "sonic" = SonicKZG10 (benches/bench.rs:81)."""
     idx = AHP.index(cs)
     assert srs.max_degree >= idx.max_degree
     pk = IndexKeys()
+    pk.pc = pc
     pk.index = idx
     pk.srs = srs
     pk.enforced_bounds = sorted([idx.domain_h.size - 2, idx.domain_k.size - 2])   # get_degree_bounds
     polys = [(l, idx.polys[l], None, None) for l in AHP.INDEXER_POLYNOMIALS]
     pk.index_polys = polys
-    pk.index_comms, pk.index_rands = marlin_commit(srs, polys, None)
+    pk.index_comms, pk.index_rands = pc_commit(pc, srs, polys, None)
     return pk
 
 
@@ -165,17 +222,17 @@ def prove(pk, cs, zk_rng):
     fs = SimpleHashFiatShamirRng(PROTOCOL_NAME + vk_bytes(pk) + b"".join(fr_bytes(x) for x in pub))
     # round 1
     first = AHP.prover_first_round(st, zk_rng)
-    c1, r1 = marlin_commit(srs, first, zk_rng)
+    c1, r1 = pc_commit(pk, srs, first, zk_rng)
     fs.absorb(b"".join(commitment_bytes(c) for c in c1))
     alpha, eta_a, eta_b, eta_c = AHP.verifier_first_round(st.domain_h, fs)
     # round 2
     second = AHP.prover_second_round(st, alpha, eta_a, eta_b, eta_c)
-    c2, r2 = marlin_commit(srs, second, zk_rng)
+    c2, r2 = pc_commit(pk, srs, second, zk_rng)
     fs.absorb(b"".join(commitment_bytes(c) for c in c2))
     beta = AHP.verifier_second_round(st.domain_h, fs)
     # round 3
     third = AHP.prover_third_round(st, beta)
-    c3, r3 = marlin_commit(srs, third, zk_rng)
+    c3, r3 = pc_commit(pk, srs, third, zk_rng)
     fs.absorb(b"".join(commitment_bytes(c) for c in c3))
     gamma = AHP.verifier_third_round(fs)
 
@@ -224,7 +281,10 @@ def prove(pk, cs, zk_rng):
     proofs = []
     for pl, point in (("beta", beta), ("gamma", gamma)):
         labels = sorted(l for l, p, _ in qs if p == pl)
-        proofs.append(marlin_open(srs, pk.enforced_bounds, [lc_polys[l] for l in labels], [lc_rands[l] for l in labels], point, xi))
+        if pk.pc == "sonic":
+            proofs.append(sonic_open(srs, [lc_polys[l] for l in labels], [lc_rands[l] for l in labels], point, xi))
+        else:
+            proofs.append(marlin_open(srs, pk.enforced_bounds, [lc_polys[l] for l in labels], [lc_rands[l] for l in labels], point, xi))
     pr = Proof()
     pr.commitments = [c1, c2, c3]
     pr.evaluations = evaluations
@@ -291,13 +351,19 @@ def verify(pk, public_input, pr):
             claimed = (ev_map[l] if l in ev_map else 0)
             claimed = (claimed - const) % R
             lc_comm = None
+            sonic = getattr(pk, "pc", "marlin") == "sonic"
             for c, t in lc:
                 if t is not None:
-                    lc_comm = EC.add(lc_comm, EC.scalar_mul(comms[t][0], c))
+                    cm = comms[t][0]
+                    if sonic and t in bounds:
+                        # a degree-bounded Sonic commitment is [p(tau) tau^(max_degree - d)]G (hiding part shifted alike);
+                        # the pairing check divides the shift out with the G2 element, here with tau itself
+                        cm = EC.scalar_mul(cm, pow(srs.tau, -(srs.max_degree - bounds[t]), R))
+                    lc_comm = EC.add(lc_comm, EC.scalar_mul(cm, c))
             ch = pow(xi, ctr, R); ctr += 1
             combined = EC.add(combined, EC.scalar_mul(lc_comm, ch))
             value = (value + claimed * ch) % R
-            if len(lc) == 1 and lc[0][1] in bounds:
+            if not sonic and len(lc) == 1 and lc[0][1] in bounds:
                 t = lc[0][1]
                 ch1 = pow(xi, ctr, R); ctr += 1
                 shift_power = srs.powers_of_g[srs.max_degree - bounds[t]]

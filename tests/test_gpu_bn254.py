@@ -22,3 +22,10 @@ def _run(files, extra=()):
 def test_bn254_ntt_msm_srs_parity():
     out = _run(["tests/test_gpu_ntt.py", "tests/test_gpu_msm.py", "tests/test_gpu_srs.py"])
     assert " passed" in out
+
+
+def test_bn254_marlin_and_sonic_provers():
+    """The whole prover on BN254 with both PC schemes: byte-identical proofs vs the oracle (fresh runs), polynomial
+    parity, general R1CS, 2^20-constraint proofs verified by the oracle (BASELINE.json configs[4])."""
+    out = _run(["tests/test_gpu_marlin.py"], extra=["-k", "not golden and not two_ranks"])
+    assert " passed" in out

@@ -30,12 +30,13 @@ def _gpu_prove(case):
     return pk, GM.prove(pk, inst, wit, SEED)
 
 
+@pytest.mark.skipif(F.CURVE != "bls12_381", reason="golden fixtures are BLS12-381 / MarlinKZG10")
 @pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: "%s-%d-%d" % (c["kind"], c["num_constraints"], c["num_variables"]))
 def test_proof_bytes_match_golden(gpu, case):
     import hashlib
     pk, proof = _gpu_prove(case)
     assert hashlib.blake2s(pk.vk_bytes()).hexdigest() == case["vk_bytes_blake2s"]     # index commitments
-    assert len(proof) == GM.PROOF_BYTES
+    assert len(proof) == GM.PROOF_BYTES == GM.proof_bytes_len("marlin")
     assert proof.hex() == case["proof_bytes"]
 
 
@@ -82,7 +83,7 @@ def test_proof_matches_fresh_oracle_and_verifies(gpu):
     assert GM.prove(pk, inst, wit, bytes(32)) != proof
 
 
-@pytest.mark.parametrize("log_n", [12, 16, 18, 20, 22])
+@pytest.mark.parametrize("log_n", [12, 16, 18, 20, 22] if F.CURVE == "bls12_381" else [12, 16, 20])
 def test_full_size_proof_verifies(gpu, log_n):
     """BASELINE.json sizes (2^18 = configs[1], 2^20 = configs[2]): the proof of DummyCircuit made on the
     device verifies under the oracle's verifier, and a wrong public input / tampered proof is rejected
@@ -100,7 +101,7 @@ def test_full_size_proof_verifies(gpu, log_n):
     c = a * b % F.R_MOD
     assert oracle_verify(vk, srs.max_degree, TAU, GAMMA, [c], proof)
     assert not oracle_verify(vk, srs.max_degree, TAU, GAMMA, [a], proof)
-    bad = bytearray(proof); bad[195 * 9 + 3] ^= 1                     # flip a bit of an evaluation
+    bad = bytearray(proof); bad[len(proof) - 2 * (2 * F.FQ_BYTES + 34) - 128 + 3] ^= 1     # flip a bit of an evaluation
     assert not oracle_verify(vk, srs.max_degree, TAU, GAMMA, [c], bytes(bad))
     assert GM.prove(pk, inst, wit, SEED) == proof                    # deterministic given the zk seed
 
@@ -226,7 +227,7 @@ def test_index_and_prove_error_paths(gpu):
     import ctypes as C
     out = (C.c_uint8 * 16)(); n = C.c_size_t()
     rc = _lib.load().mh_marlin_prove(pk.handle, inst.ctypes.data, wit.ctypes.data, SEED, 20, out, 16, C.byref(n))
-    assert rc != 0 and n.value == GM.PROOF_BYTES                      # buffer too small: reports the needed size
+    assert rc != 0 and n.value == GM.proof_bytes_len("marlin")                      # buffer too small: reports the needed size
     rc = _lib.load().mh_marlin_prove(pk.handle, inst.ctypes.data, wit.ctypes.data, SEED, 7, out, 16, C.byref(n))
     assert rc != 0                                                    # unsupported ChaCha round count
     rc = _lib.load().mh_marlin_prove(12345, inst.ctypes.data, wit.ctypes.data, SEED, 20, out, 16, C.byref(n))
@@ -246,3 +247,46 @@ def test_config0_2p10_plumbing(gpu):
     assert (pk.H, pk.K, pk.X) == (1 << 10, 1 << 12, 2)
     proof = GM.prove(pk, inst, wit, SEED)
     assert oracle_verify(pk.vk_bytes(), srs.max_degree, TAU, GAMMA, [a * b % F.R_MOD], proof)
+
+
+# ---- second PC path: SonicKZG10 (benches/bench.rs:81) -------------------------------------------------------
+@pytest.mark.parametrize("kind,nc,nv", [("dummy", 32, 10), ("dummy", 128, 10), ("test", 25, 25), ("test", 100, 25)])
+def test_sonic_proof_matches_oracle(gpu, kind, nc, nv):
+    """SonicKZG10: index commitments and proof are byte-identical to the oracle's restatement, verify, and reject a
+    wrong input."""
+    rng = FS.test_rng()
+    a, b = FS.fr_rand(rng), FS.fr_rand(rng)
+    if kind == "dummy":
+        cs = AHP.pad_and_square(AHP.dummy_circuit(a, b, nv, nc))
+        ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, nv, nc)
+        pub = [a * b % F.R_MOD]
+    else:
+        cs = AHP.pad_and_square(AHP.finalize_test_circuit(AHP.test_circuit(a, b, nc, nv)))
+        ncp, ni, mats, inst, wit = GM.test_circuit(a, b, nc, nv)
+        pub = [a * b % F.R_MOD, a * b % F.R_MOD * b % F.R_MOD]
+    m = max(nc, nv)
+    srs_o = MR.universal_setup(m, m, 3 * m, TAU, GAMMA)
+    pk_o = MR.marlin_index(srs_o, cs, "sonic")
+    pr = MR.prove(pk_o, cs, FS.ChaChaRng(SEED, 20))
+    assert MR.verify(pk_o, pub, pr) and not MR.verify(pk_o, [a] * len(pub), pr)
+    srs = GM.universal_setup(m, m, 3 * m, TAU, GAMMA, pc="sonic")
+    pk = GM.index(srs, ncp, ni, mats, pc="sonic")
+    assert pk.vk_bytes() == MR.vk_bytes(pk_o)
+    proof = GM.prove(pk, inst, wit, SEED)
+    assert len(proof) == GM.proof_bytes_len("sonic")
+    assert proof == MR.proof_bytes(pr)
+
+
+def test_sonic_full_size_verifies(gpu):
+    """BASELINE.json configs[4] shape: 2^20 constraints, SonicKZG10 (on whichever curve this process runs)."""
+    from tests.verify_adapter import oracle_verify
+    rng = FS.test_rng()
+    a, b = FS.fr_rand(rng), FS.fr_rand(rng)
+    n = 1 << 20
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc="sonic")
+    ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
+    pk = GM.index(srs, ncp, ni, mats, pc="sonic")
+    proof = GM.prove(pk, inst, wit, SEED)
+    vk = pk.vk_bytes()
+    assert oracle_verify(vk, srs.max_degree, TAU, GAMMA, [a * b % F.R_MOD], proof, pc="sonic")
+    assert not oracle_verify(vk, srs.max_degree, TAU, GAMMA, [a], proof, pc="sonic")

@@ -28,7 +28,7 @@ def _check_dlog(gpu, B, pts, dl, scalars, offset=0, montgomery=True):
     if want is None:
         assert inf
     else:
-        assert not inf and (limbs_to_fq(xy[:6]), limbs_to_fq(xy[6:])) == want
+        assert not inf and (limbs_to_fq(xy[:F.FQ_LIMBS64]), limbs_to_fq(xy[F.FQ_LIMBS64:])) == want
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 31, 32, 33, 100, 257])

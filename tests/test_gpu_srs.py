@@ -15,12 +15,12 @@ def test_srs_powers_match_oracle(gpu):
     got = B.download()
     want = EC.srs_powers(TAU, n)
     for i in range(n):
-        assert (limbs_to_fq(got[i, :6]), limbs_to_fq(got[i, 6:])) == want[i]
+        assert (limbs_to_fq(got[i, :F.FQ_LIMBS64]), limbs_to_fq(got[i, F.FQ_LIMBS64:])) == want[i]
     gamma = 0x5eed5eed5eed
     Bg = gpu.Bases.srs_powers(fr_to_np([TAU])[0], 5, scale_mont=fr_to_np([gamma])[0])
     got = Bg.download()
     for i in range(5):
-        assert (limbs_to_fq(got[i, :6]), limbs_to_fq(got[i, 6:])) == EC.scalar_mul(EC.G1_GEN, gamma * pow(TAU, i, F.R_MOD))
+        assert (limbs_to_fq(got[i, :F.FQ_LIMBS64]), limbs_to_fq(got[i, F.FQ_LIMBS64:])) == EC.scalar_mul(EC.G1_GEN, gamma * pow(TAU, i, F.R_MOD))
 
 
 @pytest.mark.parametrize("log_n", [6, 10, 13])
