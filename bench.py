@@ -97,7 +97,7 @@ class HotPathInventory:
 class MarlinProve:
     """One Marlin::prove of DummyCircuit (benches/bench.rs:26-66) at 2^log_n constraints."""
 
-    def __init__(self, M, log_n):
+    def __init__(self, M, log_n, pc="marlin"):
         from marlin_amd import marlin as GM, workload as W
         self.M, self.GM = M, GM
         self.N = 1 << log_n
@@ -107,9 +107,9 @@ class MarlinProve:
         tau, gamma = 0x1f3a9c5d7e2b4a6f8091a2b3c4d5e6f708192a3b4c5d6e7f, 0x5eed5eed5eed5eed0123456789abcdef
         a, b = 0x2d1f0e3c4b5a69788796a5b4c3d2e1f00f1e2d3c4b5a6978, 0x1a2b3c4d5e6f708192a3b4c5d6e7f8091a2b3c4d5e6f7081
         t0 = time.time()
-        self.srs = GM.universal_setup(n, n, 3 * n, tau, gamma)
+        self.srs = GM.universal_setup(n, n, 3 * n, tau, gamma, pc=pc)
         nc, ni, mats, self.inst, self.wit = GM.dummy_circuit(a, b, 10, n)
-        self.pk = GM.index(self.srs, nc, ni, mats)
+        self.pk = GM.index(self.srs, nc, ni, mats, pc=pc)
         self.setup_s = time.time() - t0
         self.seed = bytes(range(32))
         self.proof = None
@@ -125,7 +125,7 @@ def cpu_baseline(log_n_sample=16):
     from oracle import cref
     from marlin_amd import workload as W
     cref.build()
-    cores = os.cpu_count() or 1
+    host_threads = os.cpu_count() or 1
     H = 1 << log_n_sample
     K = 4 * H
     rng = np.random.default_rng(7)
@@ -141,14 +141,18 @@ def cpu_baseline(log_n_sample=16):
     t_ntt = time.time() - t0
     t0 = time.time()
     for n, _ in msms:
-        cref.msm(bases[:n], scal[:n], montgomery=True, threads=cores)
+        cref.msm(bases[:n], scal[:n], montgomery=True, threads=host_threads)
     t_msm = time.time() - t0
     total = t_ntt + t_msm
+    # the restatement parallelises an MSM like arkworks does -- one task per c-bit window -- so at most
+    # ceil(255 / c) threads are ever busy (c = ceil(log2 n) * 69 / 100 + 2), whatever the host offers
+    lg = (K - 1).bit_length()
+    used = min(host_threads, -(-255 // (lg * 69 // 100 + 2)))
     return {
-        "value": H / total, "unit": "constraints/s", "cores": cores, "kind": "port",
+        "value": H / total, "unit": "constraints/s", "cores": used, "kind": "port",
         "sample": "oracle/c/ref_hotpath.c (C restatement of arkworks' radix-2 NTT + Pippenger, NOT arkworks itself): "
-                  "NTT+MSM inventory of one prove at 2^%d constraints; NTT single-thread %.2fs, MSM windows over %d threads %.2fs"
-                  % (log_n_sample, t_ntt, cores, t_msm),
+                  "NTT+MSM inventory of one prove at 2^%d constraints; NTT single-thread %.2fs, MSM one thread per window "
+                  "(%d busy of %d host threads) %.2fs" % (log_n_sample, t_ntt, used, host_threads, t_msm),
     }
 
 
@@ -160,6 +164,9 @@ def main():
     ap.add_argument("--log-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["marlin-prove", "hotpath-inventory"], default=None)
+    ap.add_argument("--pc", choices=["marlin", "sonic"], default="marlin",
+                    help="polynomial commitment scheme (MarlinKZG10 = headline config; SonicKZG10 = configs[4]); "
+                         "the curve is chosen with MARLIN_AMD_CURVE=bls12_381|bn254")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -178,7 +185,7 @@ def main():
 
     workload = args.workload or "marlin-prove"
     if workload == "marlin-prove":
-        wl = MarlinProve(M, args.log_constraints)
+        wl = MarlinProve(M, args.log_constraints, args.pc)
         if world > 1:
             from marlin_amd import dist as MD
             MD.enable_sharded_prove(dist, device=torch.device("cuda", local_rank))
@@ -259,6 +266,14 @@ def main():
         "roofline": roofline,
         "roofline_valu": valu,
     }
+    from marlin_amd import _lib as _L
+    curve_name = {"bls12_381": "BLS12-381", "bn254": "BN254"}[_L.CURVE]
+    out["config"]["curve"] = curve_name
+    out["config"]["pc"] = {"marlin": "MarlinKZG10", "sonic": "SonicKZG10"}[args.pc]
+    out["config"]["workload"] = out["config"]["workload"].replace("BLS12-381, MarlinKZG10", "%s, %s" % (curve_name, out["config"]["pc"]))
+    if _L.CURVE != "bls12_381" or args.pc != "marlin":
+        out["dtype"] = "u32-limb Montgomery (Fr 256-bit, Fq %d-bit)" % (64 * _L.FQ_LIMBS)
+        args.no_cpu_baseline = True          # the C restatement covers the headline configuration only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
