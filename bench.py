@@ -86,11 +86,9 @@ class HotPathInventory:
             cnt = min(cnt, self.bases.n)
             partials.append(M.msm_dev(self.bases, self.scal, cnt, base_offset=0, montgomery=True))
         if self.world > 1:
-            t = torch.from_numpy(np.stack(partials).view(np.int64)).cuda()
-            out = [torch.empty_like(t) for _ in range(self.world)]
-            dist.all_gather(out, t)
-            # (the prover adds the gathered partial points on the host: W-1 additions of 144-byte points)
-            _ = [o.cpu() for o in out]
+            from marlin_amd import dist as MD
+            dev = torch.device("cuda") if dist.get_backend() == "nccl" else None
+            partials = MD.combine_partials(MD.allgather_partials(np.stack(partials), dist, dev))
         return partials
 
 
@@ -172,13 +170,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test hooks: BENCH_BACKEND=gloo and BENCH_SINGLE_DEVICE=1 let the N > 1 code path run with every rank on GPU 0
+    # (the GPU box of this project has one GPU; RCCL refuses two ranks on one device)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     import marlin_amd as M
     M.init(local_rank)
     torch.cuda.set_device(local_rank)
@@ -188,7 +191,7 @@ def main():
         wl = MarlinProve(M, args.log_constraints, args.pc)
         if world > 1:
             from marlin_amd import dist as MD
-            MD.enable_sharded_prove(dist, device=torch.device("cuda", local_rank))
+            MD.enable_sharded_prove(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
     else:
         wl = HotPathInventory(M, args.log_constraints, rank, world)
 
@@ -210,7 +213,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -259,7 +262,7 @@ def main():
                                + "DummyCircuit 2^%d constraints, BLS12-381, MarlinKZG10 (benches/bench.rs shape; SURVEY.md Appendix A)"
                                % args.log_constraints,
                    "constraints": wl.N, "curve": "BLS12-381", "pc": "MarlinKZG10",
-                   "parallelism": "msm-point-sharded x%d, ntt replicated" % world},
+                   "parallelism": "msm-point-sharded x%d (one all_gather of partial points per commit round), AHP rounds replicated" % world},
         "breakdown_ms_per_step": {"ntt": round(ntt_ms / args.steps, 3), "msm": round(msm_ms / args.steps, 3),
                                   "msm_accum": round(acc_ms / args.steps, 3), "glue": round(glue_ms / args.steps, 3),
                                   "host_and_other": round(ms_per_step - (ntt_ms + msm_ms + glue_ms) / args.steps, 3)},

@@ -419,11 +419,13 @@ int mh_init(int device_id) {
   return MH_OK;
 }
 
+extern "C" int mh_marlin_release_all(void);
 int mh_shutdown(void) {
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
   if (!c.inited) return MH_OK;
   (void)hipStreamSynchronize(c.stream);
+  (void)mh_marlin_release_all();
   if (c.tw) (void)hipFree(c.tw);
   c.tw = nullptr; c.tw_log = 0;
   c.ntt_tmp[0].release(); c.ntt_tmp[1].release(); c.io.release();

@@ -406,6 +406,13 @@ int ensure_twiddles_public(Context& c, uint32_t log_n);
 
 extern "C" {
 
+// called by mh_shutdown: release every prover key
+int mh_marlin_release_all(void) {
+  for (auto& kv : g_pks) kv.second->free_all();
+  g_pks.clear();
+  return MH_OK;
+}
+
 int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* user) {
   if (world < 1 || rank < 0 || rank >= world) return fail(MH_EINVAL, "mh_marlin_set_shard: bad rank/world");
   if (world > 1 && !allgather) return fail(MH_EINVAL, "mh_marlin_set_shard: all_gather callback required for world > 1");
