@@ -23,7 +23,7 @@
 namespace ntt {
 
 constexpr int MAX_B = 8;          // stages per pass
-constexpr int MAX_LOGC = 3;       // 8 columns per tile
+constexpr int MAX_LOGC = 2;       // 4 columns per tile (128-B runs; 35 KB of LDS -> 4 blocks per CU)
 constexpr int THREADS = 256;
 
 // LDS row stride in uint4 units: 2*C data + 1 pad (breaks the 256-B power-of-two
