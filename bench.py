@@ -66,15 +66,6 @@ class HotPathInventory:
         # scalars for this rank's shard of the largest MSM
         self.scal = M.DeviceBuffer.from_numpy(rand_fr_np(rng, self.hi - self.lo))
 
-    def shard(self, n):
-        """this rank's [lo, hi) slice of an n-point MSM whose bases start at SRS index 0."""
-        lo = max(0, min(n, self.lo))
-        hi = max(0, min(n, self.hi))
-        # balance: split n evenly instead of by fixed SRS slices when n < srs_n
-        lo = (n * self.rank) // self.world
-        hi = (n * (self.rank + 1)) // self.world
-        return lo, hi
-
     def step(self, dist=None, torch=None):
         M = self.M
         for lg, inverse, _ in self.ntts:

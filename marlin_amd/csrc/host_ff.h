@@ -1,4 +1,4 @@
-// Host-side (x86-64) Montgomery arithmetic for BLS12-381 Fr / Fq and G1 group
+// Host-side (x86-64) Montgomery arithmetic for the curve's Fr / Fq (BLS12-381, or BN254) and G1 group
 // operations, used by the product's host code for the O(1)-per-call work around
 // the kernels: combining MSM window sums, affine normalisation, Fiat-Shamir
 // challenge arithmetic, n^-1 for inverse NTTs.  64-bit limbs, same in-memory
@@ -15,11 +15,6 @@
 namespace hostff {
 
 typedef unsigned __int128 u128;
-
-template <int N>
-struct Big {
-  uint64_t v[N];
-};
 
 template <class P>
 struct HFp {

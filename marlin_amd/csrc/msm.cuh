@@ -10,8 +10,8 @@
 // copied from arkworks (which uses unsigned c-bit windows, Jacobian buckets and
 // one rayon task per window).
 //
-// Pipeline (all on one stream, no host synchronisation until the W window sums
-// are copied back):
+// Pipeline (all on one stream; a batch of up to MAX_JOBS independent MSMs goes through every stage together;
+// the only host round-trips are a 4-byte read of the largest bucket size and the final copy of the window sums):
 //   1. digits   : Montgomery -> canonical scalar, signed base-2^c recoding;
 //                 one u32 entry (bucket+1 | sign<<31, 0 = skip) per (window, scalar)
 //   2. hist     : per (window, tile) LDS-privatised histogram of bucket ids
@@ -25,7 +25,7 @@
 //                 the segment + (segment offset) * (segment total) by double-and-add
 //   8. reduce2  : per window: tree-sum of the segment results
 // The host combines the W window sums (Horner with c doublings each) and
-// normalises to affine (host_ec.h).
+// normalises to affine (host_ff.h).
 #pragma once
 #include "g1.cuh"
 

@@ -691,7 +691,6 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   const uint32_t lgH = pk.logH, lgK = pk.logK, lgX = pk.logX;
   fsh::ChaChaRng zk(zk_seed, zk_rounds);
   Trace tr(c);
-  Fr** Sp = nullptr; (void)Sp;
   Fr* S[8]; for (int i = 0; i < 8; i++) S[i] = pk.S[i].fr();
   const Fr* tw = (const Fr*)c.tw;
 
