@@ -32,7 +32,7 @@
 namespace msm {
 
 constexpr int HIST_THREADS = 1024;
-constexpr int SEG = 16;  // buckets per reduce1 segment
+constexpr int SEG = 32;  // buckets per reduce1 segment
 
 constexpr int MAX_WINDOWS = 64;
 

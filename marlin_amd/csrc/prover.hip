@@ -233,13 +233,37 @@ int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<H
 // affine normalisation of an MSM result
 HG1 jac_from(const uint64_t* xyz) { HG1 p; memcpy(p.X.v, xyz, FQ_B); memcpy(p.Y.v, xyz + FQ_L, FQ_B); memcpy(p.Z.v, xyz + 2 * FQ_L, FQ_B); return p; }
 
+// sum_i scalars[i] * bases[i] for the 3-coefficient hiding polynomials (host): Straus' interleaving -- one shared
+// doubling chain, a table of the 2^k - 1 subset sums of the k <= 3 bases
 HG1 small_msm(const HG1Affine* bases, const std::vector<HFr>& scalars) {
-  HG1 acc = HG1::identity();
-  for (size_t i = 0; i < scalars.size(); i++) {
-    if (scalars[i].is_zero()) continue;
-    uint64_t k[4]; scalars[i].to_canonical(k);
-    acc = acc.add(HG1::from_affine(bases[i]).mul(k, 4));
+  const size_t k = scalars.size();
+  if (k == 0) return HG1::identity();
+  if (k > 3) {
+    HG1 acc = HG1::identity();
+    for (size_t i = 0; i < k; i++) {
+      if (scalars[i].is_zero()) continue;
+      uint64_t e[4]; scalars[i].to_canonical(e);
+      acc = acc.add(HG1::from_affine(bases[i]).mul(e, 4));
+    }
+    return acc;
   }
+  uint64_t e[3][4];
+  for (size_t i = 0; i < k; i++) scalars[i].to_canonical(e[i]);
+  HG1 table[8];
+  table[0] = HG1::identity();
+  for (unsigned m = 1; m < (1u << k); m++) {
+    unsigned low = m & (~m + 1);                    // lowest set bit
+    int idx = low == 1 ? 0 : (low == 2 ? 1 : 2);
+    table[m] = table[m ^ low].add(HG1::from_affine(bases[idx]));
+  }
+  HG1 acc = HG1::identity();
+  for (int limb = 3; limb >= 0; limb--)
+    for (int b = 63; b >= 0; b--) {
+      acc = acc.dbl();
+      unsigned m = 0;
+      for (size_t i = 0; i < k; i++) m |= (unsigned)((e[i][limb] >> b) & 1) << i;
+      if (m) acc = acc.add(table[m]);
+    }
   return acc;
 }
 
