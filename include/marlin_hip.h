@@ -87,6 +87,15 @@ int mh_srs_powers(int curve, const uint64_t* tau_mont, const uint64_t* scale_mon
 int mh_bases_download(uint64_t handle, size_t offset, size_t n, uint64_t* xy_mont_out);
 int mh_bases_free(uint64_t handle);
 int mh_bases_len(uint64_t handle, size_t* n_out);
+/* Fixed-base acceleration for a base set that is multiplied again and again (the SRS): precomputes the shifts
+ * 2^{start_j} * P of all window positions (W x n affine points of device memory; W = 13 at window_bits = 20), after
+ * which every MSM against this handle with enough scalars runs Pippenger over ONE shared bucket set.  window_bits
+ * in [4, 22], 0 = choose from n.  Results are unchanged (an MSM has one answer).  mh_marlin_index calls this for
+ * powers_of_g.  No counterpart in the reference (arkworks recomputes nothing across calls). */
+int mh_bases_precompute(uint64_t handle, uint32_t window_bits);
+/* How many job groups (<= 8 MSMs launched together) have run on the fixed-base path / on the variable-base path
+ * since mh_init: lets a caller (and the tests) see which algorithm served its MSMs. */
+int mh_msm_path_counts(uint64_t* fixed_base_groups, uint64_t* variable_base_groups);
 int mh_msm(uint64_t bases_handle, size_t base_offset, const uint64_t* scalars, int scalars_are_montgomery,
            size_t n, uint64_t* out_xyz_mont);
 int mh_msm_dev(uint64_t bases_handle, size_t base_offset, const void* d_scalars, int scalars_are_montgomery,

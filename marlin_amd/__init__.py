@@ -14,4 +14,4 @@ in arkworks' in-memory layout (little-endian limbs, Montgomery form).
 """
 from ._lib import MarlinHipError, load, check, LIB_PATH  # noqa: F401
 from .api import (init, shutdown, device_info, ntt, intt, ntt_dev, Bases, msm, msm_dev, msm_batch_dev,  # noqa: F401
-                  DeviceBuffer, g1_to_affine, prof_enable, prof_reset, prof_get, synchronize)
+                  DeviceBuffer, g1_to_affine, msm_path_counts, prof_enable, prof_reset, prof_get, synchronize)

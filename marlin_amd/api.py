@@ -140,6 +140,11 @@ class Bases:
         self.n = int(n)
         return self
 
+    def precompute(self, window_bits=0):
+        """Build the fixed-base window table (mh_bases_precompute); later MSMs against this set use it."""
+        _lib.check(_L().mh_bases_precompute(self.handle, int(window_bits)), "mh_bases_precompute")
+        return self
+
     def download(self, offset=0, n=None):
         n = self.n - offset if n is None else n
         out = np.zeros((n, 2 * _fql()), dtype=np.uint64)
@@ -186,6 +191,13 @@ def msm_batch_dev(jobs, montgomery=True):
     out = np.zeros((k, 3 * _fql()), dtype=np.uint64)
     _lib.check(_L().mh_msm_batch_dev(k, handles, offs, ptrs, ns, 1 if montgomery else 0, out.ctypes.data), "mh_msm_batch_dev")
     return out
+
+
+def msm_path_counts():
+    """(fixed-base groups, variable-base groups) served since mh_init (mh_msm_path_counts)."""
+    a, b = C.c_uint64(), C.c_uint64()
+    _lib.check(_L().mh_msm_path_counts(C.byref(a), C.byref(b)), "mh_msm_path_counts")
+    return a.value, b.value
 
 
 def g1_to_affine(xyz):

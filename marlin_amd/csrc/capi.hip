@@ -5,6 +5,7 @@
 #include "g1.cuh"
 #include "msm.cuh"
 #include "msm_tree.cuh"
+#include "msm_fb.cuh"
 #include <cstdlib>
 #include "ntt.cuh"
 #include "srs.cuh"
@@ -135,6 +136,8 @@ static int msm_set_attrs() {
   int lds = 32768 * 4;
   MH_HIP(hipFuncSetAttribute((const void*)msm::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   g_msm_attr_done = true;
   return MH_OK;
 }
@@ -218,6 +221,190 @@ static int msm_tree_accumulate(Context& c, const msm::Jobs& jobs, u64 WN, const 
   return MH_OK;
 }
 
+
+// --------------------------------------------------------------------------------
+// Fixed-base path (msm_fb.cuh): all jobs of the group read one precomputed window table
+// --------------------------------------------------------------------------------
+// the tabled base set that contains [b, b + n) (callers pass plain device pointers into uploaded base sets)
+static const BaseSet* find_table(Context& c, const void* b, size_t n, size_t& off) {
+  for (auto& kv : c.bases) {
+    const BaseSet& bs = kv.second;
+    if (!bs.d_table) continue;
+    const char* lo = (const char*)bs.d_points;
+    const char* p = (const char*)b;
+    if (p >= lo && p + n * PT_B <= lo + bs.n * PT_B && (size_t)(p - lo) % PT_B == 0) { off = (size_t)(p - lo) / PT_B; return &bs; }
+  }
+  return nullptr;
+}
+
+// One group of <= MAX_JOBS jobs.  skewed = true (and nothing written) when a bucket is so overfull that the caller
+// should take the variable-base path with its pair-tree accumulation instead.
+static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* offs, const void* const* d_scalars, const size_t* ns,
+                        int is_mont, HG1* out, bool& skewed) {
+  namespace F = msmfb;
+  hipStream_t s = c.stream;
+  skewed = false;
+  msm::Windows win;
+  const u32 W = msm::make_windows(bs.tab_c, win);
+  const u32 nbt = 1u << (bs.tab_c - 1);                                  // buckets per job
+  const u32 pshift = F::part_bits(bs.tab_c);
+  const u32 nb = 1u << pshift;                                           // per virtual window
+  const u32 nparts = nbt / nb;
+  const u32 WT = nparts * nj;
+  const size_t WB = (size_t)nbt * nj;
+  F::FbJobs jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  jobs.njobs = nj;
+  u64 ent = 0, pco = 0; u32 max_blk = 0;
+  for (int k = 0; k < nj; k++) {
+    jobs.scalars[k] = (const Fr*)d_scalars[k]; jobs.n[k] = ns[k]; jobs.tab_off[k] = (u32)offs[k];
+    jobs.ent_off[k] = ent; ent += (u64)W * ns[k];
+    jobs.nblk[k] = (u32)((ns[k] + F::TPB * F::SPT - 1) / (F::TPB * F::SPT));
+    jobs.pc_off[k] = pco; pco += (u64)nparts * jobs.nblk[k];
+    max_blk = std::max(max_blk, jobs.nblk[k]);
+  }
+  if (ent >= (1ull << 32)) return fail(MH_EINVAL, "msm batch too large for 32-bit entry offsets");
+  u64 tile = (ent + 1023) / 1024;
+  if (tile < 4096) tile = 4096;
+  if (tile > 65536) tile = 65536;
+  const u64 max_tiles_total = ent / tile + WT + 1;
+  MH_TRY(c.msm_dig.ensure(ent * 4)); MH_TRY(c.fb_val.ensure(ent * 4)); MH_TRY(c.msm_sorted.ensure(ent * 4));
+  MH_TRY(c.fb_pc.ensure(pco * 4)); MH_TRY(c.fb_ptot.ensure((size_t)WT * 8)); MH_TRY(c.fb_desc.ensure((size_t)WT * sizeof(msm::FbWin)));
+  MH_TRY(c.fb_blk.ensure(8 * max_tiles_total * sizeof(F::FbBlk)));
+  MH_TRY(c.msm_bh.ensure(max_tiles_total * nb * 4));
+  MH_TRY(c.msm_tot.ensure(WB * 4)); MH_TRY(c.msm_base.ensure(WB * 4)); MH_TRY(c.msm_pend.ensure(WB * 4));
+  MH_TRY(c.msm_buckets.ensure(WB * sizeof(G1Xyzz)));
+  const u32 nseg = (nbt + msm::SEG - 1) / msm::SEG;
+  const u32 chunks = nseg >= 4096 ? nseg / 256 : 1;                      // reduce2 in two launches when nseg is large
+  MH_TRY(c.msm_seg.ensure((size_t)nj * (nseg + chunks) * sizeof(G1Xyzz)));
+  MH_TRY(c.msm_win.ensure((size_t)nj * sizeof(G1Xyzz)));
+  MH_TRY(c.tr_sums.ensure(64));
+  std::vector<msm::FbWin> desc(WT);
+  std::vector<F::FbBlk> blk;
+  std::vector<u32> ptot(WT);
+  {
+    ProfScope ps(c, PF_MSM);
+    u32* key = (u32*)c.msm_dig.ptr; u32* val = (u32*)c.fb_val.ptr;
+    u32* d_ptot = (u32*)c.fb_ptot.ptr; u32* d_pstart = d_ptot + WT;
+    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)c.fb_pc.ptr, W, win, is_mont, nparts, pshift);
+    hipLaunchKernelGGL(F::pscan_kernel, dim3(nparts, nj), dim3(1024), 0, s, jobs, (u32*)c.fb_pc.ptr, d_ptot, nparts);
+    hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
+    hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (const u32*)c.fb_pc.ptr, (const u32*)d_pstart,
+                       key, val, W, win, is_mont, nparts, pshift, (u32)bs.n);
+    MH_HIP(hipMemcpyAsync(ptot.data(), c.fb_ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count
+    u64 bho = 0, xcd_tiles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < nj; k++) {
+      u64 off = jobs.ent_off[k];
+      for (u32 v = 0; v < nparts; v++) {
+        const u32 gw = k * nparts + v;
+        msm::FbWin& d = desc[gw];
+        d.off = off; d.cnt = ptot[gw]; d.ntiles = (u32)((d.cnt + tile - 1) / tile); d.bh_off = bho;
+        off += d.cnt; bho += (u64)d.ntiles * nb; xcd_tiles[gw & 7] += d.ntiles;
+      }
+    }
+    u64 grid_tiles = 0;
+    for (int x = 0; x < 8; x++) grid_tiles = std::max(grid_tiles, xcd_tiles[x]);
+    blk.assign(grid_tiles * 8, F::FbBlk{0xffffffffu, 0});
+    for (u32 x = 0; x < 8; x++) {
+      u64 k = 0;
+      for (u32 gw = x; gw < WT; gw += 8)
+        for (u32 t = 0; t < desc[gw].ntiles; t++) blk[(k++ << 3) | x] = F::FbBlk{gw, t};
+    }
+    MH_HIP(hipMemcpyAsync(c.fb_desc.ptr, desc.data(), (size_t)WT * sizeof(msm::FbWin), hipMemcpyHostToDevice, s));
+    if (grid_tiles) MH_HIP(hipMemcpyAsync(c.fb_blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
+    const msm::FbWin* fbw = (const msm::FbWin*)c.fb_desc.ptr;
+    const F::FbBlk* dblk = (const F::FbBlk*)c.fb_blk.ptr;
+    const size_t lds = (size_t)nb * 4;
+    if (grid_tiles) {
+      hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(msm::HIST_THREADS), lds, s, fbw, dblk, (const u32*)key,
+                         (u32*)c.msm_bh.ptr, nb, (u32)tile);
+    }
+    hipLaunchKernelGGL(F::colscan_kernel, dim3((nb + 255) / 256, WT), dim3(256), 0, s, fbw, (u32*)c.msm_bh.ptr, (u32*)c.msm_tot.ptr, nb);
+    u32* d_max = (u32*)c.tr_sums.ptr;
+    MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
+    hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, nb, d_max);
+    if (grid_tiles) {
+      hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(msm::HIST_THREADS), lds, s, fbw, dblk, (const u32*)key,
+                         (const u32*)val, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr, nb, (u32)tile);
+    }
+    u32 mx = 0;
+    MH_HIP(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    const u64 avg = ent / WB + 1;
+    if (mx > 4096 && (u64)mx > 32 * avg) { skewed = true; return MH_OK; }
+    msm::Jobs none;
+    memset(&none, 0, sizeof(none));
+    {
+      ProfScope pa(c, PF_MSM_ACCUM);
+      const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
+      hipLaunchKernelGGL(msm::accum_kernel<true>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, none, fbw, (const G1Affine*)bs.d_table,
+                         (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (G1Xyzz*)c.msm_buckets.ptr,
+                         (u32*)c.msm_pend.ptr, nb, 1u, (u64)WB);
+    }
+    hipLaunchKernelGGL(msm::fixup_kernel<true>, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, none, fbw, (const G1Affine*)bs.d_table,
+                       (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr, (G1Xyzz*)c.msm_buckets.ptr,
+                       nb, 1u, (u64)WB);
+    // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
+    hipLaunchKernelGGL(msm::reduce1_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const G1Xyzz*)c.msm_buckets.ptr,
+                       (G1Xyzz*)c.msm_seg.ptr, nbt, nseg, (u32)nj);
+    if (chunks > 1) {
+      G1Xyzz* mid = (G1Xyzz*)c.msm_seg.ptr + (size_t)nj * nseg;
+      hipLaunchKernelGGL(msm::reduce2_kernel, dim3(chunks, nj), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr, mid, nseg);
+      hipLaunchKernelGGL(msm::reduce2_kernel, dim3(1, nj), dim3(256), 0, s, (const G1Xyzz*)mid, (G1Xyzz*)c.msm_win.ptr, chunks);
+    } else {
+      hipLaunchKernelGGL(msm::reduce2_kernel, dim3(1, nj), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr, (G1Xyzz*)c.msm_win.ptr, nseg);
+    }
+    MH_HIP(hipGetLastError());
+  }
+  std::vector<uint64_t> sums((size_t)nj * XYZZ_L);
+  MH_HIP(hipMemcpyAsync(sums.data(), c.msm_win.ptr, sums.size() * 8, hipMemcpyDeviceToHost, s));
+  MH_HIP(hipStreamSynchronize(s));
+  for (int k = 0; k < nj; k++) {
+    const uint64_t* p = sums.data() + (size_t)k * XYZZ_L;
+    HFq X, Y, ZZ, ZZZ;
+    memcpy(X.v, p, FQ_B); memcpy(Y.v, p + FQ_L, FQ_B); memcpy(ZZ.v, p + 2 * FQ_L, FQ_B); memcpy(ZZZ.v, p + 3 * FQ_L, FQ_B);
+    out[k] = HG1::from_xyzz(X, Y, ZZ, ZZZ);
+  }
+  return MH_OK;
+}
+
+// Build the window table of a base set: level j = 2^{start_j} * P (c-bit windows tiling 256 bits), affine.
+int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
+  if (bs.d_table) { (void)hipFree(bs.d_table); bs.d_table = nullptr; bs.tab_c = bs.tab_W = 0; }
+  if (bs.n == 0) return MH_OK;
+  if (cbits == 0) {
+    static const int env_c = [] { const char* e = getenv("MH_FB_C"); return e ? atoi(e) : 0; }();
+    if (env_c) cbits = (uint32_t)env_c;
+    else {
+      u32 lg = 0;
+      while ((1ull << lg) < bs.n) lg++;
+      int cc = (int)lg - 2;
+      cbits = (uint32_t)(cc > 20 ? 20 : (cc < 8 ? 8 : cc));
+    }
+  }
+  if (cbits < 4 || cbits > 16 + 6) return fail(MH_EINVAL, "mh_bases_precompute: window width must be in [4, 22]");
+  if (((256 + cbits - 1) / cbits) * (cbits - 1) > 256)
+    return fail(MH_EINVAL, "mh_bases_precompute: windows of window_bits / window_bits - 1 bits cannot tile 256 bits (21: use 20)");
+  msm::Windows win;
+  const u32 W = msm::make_windows(cbits, win);
+  if ((u64)W * bs.n >= (1ull << 31)) return fail(MH_EINVAL, "mh_bases_precompute: table too large for 31-bit entry indices");
+  void* tab = nullptr;
+  hipError_t e = hipMalloc(&tab, (size_t)W * bs.n * PT_B);
+  if (e != hipSuccess) return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the window table failed");
+  hipStream_t s = c.stream;
+  MH_HIP(hipMemcpyAsync(tab, bs.d_points, bs.n * PT_B, hipMemcpyDeviceToDevice, s));
+  for (u32 j = 1; j < W; j++)
+    hipLaunchKernelGGL(msmfb::table_level_kernel, dim3((unsigned)((bs.n + 127) / 128)), dim3(128), 0, s,
+                       (const G1Affine*)((const char*)tab + (size_t)(j - 1) * bs.n * PT_B), (G1Affine*)((char*)tab + (size_t)j * bs.n * PT_B),
+                       (u64)bs.n, (u32)win.bits[j - 1]);
+  MH_HIP(hipGetLastError());
+  MH_HIP(hipStreamSynchronize(s));
+  bs.d_table = tab; bs.tab_c = cbits; bs.tab_W = W;
+  return MH_OK;
+}
+
 // A batch of independent MSMs through one launch sequence.  d_bases[j]: G1Affine[n_j]; d_scalars[j]: Fr[n_j];
 // out_xyz: njobs x 18 limbs (Jacobian).  Jobs with n_j == 0 yield the identity.
 int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const void* const* d_scalars, const size_t* ns,
@@ -229,11 +416,39 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
   for (int j = 0; j < njobs_in; j++) if (ns[j]) { if (ns[j] >= (1ull << 31)) return fail(MH_EINVAL, "msm: n must be < 2^31"); live.push_back(j); }
   MH_TRY(msm_set_attrs());
   hipStream_t s = c.stream;
+  // MH_MSM_ALGO = xyzz | tree forces that accumulation on the variable-base path (and disables the fixed-base tables)
   static const int forced = [] { const char* e = getenv("MH_MSM_ALGO"); return !e ? 0 : (std::string(e) == "tree" ? 2 : 1); }();
   for (size_t g0 = 0; g0 < live.size(); g0 += msm::MAX_JOBS) {
     const int nj = (int)std::min<size_t>(msm::MAX_JOBS, live.size() - g0);
     size_t nmax = 0, nsum = 0;
     for (int k = 0; k < nj; k++) { size_t n = ns[live[g0 + k]]; nmax = std::max(nmax, n); nsum += n; }
+    // fixed-base path: every job of the group lies inside one base set with a window table, and the shared bucket
+    // set is reasonably loaded
+    if (forced == 0) {
+      size_t off0 = 0;
+      const BaseSet* bs = find_table(c, d_bases[live[g0]], ns[live[g0]], off0);
+      bool ok = bs != nullptr;
+      std::vector<size_t> offs(nj); std::vector<const void*> sc(nj); std::vector<size_t> nn(nj);
+      for (int k = 0; ok && k < nj; k++) {
+        size_t o = 0;
+        ok = find_table(c, d_bases[live[g0 + k]], ns[live[g0 + k]], o) == bs;
+        offs[k] = o; sc[k] = d_scalars[live[g0 + k]]; nn[k] = ns[live[g0 + k]];
+      }
+      if (ok && (u64)bs->tab_W * nsum >= 8ull * nj * (1ull << (bs->tab_c - 1))) {
+        std::vector<HG1> res(nj);
+        bool skewed = false;
+        MH_TRY(msm_fb_group(c, *bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed));
+        if (!skewed) {
+          c.n_fb_groups++;
+          for (int k = 0; k < nj; k++) {
+            uint64_t* o = out_xyz + XYZ_L * live[g0 + k];
+            memcpy(o, res[k].X.v, FQ_B); memcpy(o + FQ_L, res[k].Y.v, FQ_B); memcpy(o + 2 * FQ_L, res[k].Z.v, FQ_B);
+          }
+          continue;
+        }
+      }
+    }
+    c.n_vb_groups++;
     msm::Plan p = msm::make_plan(nmax);
     // tiles: aim for ~1024 (window, tile) blocks over the whole batch
     {
@@ -272,7 +487,10 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
                          (const u32*)c.msm_dig.ptr, (u32*)c.msm_bh.ptr, p.nb, p.tile, max_tiles, p.W);
       hipLaunchKernelGGL(msm::colscan_kernel, dim3((p.nb + 255) / 256, p.W, nj), dim3(256), 0, s, jobs, (u32*)c.msm_bh.ptr,
                          (u32*)c.msm_tot.ptr, p.nb, p.W);
-      hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, p.nb);
+      MH_TRY(c.tr_sums.ensure(64));
+      u32* d_max = (u32*)c.tr_sums.ptr;
+      MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
+      hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, p.nb, d_max);
       hipLaunchKernelGGL(msm::scatter_kernel, dim3(msm::xcd_grid(max_tiles, WT)), dim3(msm::HIST_THREADS), lds, s, jobs,
                          (const u32*)c.msm_dig.ptr, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr,
                          p.nb, p.tile, p.W, max_tiles);
@@ -280,10 +498,6 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
       // (e.g. many equal scalars), where a thread-per-bucket loop would serialise.  MH_MSM_ALGO=xyzz|tree forces one.
       bool use_tree = forced == 2;
       if (forced == 0) {
-        MH_TRY(c.tr_sums.ensure(64));
-        u32* d_max = (u32*)c.tr_sums.ptr;
-        MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
-        hipLaunchKernelGGL(msm::max_kernel, dim3((unsigned)((WB + 255) / 256)), dim3(256), 0, s, (const u32*)c.msm_tot.ptr, (u64)WB, d_max);
         u32 mx = 0;
         MH_HIP(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
@@ -296,11 +510,13 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
           // (forcing 2 resident blocks per CU to make the block count an integral number of rounds was measured
           //  and is not faster than letting 3 reside: 15.3 vs 14.6 ms at 2^22)
           const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
-          hipLaunchKernelGGL(msm::accum_kernel, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, jobs, (u32*)c.msm_sorted.ptr,
+          hipLaunchKernelGGL(msm::accum_kernel<false>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, jobs, (const msm::FbWin*)nullptr,
+                             (const G1Affine*)nullptr, (u32*)c.msm_sorted.ptr,
                              (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (G1Xyzz*)c.msm_buckets.ptr,
                              (u32*)c.msm_pend.ptr, p.nb, p.W, (u64)WB);
         }
-        hipLaunchKernelGGL(msm::fixup_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, jobs, (const u32*)c.msm_sorted.ptr,
+        hipLaunchKernelGGL(msm::fixup_kernel<false>, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, jobs, (const msm::FbWin*)nullptr,
+                           (const G1Affine*)nullptr, (const u32*)c.msm_sorted.ptr,
                            (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr, (G1Xyzz*)c.msm_buckets.ptr, p.nb, p.W, (u64)WB);
       } else {
         ProfScope pa(c, PF_MSM_ACCUM);
@@ -308,7 +524,7 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
       }
       hipLaunchKernelGGL(msm::reduce1_kernel, dim3((WT * p.nseg + 63) / 64), dim3(64), 0, s, (const G1Xyzz*)c.msm_buckets.ptr,
                          (G1Xyzz*)c.msm_seg.ptr, p.nb, p.nseg, WT);
-      hipLaunchKernelGGL(msm::reduce2_kernel, dim3(WT), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr, (G1Xyzz*)c.msm_win.ptr, p.nseg);
+      hipLaunchKernelGGL(msm::reduce2_kernel, dim3(1, WT), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr, (G1Xyzz*)c.msm_win.ptr, p.nseg);
       MH_HIP(hipGetLastError());
     }
     std::vector<uint64_t> win((size_t)WT * XYZZ_L);
@@ -433,8 +649,9 @@ int mh_shutdown(void) {
   c.msm_buckets.release(); c.msm_seg.release(); c.msm_win.release(); c.msm_pend.release();
   for (auto& b : c.tr_off) b.release(); for (auto& b : c.tr_cnt) b.release(); for (auto& b : c.tr_p) b.release();
   c.tr_sums.release(); c.tr_ob.release(); c.tr_pre.release(); c.tr_prod.release(); c.tr_scr.release();
-  for (auto& kv : c.bases) if (kv.second.d_points) (void)hipFree(kv.second.d_points);
+  for (auto& kv : c.bases) { if (kv.second.d_points) (void)hipFree(kv.second.d_points); if (kv.second.d_table) (void)hipFree(kv.second.d_table); }
   c.bases.clear();
+  c.fb_val.release(); c.fb_pc.release(); c.fb_ptot.release(); c.fb_desc.release(); c.fb_blk.release();
   if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }
   for (auto& r : c.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   c.prof.clear();
@@ -616,7 +833,22 @@ int mh_bases_free(uint64_t handle) {
   if (it == c.bases.end()) return fail(MH_EINVAL, "mh_bases_free: unknown handle");
   MH_HIP(hipStreamSynchronize(c.stream));
   if (it->second.d_points) (void)hipFree(it->second.d_points);
+  if (it->second.d_table) (void)hipFree(it->second.d_table);
   c.bases.erase(it);
+  return MH_OK;
+}
+
+int mh_bases_precompute(uint64_t handle, uint32_t window_bits) {
+  LOCKED_CTX();
+  auto it = c.bases.find(handle);
+  if (it == c.bases.end()) return fail(MH_EINVAL, "mh_bases_precompute: unknown handle");
+  return bases_precompute(c, it->second, window_bits);
+}
+
+int mh_msm_path_counts(uint64_t* fixed_base_groups, uint64_t* variable_base_groups) {
+  LOCKED_CTX();
+  if (fixed_base_groups) *fixed_base_groups = c.n_fb_groups;
+  if (variable_base_groups) *variable_base_groups = c.n_vb_groups;
   return MH_OK;
 }
 

@@ -57,6 +57,9 @@ struct Scratch {
 struct BaseSet {
   void* d_points = nullptr;  // G1Affine[n]
   size_t n = 0;
+  // fixed-base window table (mh_bases_precompute): G1Affine[tab_W][n], level j = 2^{start_j} * points; level 0 is a copy
+  void* d_table = nullptr;
+  uint32_t tab_c = 0, tab_W = 0;
 };
 
 enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_COUNT = 4 };
@@ -80,6 +83,8 @@ struct Context {
   std::map<uint64_t, BaseSet> bases;
   uint64_t next_handle = 1;
   Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win, msm_pend;
+  Scratch fb_val, fb_pc, fb_ptot, fb_desc, fb_blk;   // fixed-base path (msm_fb.cuh)
+  uint64_t n_fb_groups = 0, n_vb_groups = 0;  // job groups that ran on the fixed-base / variable-base path
   Scratch tr_off[3], tr_cnt[2], tr_p[2], tr_sums, tr_ob, tr_pre, tr_prod, tr_scr;   // pair-tree accumulation
 
   // profiling

@@ -10,6 +10,8 @@ int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mo
 // a batch of independent MSMs through one launch sequence; out_xyz: njobs x 18 limbs
 int msm_batch_device(Context& c, int njobs, const void* const* d_bases, const void* const* d_scalars, const size_t* ns, int is_mont,
                      uint64_t* out_xyz);
+// fixed-base window table for a base set (msm_fb.cuh); window_bits = 0 picks a width from the set's size
+int bases_precompute(Context& c, BaseSet& bs, uint32_t window_bits);
 // twiddle table (tw[2^(l-1) + e] = omega_{2^l}^e) covering at least log_n levels
 int ensure_twiddles_public(Context& c, uint32_t log_n);
 }  // namespace mh

@@ -16,7 +16,7 @@
 //                 one u32 entry (bucket+1 | sign<<31, 0 = skip) per (window, scalar)
 //   2. hist     : per (window, tile) LDS-privatised histogram of bucket ids
 //   3. colscan  : per (window, bucket) exclusive prefix over tiles + bucket totals
-//   4. binscan  : per window exclusive scan over buckets -> bucket start offsets
+//   4. binscan  : per window exclusive scan over buckets -> bucket start offsets (+ the largest bucket size)
 //   5. scatter  : per (window, tile) LDS-atomic local rank -> point-index lists
 //                 grouped by bucket (counting sort; no global atomics anywhere)
 //   6. accum    : one thread per (window, bucket): XYZZ += affine base (8M+2S); rare collisions
@@ -69,6 +69,20 @@ struct Jobs {
   u32 njobs;
 };
 
+// windows of c or c-1 bits (the narrow ones on top) tiling exactly 256 bits; returns their number
+inline u32 make_windows(u32 c, Windows& win) {
+  const u32 W = (256 + c - 1) / c;
+  const u32 narrow = W * c - 256;
+  u32 bit = 0;
+  for (u32 w = 0; w < W; w++) {
+    u32 wb = (w >= W - narrow) ? c - 1 : c;
+    win.start[w] = (unsigned char)bit;
+    win.bits[w] = (unsigned char)wb;
+    bit += wb;
+  }
+  return W;
+}
+
 inline Plan make_plan(u64 n) {
   Plan p;
   u32 lg = 0;
@@ -78,18 +92,8 @@ inline Plan make_plan(u64 n) {
   if (c > 16) c = 16;
   if (c < 4) c = 4;
   p.c = (u32)c;
-  p.W = (256 + c - 1) / c;
   p.nb = 1u << (c - 1);
-  {
-    u32 narrow = p.W * c - 256;          // windows that are c-1 bits wide (the top ones)
-    u32 bit = 0;
-    for (u32 w = 0; w < p.W; w++) {
-      u32 wb = (w >= p.W - narrow) ? (u32)c - 1 : (u32)c;
-      p.win.start[w] = (unsigned char)bit;
-      p.win.bits[w] = (unsigned char)wb;
-      bit += wb;
-    }
-  }
+  p.W = make_windows((u32)c, p.win);
   u64 t = (n * p.W + 1023) / 1024;       // aim for ~1024 tiles in total
   if (t < 4096) t = 4096;
   if (t > 65536) t = 65536;
@@ -100,14 +104,9 @@ inline Plan make_plan(u64 n) {
 }
 
 // ---- 1. digits -----------------------------------------------------------------
-__global__ __launch_bounds__(256) void digits_kernel(Jobs jobs, u32* __restrict__ dig_all, u32 W, Windows win, int is_mont) {
-  const u32 job = blockIdx.y;
-  const u64 n = jobs.n[job];
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  u32* dig = dig_all + jobs.ent_off[job];
-  Fr s = ff_load(jobs.scalars[job] + i);
-  if (is_mont) s = ff_from_mont(s);
+// signed base-2^c recoding of a canonical scalar: f(w, e) with e = bucket | sign << 31 (bucket in [0, 2^(wb-1)], 0 = skip)
+template <class F>
+__device__ __forceinline__ void for_each_digit(const Fr& s, u32 W, const Windows& win, F f) {
   u32 carry = 0;
   for (u32 w = 0; w < W; w++) {
     const u32 bit = win.start[w], wb = win.bits[w];
@@ -120,8 +119,19 @@ __global__ __launch_bounds__(256) void digits_kernel(Jobs jobs, u32* __restrict_
     u32 e;
     if (raw > half) { e = ((1u << wb) - raw) | 0x80000000u; carry = 1; }
     else { e = raw; carry = 0; }           // raw == 0 -> skip entry
-    dig[(u64)w * n + i] = e;
+    f(w, e);
   }
+}
+
+__global__ __launch_bounds__(256) void digits_kernel(Jobs jobs, u32* __restrict__ dig_all, u32 W, Windows win, int is_mont) {
+  const u32 job = blockIdx.y;
+  const u64 n = jobs.n[job];
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32* dig = dig_all + jobs.ent_off[job];
+  Fr s = ff_load(jobs.scalars[job] + i);
+  if (is_mont) s = ff_from_mont(s);
+  for_each_digit(s, W, win, [&](u32 w, u32 e) { dig[(u64)w * n + i] = e; });
 }
 
 // ---- 2. hist ---------------------------------------------------------------------
@@ -186,13 +196,19 @@ __global__ __launch_bounds__(256) void colscan_kernel(Jobs jobs, u32* __restrict
 }
 
 // ---- 4. binscan: block per window: exclusive scan of tot -> base -----------------
-__global__ __launch_bounds__(1024) void binscan_kernel(const u32* __restrict__ tot, u32* __restrict__ base, u32 nb) {
+// also folds the largest bucket size of the whole launch into *maxout (selects the accumulation algorithm)
+__global__ __launch_bounds__(1024) void binscan_kernel(const u32* __restrict__ tot, u32* __restrict__ base, u32 nb, u32* __restrict__ maxout) {
   __shared__ u32 part[1024];
+  __shared__ u32 wmax;
   const u32 w = blockIdx.x;
   const u32 per = (nb + 1023) / 1024;
   const u32 lo = threadIdx.x * per;
-  u32 s = 0;
-  for (u32 k = 0; k < per; k++) { u32 b = lo + k; if (b < nb) s += tot[(u64)w * nb + b]; }
+  u32 s = 0, m = 0;
+  if (threadIdx.x == 0) wmax = 0;
+  for (u32 k = 0; k < per; k++) { u32 b = lo + k; if (b < nb) { u32 t = tot[(u64)w * nb + b]; s += t; m = t > m ? t : m; } }
+  __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) { u32 o = __shfl_down(m, off); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(&wmax, m);
   part[threadIdx.x] = s;
   __syncthreads();
   // Hillis-Steele inclusive scan over 1024 partials
@@ -207,6 +223,7 @@ __global__ __launch_bounds__(1024) void binscan_kernel(const u32* __restrict__ t
     u32 b = lo + k;
     if (b < nb) { base[(u64)w * nb + b] = run; run += tot[(u64)w * nb + b]; }
   }
+  if (threadIdx.x == 0 && wmax) atomicMax(maxout, wmax);
 }
 
 // ---- 5. scatter -------------------------------------------------------------------
@@ -258,7 +275,13 @@ __global__ __launch_bounds__(HIST_THREADS) void scatter_kernel(Jobs jobs, const 
 // (A persistent variant that handed buckets to lanes dynamically was slower: lanes refilling a bucket stall the
 // lanes that are adding, through the dependent loads of the refill path.)
 constexpr int ACC_TPB = 256;
-__global__ __launch_bounds__(ACC_TPB) void accum_kernel(Jobs jobs, u32* __restrict__ sorted_all,
+// Virtual window of the fixed-base path (msm_fb.cuh): a variable-length run of the entry arrays
+struct FbWin { u64 off; u64 bh_off; u32 cnt; u32 ntiles; };
+// FB = false: bucket gid = (job * W + w) * nb + b, list inside the job's window region, bases per job;
+// FB = true : gid = gw * nb + b with gw a virtual window described by fbw[gw]; entries index the precomputed table
+template <bool FB>
+__global__ __launch_bounds__(ACC_TPB) void accum_kernel(Jobs jobs, const FbWin* __restrict__ fbw, const G1Affine* __restrict__ table,
+                                                        u32* __restrict__ sorted_all,
                                                         const u32* __restrict__ base, const u32* __restrict__ tot,
                                                         G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u32 nb, u32 W,
                                                         u64 WB) {
@@ -285,10 +308,17 @@ __global__ __launch_bounds__(ACC_TPB) void accum_kernel(Jobs jobs, u32* __restri
   }
   const u64 gid = lo + (keys[threadIdx.x] & 255u);
   if (gid >= WB) return;
-  const u32 job = (u32)(gid / ((u64)W * nb));
-  const u32 w = (u32)((gid / nb) % W);
-  const G1Affine* __restrict__ bases = jobs.bases[job];
-  u32* lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
+  const G1Affine* __restrict__ bases;
+  u32* lst;
+  if (FB) {
+    bases = table;
+    lst = sorted_all + fbw[gid / nb].off + base[gid];
+  } else {
+    const u32 job = (u32)(gid / ((u64)W * nb));
+    const u32 w = (u32)((gid / nb) % W);
+    bases = jobs.bases[job];
+    lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
+  }
   const u32 cnt = tot[gid];
   if (cnt == 0) { g1_store_xyzz(buckets + gid, G1Xyzz::identity()); pend[gid] = 0; return; }
   G1Xyzz acc;
@@ -321,17 +351,26 @@ __global__ __launch_bounds__(ACC_TPB) void accum_kernel(Jobs jobs, u32* __restri
 }
 
 // deferred entries (see accum_kernel): full group law, one thread per bucket that has any
-__global__ __launch_bounds__(64) void fixup_kernel(Jobs jobs, const u32* __restrict__ sorted_all,
+template <bool FB>
+__global__ __launch_bounds__(64) void fixup_kernel(Jobs jobs, const FbWin* __restrict__ fbw, const G1Affine* __restrict__ table,
+                                                   const u32* __restrict__ sorted_all,
                                                    const u32* __restrict__ base, const u32* __restrict__ pend,
                                                    G1Xyzz* __restrict__ buckets, u32 nb, u32 W, u64 WB) {
   u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= WB) return;
   const u32 np = pend[gid];
   if (np == 0) return;
-  const u32 job = (u32)(gid / ((u64)W * nb));
-  const u32 w = (u32)((gid / nb) % W);
-  const G1Affine* __restrict__ bases = jobs.bases[job];
-  const u32* lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
+  const G1Affine* __restrict__ bases;
+  const u32* lst;
+  if (FB) {
+    bases = table;
+    lst = sorted_all + fbw[gid / nb].off + base[gid];
+  } else {
+    const u32 job = (u32)(gid / ((u64)W * nb));
+    const u32 w = (u32)((gid / nb) % W);
+    bases = jobs.bases[job];
+    lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
+  }
   G1Xyzz acc = g1_load_xyzz(buckets + gid);
   for (u32 k = 0; k < np; k++) {
     u32 e = lst[k];
@@ -340,14 +379,6 @@ __global__ __launch_bounds__(64) void fixup_kernel(Jobs jobs, const u32* __restr
     g1_madd(acc, p.x, p.y);
   }
   g1_store_xyzz(buckets + gid, acc);
-}
-
-// largest bucket (selects the accumulation algorithm)
-__global__ __launch_bounds__(256) void max_kernel(const u32* __restrict__ tot, u64 n, u32* __restrict__ out) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  u32 m = i < n ? tot[i] : 0;
-  for (int off = 32; off > 0; off >>= 1) { u32 o = __shfl_down(m, off); m = o > m ? o : m; }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 // ---- 7. reduce1: thread per (window, segment) ----------------------------------------
@@ -378,13 +409,19 @@ __global__ __launch_bounds__(64) void reduce1_kernel(const G1Xyzz* __restrict__ 
   g1_store_xyzz(segsum + gid, acc);
 }
 
-// ---- 8. reduce2: block per window -----------------------------------------------------
+// ---- 8. reduce2: tree sums ---------------------------------------------------------------
+// grid (chunks, windows): block (k, w) sums elements [k * per, (k + 1) * per) of window w's nseg points into
+// out[w * chunks + k].  One launch with chunks = 1 when nseg is small, two launches (chunks = nseg / 256, then 1)
+// when a single block per window would spend its time in a long serial loop (the fixed-base path: 16384 segments).
 __global__ __launch_bounds__(256) void reduce2_kernel(const G1Xyzz* __restrict__ segsum, G1Xyzz* __restrict__ winsum,
                                                       u32 nseg) {
   __shared__ G1Xyzz sh[256];
-  const u32 w = blockIdx.x;
+  const u32 w = blockIdx.y, chunks = gridDim.x;
+  const u32 per = (nseg + chunks - 1) / chunks;
+  const u32 lo = blockIdx.x * per;
+  u32 hi = lo + per; if (hi > nseg) hi = nseg;
   G1Xyzz acc = G1Xyzz::identity();
-  for (u32 s = threadIdx.x; s < nseg; s += 256) {
+  for (u32 s = lo + threadIdx.x; s < hi; s += 256) {
     G1Xyzz t = g1_load_xyzz(segsum + (u64)w * nseg + s);
     g1_add(acc, t);
   }
@@ -399,7 +436,7 @@ __global__ __launch_bounds__(256) void reduce2_kernel(const G1Xyzz* __restrict__
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) g1_store_xyzz(winsum + w, sh[0]);
+  if (threadIdx.x == 0) g1_store_xyzz(winsum + (u64)w * chunks + blockIdx.x, sh[0]);
 }
 
 }  // namespace msm

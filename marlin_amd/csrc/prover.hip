@@ -477,6 +477,12 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
   auto sg = c.bases.find(srs_g), sgg = c.bases.find(srs_gamma_g);
   if (sg == c.bases.end() || sgg == c.bases.end()) return fail(MH_EINVAL, "mh_marlin_index: unknown SRS handle");
   if (sgg->second.n < 3) return fail(MH_EINVAL, "mh_marlin_index: powers_of_gamma_g needs >= 3 points");
+  // every commitment of this key multiplies the same powers_of_g: precompute their window table once (msm_fb.cuh).
+  // MH_FB=0 keeps the variable-base path.
+  {
+    static const bool fb_on = [] { const char* e = getenv("MH_FB"); return !e || atoi(e) != 0; }();
+    if (fb_on && !sg->second.d_table) MH_TRY(bases_precompute(c, sg->second, 0));
+  }
 
   std::unique_ptr<ProverKey> pkp(new ProverKey());
   ProverKey& pk = *pkp;

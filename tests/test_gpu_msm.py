@@ -151,3 +151,67 @@ def test_msm_batch_equals_individual(gpu, bases4k):
         assert jac_np_to_affine(out[k]) == want[k], k
         if sizes[k]:
             assert jac_np_to_affine(gpu.msm_dev(B, bufs[k], sizes[k], base_offset=offs[k])) == want[k]
+
+
+# ---- fixed-base path: mh_bases_precompute + Pippenger over the window table (msm_fb.cuh) -----------------------
+
+@pytest.mark.parametrize("cbits,n", [(6, 4096), (9, 2 ** 14), (13, 2 ** 16 + 7), (16, 2 ** 17), (17, 2 ** 18), (18, 2 ** 19 - 3), (20, 2 ** 19 + 11)])
+def test_msm_fixed_base_every_layout(gpu, bases4k, cbits, n):
+    """window widths with one virtual window (c <= 13) and with 8 ... 128 of them (c = 16 ... 20); known-dlog answer, and the
+    same element as the variable-base path on a set without a table."""
+    pts, dl = bases4k
+    reps = (n + 4095) // 4096
+    big = np.tile(points_to_np(pts), (reps, 1))[:n]
+    B = gpu.Bases(big).precompute(cbits)
+    sc = rand_fr(n, 900 + n)
+    fb0, vb0 = gpu.msm_path_counts()
+    out = gpu.msm(B, fr_to_np(sc))
+    assert gpu.msm_path_counts() == (fb0 + 1, vb0)            # served by the fixed-base path
+    k = sum(s * dl[i % 4096] for i, s in enumerate(sc)) % F.R_MOD
+    assert jac_np_to_affine(out) == EC.scalar_mul(EC.G1_GEN, k)
+    B0 = gpu.Bases(big)
+    assert jac_np_to_affine(gpu.msm(B0, fr_to_np(sc))) == jac_np_to_affine(out)
+    assert gpu.msm_path_counts() == (fb0 + 1, vb0 + 1)
+
+
+def test_msm_fixed_base_offsets_batch_and_edges(gpu, bases4k):
+    """offsets into the tabled set, canonical scalars, a batch of jobs (one empty, one tiny; 9 live jobs = two groups),
+    edge scalars 0 / 1 / r-1 / 2^k with heavily repeated (base, scalar) pairs (the deferred-collision fix-up), and a
+    skewed input that makes the driver fall back to the variable-base path and its pair tree."""
+    pts, dl = bases4k
+    n = 1 << 15
+    big = np.tile(points_to_np(pts), (n // 4096, 1))
+    dlb = [dl[i % 4096] for i in range(n)]
+    B = gpu.Bases(big).precompute(10)
+    r = F.R_MOD
+
+    def want(sc, off):
+        return EC.scalar_mul(EC.G1_GEN, sum(s * a for s, a in zip(sc, dlb[off:off + len(sc)])) % r)
+
+    sc = rand_fr(20000, 3)
+    assert jac_np_to_affine(gpu.msm(B, fr_to_np(sc), base_offset=12345)) == want(sc, 12345)
+    assert jac_np_to_affine(gpu.msm(B, fr_to_np(sc[:12768]), base_offset=20000)) == want(sc[:12768], 20000)   # ends at the last base
+    assert jac_np_to_affine(gpu.msm(B, fr_to_np(sc, montgomery=False), base_offset=1, montgomery=False)) == want(sc, 1)
+    edge = ([0, 1, r - 1, 2, r - 2, 1 << 254, (1 << 255) % r, 1 << 19, (1 << 20) - 1, 1 << 9, 513] * 2000)[:n - 5]
+    assert jac_np_to_affine(gpu.msm(B, fr_to_np(edge), base_offset=5)) == want(edge, 5)
+    assert jac_np_to_affine(gpu.msm(B, fr_to_np([0] * 9000))) is None
+    sizes = [30000, 0, 12000, 40, 32768, 9000, 25000, 8191, 16384, 31000]
+    offs = [100, 0, 20000, 7, 0, 1, 7000, 3, 16384, 1768]
+    bufs, jobs, exp = [], [], []
+    for k, (m, off) in enumerate(zip(sizes, offs)):
+        s = rand_fr(m, 2000 + k)
+        bufs.append(gpu.DeviceBuffer.from_numpy(fr_to_np(s)) if m else gpu.DeviceBuffer(32))
+        jobs.append((B, off, bufs[-1], m))
+        exp.append(want(s, off) if m else None)
+    out = gpu.msm_batch_dev(jobs)
+    for k in range(len(jobs)):
+        assert jac_np_to_affine(out[k]) == exp[k], k
+    vals = rand_fr(3, 41)
+    skew = [vals[i % 3] for i in range(n)]
+    assert jac_np_to_affine(gpu.msm(B, fr_to_np(skew))) == want(skew, 0)
+    B16 = gpu.Bases(big).precompute(16)          # 2^15 buckets, average load 16, largest ~10900: falls back
+    fb0, vb0 = gpu.msm_path_counts()
+    assert jac_np_to_affine(gpu.msm(B16, fr_to_np(skew))) == want(skew, 0)
+    assert gpu.msm_path_counts() == (fb0, vb0 + 1)
+    with pytest.raises(gpu.MarlinHipError):
+        gpu.Bases(big[:64]).precompute(23)
