@@ -90,7 +90,7 @@ int mh_bases_len(uint64_t handle, size_t* n_out);
 /* Fixed-base acceleration for a base set that is multiplied again and again (the SRS): precomputes the shifts
  * 2^{start_j} * P of all window positions (W x n affine points of device memory; W = 13 at window_bits = 20), after
  * which every MSM against this handle with enough scalars runs Pippenger over ONE shared bucket set.  window_bits
- * in [4, 22], 0 = choose from n.  Results are unchanged (an MSM has one answer).  mh_marlin_index calls this for
+ * in [4, 20], 0 = choose from n.  Results are unchanged (an MSM has one answer).  mh_marlin_index calls this for
  * powers_of_g.  No counterpart in the reference (arkworks recomputes nothing across calls). */
 int mh_bases_precompute(uint64_t handle, uint32_t window_bits);
 /* How many job groups (<= 8 MSMs launched together) have run on the fixed-base path / on the variable-base path

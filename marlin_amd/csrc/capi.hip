@@ -136,8 +136,8 @@ static int msm_set_attrs() {
   int lds = 32768 * 4;
   MH_HIP(hipFuncSetAttribute((const void*)msm::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   g_msm_attr_done = true;
   return MH_OK;
 }
@@ -252,6 +252,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   const u32 nparts = nbt / nb;
   const u32 WT = nparts * nj;
   const size_t WB = (size_t)nbt * nj;
+  const u32 S = F::split_scalars(W);                                     // scalars per count / split block
   F::FbJobs jobs;
   memset(&jobs, 0, sizeof(jobs));
   jobs.njobs = nj;
@@ -259,14 +260,14 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   for (int k = 0; k < nj; k++) {
     jobs.scalars[k] = (const Fr*)d_scalars[k]; jobs.n[k] = ns[k]; jobs.tab_off[k] = (u32)offs[k];
     jobs.ent_off[k] = ent; ent += (u64)W * ns[k];
-    jobs.nblk[k] = (u32)((ns[k] + F::TPB * F::SPT - 1) / (F::TPB * F::SPT));
+    jobs.nblk[k] = (u32)((ns[k] + S - 1) / S);
     jobs.pc_off[k] = pco; pco += (u64)nparts * jobs.nblk[k];
     max_blk = std::max(max_blk, jobs.nblk[k]);
   }
   if (ent >= (1ull << 32)) return fail(MH_EINVAL, "msm batch too large for 32-bit entry offsets");
-  u64 tile = (ent + 1023) / 1024;
-  if (tile < 4096) tile = 4096;
-  if (tile > 65536) tile = 65536;
+  u64 tile = (ent + 2047) / 2048;
+  if (tile < 2048) tile = 2048;
+  if (tile > F::MAX_TILE) tile = F::MAX_TILE;
   const u64 max_tiles_total = ent / tile + WT + 1;
   MH_TRY(c.msm_dig.ensure(ent * 4)); MH_TRY(c.fb_val.ensure(ent * 4)); MH_TRY(c.msm_sorted.ensure(ent * 4));
   MH_TRY(c.fb_pc.ensure(pco * 4)); MH_TRY(c.fb_ptot.ensure((size_t)WT * 8)); MH_TRY(c.fb_desc.ensure((size_t)WT * sizeof(msm::FbWin)));
@@ -286,11 +287,11 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     ProfScope ps(c, PF_MSM);
     u32* key = (u32*)c.msm_dig.ptr; u32* val = (u32*)c.fb_val.ptr;
     u32* d_ptot = (u32*)c.fb_ptot.ptr; u32* d_pstart = d_ptot + WT;
-    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)c.fb_pc.ptr, W, win, is_mont, nparts, pshift);
+    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)c.fb_pc.ptr, W, win, is_mont, nparts, pshift, S);
     hipLaunchKernelGGL(F::pscan_kernel, dim3(nparts, nj), dim3(1024), 0, s, jobs, (u32*)c.fb_pc.ptr, d_ptot, nparts);
     hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
-    hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (const u32*)c.fb_pc.ptr, (const u32*)d_pstart,
-                       key, val, W, win, is_mont, nparts, pshift, (u32)bs.n);
+    hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)c.fb_pc.ptr,
+                       (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S);
     MH_HIP(hipMemcpyAsync(ptot.data(), c.fb_ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count
@@ -318,7 +319,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     const F::FbBlk* dblk = (const F::FbBlk*)c.fb_blk.ptr;
     const size_t lds = (size_t)nb * 4;
     if (grid_tiles) {
-      hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(msm::HIST_THREADS), lds, s, fbw, dblk, (const u32*)key,
+      hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), lds, s, fbw, dblk, (const u32*)key,
                          (u32*)c.msm_bh.ptr, nb, (u32)tile);
     }
     hipLaunchKernelGGL(F::colscan_kernel, dim3((nb + 255) / 256, WT), dim3(256), 0, s, fbw, (u32*)c.msm_bh.ptr, (u32*)c.msm_tot.ptr, nb);
@@ -326,7 +327,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
     hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, nb, d_max);
     if (grid_tiles) {
-      hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(msm::HIST_THREADS), lds, s, fbw, dblk, (const u32*)key,
+      hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::scatter_lds_bytes(nb), s, fbw, dblk, (const u32*)key,
                          (const u32*)val, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr, nb, (u32)tile);
     }
     u32 mx = 0;
@@ -384,9 +385,7 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
       cbits = (uint32_t)(cc > 20 ? 20 : (cc < 8 ? 8 : cc));
     }
   }
-  if (cbits < 4 || cbits > 16 + 6) return fail(MH_EINVAL, "mh_bases_precompute: window width must be in [4, 22]");
-  if (((256 + cbits - 1) / cbits) * (cbits - 1) > 256)
-    return fail(MH_EINVAL, "mh_bases_precompute: windows of window_bits / window_bits - 1 bits cannot tile 256 bits (21: use 20)");
+  if (cbits < 4 || cbits > (uint32_t)msmfb::MAX_C) return fail(MH_EINVAL, "mh_bases_precompute: window width must be in [4, 20]");
   msm::Windows win;
   const u32 W = msm::make_windows(cbits, win);
   if ((u64)W * bs.n >= (1ull << 31)) return fail(MH_EINVAL, "mh_bases_precompute: table too large for 31-bit entry indices");

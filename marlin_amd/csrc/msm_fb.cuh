@@ -9,14 +9,16 @@
 // c = 20 needs 13 bucket additions per scalar instead of 16.
 //
 // Sorting 13 n entries by a 19-bit bucket id is done in two levels:
-//   count/pscan/pstart/split : partition the entries by the top bits of the bucket id into "virtual windows" of
-//                       2^12 buckets; per-block LDS counters, a scan over blocks, then LDS-ranked writes (runs of
-//                       ~400 B per block and partition)
-//   hist/colscan/binscan/scatter : the LDS counting sort of msm.cuh inside every virtual window, driven by a
-//                       descriptor (offset, count, tiles) per virtual window because their sizes differ.  With 4096
-//                       buckets per virtual window a 65536-entry tile writes ~16 consecutive entries per bucket,
-//                       i.e. whole 64-byte lines (the 2^15-bucket windows of the variable-base path write 8 bytes
-//                       at a time and cost ~8x their payload in HBM writes: profiles/pmc_traffic.json)
+//   count/pscan/pstart/split : partition the entries by the top bits of the bucket id into <= 256 "virtual windows"
+//                       of 2^11 buckets (per-block LDS counters, a scan over blocks, then the split proper)
+//   hist/colscan/binscan/scatter : a counting sort inside every virtual window, driven by a descriptor (offset,
+//                       count, tiles) per virtual window because their sizes differ
+// Both split and scatter first sort their block's entries in LDS and then copy the sorted block out, so the lanes
+// of a wave store to consecutive addresses: runs of ~200 B per (block, partition) in split, ~32 B per (tile, bucket)
+// in scatter.  Ranking straight into global memory (what the variable-base path's scatter does) issues one 4-byte
+// store per entry to ~random lines; the L2s cannot keep that many partial lines open, and HBM sees ~8x the payload
+// (profiles/pmc_traffic.json; measured the same way for this path before the LDS staging: 2.6 GB written per launch
+// for 0.33 GB of entries).
 // followed by msm.cuh's accumulate (entries index the table), fix-up and segment reduction with W = 1.
 #pragma once
 #include "msm.cuh"
@@ -25,15 +27,42 @@ namespace msmfb {
 using msm::FbWin;
 using msm::Windows;
 
-constexpr int MIN_PART_BITS = 12;  // buckets per virtual window = 2^12 (16 KB LDS histogram) ...
-constexpr int MAX_PARTS = 256;     // ... unless that needs more than 256 partitions (c = 22: 2^13 buckets each)
-inline u32 part_bits(u32 c) {
-  u32 b = c - 1;                   // bucket-id bits
-  if (b <= MIN_PART_BITS) return b;
-  return b - 8 > MIN_PART_BITS ? b - 8 : MIN_PART_BITS;
+constexpr int MAX_C = 20;          // 2^19 buckets = 256 partitions x 2^11
+constexpr int PART_BITS = 11;      // buckets per virtual window = 2^11
+constexpr int MAX_PARTS = 256;
+inline u32 part_bits(u32 c) { return c - 1 < PART_BITS ? c - 1 : PART_BITS; }
+constexpr int TPB = 256;           // count kernel
+constexpr int SORT_THREADS = 1024; // split / hist / scatter
+constexpr int SPLIT_ENTRIES = 13312;   // entries one split block stages in LDS (13 windows x 1024 scalars)
+constexpr int TILE_EPT = 16;           // scatter: entries per thread -> tiles of <= 16384 entries
+constexpr int MAX_TILE = TILE_EPT * SORT_THREADS;
+// scalars per count/split block for W windows
+inline u32 split_scalars(u32 W) { u32 sc = (SPLIT_ENTRIES / W) & ~63u; return sc > 1024 ? 1024 : sc; }
+inline size_t split_lds_bytes(u32 W) { return (size_t)(2 * MAX_PARTS + 32) * 4 + (size_t)split_scalars(W) * W * 9 + 16; }
+inline size_t scatter_lds_bytes(u32 nb) { return (size_t)(2 * nb + 32) * 4 + (size_t)MAX_TILE * 6; }
+
+// exclusive scan of a[0, n) in LDS for n <= 2 * blockDim.x (blockDim.x a multiple of 64); tmp: 32 words of LDS
+__device__ __forceinline__ void block_excl_scan2(u32* a, u32 n, u32* tmp) {
+  const u32 t = threadIdx.x;
+  const u32 x0 = 2 * t < n ? a[2 * t] : 0, x1 = 2 * t + 1 < n ? a[2 * t + 1] : 0;
+  const u32 sum = x0 + x1;
+  u32 inc = sum;
+  for (int off = 1; off < 64; off <<= 1) { u32 o = __shfl_up(inc, off); if ((t & 63) >= (u32)off) inc += o; }
+  if ((t & 63) == 63) tmp[t >> 6] = inc;
+  __syncthreads();
+  if (t < 64) {
+    const u32 nw = blockDim.x >> 6;
+    const u32 v = t < nw ? tmp[t] : 0;
+    u32 iv = v;
+    for (int off = 1; off < 64; off <<= 1) { u32 o = __shfl_up(iv, off); if (t >= (u32)off) iv += o; }
+    if (t < nw) tmp[t] = iv - v;
+  }
+  __syncthreads();
+  const u32 excl = inc - sum + tmp[t >> 6];
+  if (2 * t < n) a[2 * t] = excl;
+  if (2 * t + 1 < n) a[2 * t + 1] = excl + x0;
+  __syncthreads();
 }
-constexpr int TPB = 256;
-constexpr int SPT = 4;            // scalars per thread in count/split (1024 per block)
 
 struct FbJobs {
   const Fr* scalars[msm::MAX_JOBS];
@@ -65,7 +94,7 @@ __global__ __launch_bounds__(128) void table_level_kernel(const G1Affine* __rest
 
 // ---- partition pass ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void count_kernel(FbJobs jobs, u32* __restrict__ pc, u32 W, Windows win, int is_mont, u32 nparts,
-                                                    u32 pshift) {
+                                                    u32 pshift, u32 S) {
   __shared__ u32 cnt[MAX_PARTS];
   const u32 job = blockIdx.y, blk = blockIdx.x;
   if (blk >= jobs.nblk[job]) return;
@@ -73,8 +102,8 @@ __global__ __launch_bounds__(TPB) void count_kernel(FbJobs jobs, u32* __restrict
   if (threadIdx.x < MAX_PARTS) cnt[threadIdx.x] = 0;
   __syncthreads();
   const u64 n = jobs.n[job];
-  for (int k = 0; k < SPT; k++) {
-    u64 i = (u64)blk * (TPB * SPT) + k * TPB + threadIdx.x;
+  for (u32 k = threadIdx.x; k < S; k += TPB) {
+    u64 i = (u64)blk * S + k;
     if (i < n) {
       Fr s = ff_load(jobs.scalars[job] + i);
       if (is_mont) s = ff_from_mont(s);
@@ -128,34 +157,60 @@ __global__ __launch_bounds__(MAX_PARTS) void pstart_kernel(const u32* __restrict
   if (v < nparts) pstart[job * nparts + v] = sh[v] - mine;
 }
 
-__global__ __launch_bounds__(TPB) void split_kernel(FbJobs jobs, const u32* __restrict__ pc, const u32* __restrict__ pstart,
-                                                    u32* __restrict__ key, u32* __restrict__ val, u32 W, Windows win, int is_mont,
-                                                    u32 nparts, u32 pshift, u32 tab_n) {
-  __shared__ u32 pos[MAX_PARTS];
-  const u32 job = blockIdx.y, blk = blockIdx.x;
+// One block = S scalars (the same S as count_kernel): digits -> LDS counters -> local offsets -> entries placed in
+// LDS grouped by partition -> copied out, consecutive lanes to consecutive addresses of each partition's run.
+__global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const u32* __restrict__ pc, const u32* __restrict__ pstart,
+                                                             u32* __restrict__ key, u32* __restrict__ val, u32 W, Windows win,
+                                                             int is_mont, u32 nparts, u32 pshift, u32 tab_n, u32 S) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  u32* cur = lds;                                  // [MAX_PARTS] counts -> local starts -> cursors
+  u32* gdst = lds + MAX_PARTS;                     // [MAX_PARTS] global position of local entry 0 of each partition
+  u32* tmp = lds + 2 * MAX_PARTS;                  // [32]
+  u32* skey = lds + 2 * MAX_PARTS + 32;            // [S * W]
+  u32* sval = skey + S * W;
+  unsigned char* spart = (unsigned char*)(sval + S * W);
+  const u32 job = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   if (blk >= jobs.nblk[job]) return;
-  if (threadIdx.x < nparts)
-    pos[threadIdx.x] = pstart[job * nparts + threadIdx.x] + pc[jobs.pc_off[job] + (u64)threadIdx.x * jobs.nblk[job] + blk];
+  if (t < MAX_PARTS) cur[t] = 0;
   __syncthreads();
   const u64 n = jobs.n[job];
+  const u64 i = (u64)blk * S + t;
+  const bool live = t < S && i < n;
+  Fr s;
+  if (live) {
+    s = ff_load(jobs.scalars[job] + i);
+    if (is_mont) s = ff_from_mont(s);
+    msm::for_each_digit(s, W, win, [&](u32, u32 e) {
+      u32 b = e & 0x7fffffffu;
+      if (b) atomicAdd(&cur[(b - 1) >> pshift], 1u);
+    });
+  }
+  __syncthreads();
+  block_excl_scan2(cur, MAX_PARTS, tmp);
+  if (t < nparts) gdst[t] = pstart[job * nparts + t] + pc[jobs.pc_off[job] + (u64)t * jobs.nblk[job] + blk] - cur[t];
+  __syncthreads();
+  if (live) {
+    const u32 t0 = jobs.tab_off[job] + (u32)i;
+    msm::for_each_digit(s, W, win, [&](u32 w, u32 e) {
+      u32 b = e & 0x7fffffffu;
+      if (b) {
+        b -= 1;
+        const u32 v = b >> pshift;
+        const u32 p = atomicAdd(&cur[v], 1u);
+        skey[p] = ((b & ((1u << pshift) - 1)) + 1) | (e & 0x80000000u);
+        sval[p] = w * tab_n + t0;
+        spart[p] = (unsigned char)v;
+      }
+    });
+  }
+  __syncthreads();
+  const u32 total = cur[MAX_PARTS - 1];             // cursor of the last partition = number of entries of the block
   u32* kj = key + jobs.ent_off[job];
   u32* vj = val + jobs.ent_off[job];
-  for (int k = 0; k < SPT; k++) {
-    u64 i = (u64)blk * (TPB * SPT) + k * TPB + threadIdx.x;
-    if (i < n) {
-      Fr s = ff_load(jobs.scalars[job] + i);
-      if (is_mont) s = ff_from_mont(s);
-      const u32 t0 = jobs.tab_off[job] + (u32)i;
-      msm::for_each_digit(s, W, win, [&](u32 w, u32 e) {
-        u32 b = e & 0x7fffffffu;
-        if (b) {
-          b -= 1;
-          u32 p = atomicAdd(&pos[b >> pshift], 1u);
-          kj[p] = ((b & ((1u << pshift) - 1)) + 1) | (e & 0x80000000u);
-          vj[p] = w * tab_n + t0;
-        }
-      });
-    }
+  for (u32 idx = t; idx < total; idx += SORT_THREADS) {
+    const u32 d = gdst[spart[idx]] + idx;
+    kj[d] = skey[idx];
+    vj[d] = sval[idx];
   }
 }
 
@@ -165,7 +220,7 @@ __global__ __launch_bounds__(TPB) void split_kernel(FbJobs jobs, const u32* __re
 // partial lines of one window's bucket lists meet in that XCD's L2.  gw = ~0 marks padding.
 struct FbBlk { u32 gw, tile; };
 
-__global__ __launch_bounds__(msm::HIST_THREADS) void hist_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk,
+__global__ __launch_bounds__(SORT_THREADS) void hist_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk,
                                                                  const u32* __restrict__ key, u32* __restrict__ bh, u32 nb, u32 tile) {
   extern __shared__ __attribute__((aligned(16))) u32 h[];
   const u32 gw = blk[blockIdx.x].gw, tb = blk[blockIdx.x].tile;
@@ -198,28 +253,59 @@ __global__ __launch_bounds__(256) void colscan_kernel(const FbWin* __restrict__ 
   tot[(u64)gw * nb + b] = run;
 }
 
-__global__ __launch_bounds__(msm::HIST_THREADS) void scatter_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk,
-                                                                    const u32* __restrict__ key, const u32* __restrict__ val,
-                                                                    const u32* __restrict__ bh, const u32* __restrict__ base,
-                                                                    u32* __restrict__ sorted, u32 nb, u32 tile) {
-  extern __shared__ __attribute__((aligned(16))) u32 h[];
-  const u32 gw = blk[blockIdx.x].gw, tb = blk[blockIdx.x].tile;
+// One block = one tile of <= MAX_TILE entries of one virtual window: local ranks by LDS atomics, local bucket starts by
+// a scan, entries placed in LDS in bucket order, then copied out (global position = where the tile's share of the
+// bucket starts + offset inside the tile's share).
+__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk,
+                                                               const u32* __restrict__ key, const u32* __restrict__ val,
+                                                               const u32* __restrict__ bh, const u32* __restrict__ base,
+                                                               u32* __restrict__ sorted, u32 nb, u32 tile) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  u32* lcnt = lds;                                 // [nb] counts -> local starts
+  u32* gdst = lds + nb;                            // [nb]
+  u32* tmp = lds + 2 * nb;                         // [32]
+  u32* stage = lds + 2 * nb + 32;                  // [MAX_TILE]
+  unsigned short* sbkt = (unsigned short*)(stage + MAX_TILE);
+  const u32 gw = blk[blockIdx.x].gw, tb = blk[blockIdx.x].tile, t = threadIdx.x;
   if (gw == 0xffffffffu) return;
   const FbWin d = fbw[gw];
-  const u32* pre = bh + d.bh_off + (u64)tb * nb;
-  const u32* bs = base + (u64)gw * nb;
-  for (u32 b = threadIdx.x; b < nb; b += blockDim.x) h[b] = bs[b] + pre[b];
+  for (u32 b = t; b < nb; b += SORT_THREADS) lcnt[b] = 0;
   __syncthreads();
   const u32 lo = tb * tile;
-  u32 hi = lo + tile; if (hi > d.cnt) hi = d.cnt;
-  const u32* k = key + d.off;
-  const u32* v = val + d.off;
-  u32* out = sorted + d.off;
-  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    u32 e = k[i];
-    u32 pos = atomicAdd(&h[(e & 0x7fffffffu) - 1], 1u);
-    out[pos] = v[i] | (e & 0x80000000u);
+  const u32 cnt = d.cnt - lo < tile ? d.cnt - lo : tile;
+  const u32* k = key + d.off + lo;
+  const u32* v = val + d.off + lo;
+  u32 rk[TILE_EPT], ev[TILE_EPT], bk[TILE_EPT];
+#pragma unroll
+  for (int j = 0; j < TILE_EPT; j++) {
+    const u32 i = j * SORT_THREADS + t;
+    if (i < cnt) {
+      const u32 e = k[i];
+      bk[j] = (e & 0x7fffffffu) - 1;
+      ev[j] = v[i] | (e & 0x80000000u);
+      rk[j] = atomicAdd(&lcnt[bk[j]], 1u);
+    }
   }
+  __syncthreads();
+  block_excl_scan2(lcnt, nb, tmp);
+  {
+    const u32* pre = bh + d.bh_off + (u64)tb * nb;
+    const u32* bs = base + (u64)gw * nb;
+    for (u32 b = t; b < nb; b += SORT_THREADS) gdst[b] = bs[b] + pre[b] - lcnt[b];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TILE_EPT; j++) {
+    const u32 i = j * SORT_THREADS + t;
+    if (i < cnt) {
+      const u32 idx = lcnt[bk[j]] + rk[j];
+      stage[idx] = ev[j];
+      sbkt[idx] = (unsigned short)bk[j];
+    }
+  }
+  __syncthreads();
+  u32* out = sorted + d.off;
+  for (u32 idx = t; idx < cnt; idx += SORT_THREADS) out[gdst[sbkt[idx]] + idx] = stage[idx];
 }
 
 }  // namespace msmfb
