@@ -270,7 +270,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   if (tile > F::MAX_TILE) tile = F::MAX_TILE;
   const u64 max_tiles_total = ent / tile + WT + 1;
   MH_TRY(c.msm_dig.ensure(ent * 4)); MH_TRY(c.fb_val.ensure(ent * 4)); MH_TRY(c.msm_sorted.ensure(ent * 4));
-  MH_TRY(c.fb_pc.ensure(pco * 4)); MH_TRY(c.fb_ptot.ensure((size_t)WT * 8)); MH_TRY(c.fb_desc.ensure((size_t)WT * sizeof(msm::FbWin)));
+  MH_TRY(c.fb_pc.ensure(pco * 4)); MH_TRY(c.fb_ptot.ensure((size_t)WT * 8)); MH_TRY(c.fb_desc.ensure((size_t)WT * sizeof(msmfb::FbWin)));
   MH_TRY(c.fb_blk.ensure(8 * max_tiles_total * sizeof(F::FbBlk)));
   MH_TRY(c.msm_bh.ensure(max_tiles_total * nb * 4));
   MH_TRY(c.msm_tot.ensure(WB * 4)); MH_TRY(c.msm_base.ensure(WB * 4)); MH_TRY(c.msm_pend.ensure(WB * 4));
@@ -280,7 +280,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   MH_TRY(c.msm_seg.ensure((size_t)nj * (nseg + chunks) * sizeof(G1Xyzz)));
   MH_TRY(c.msm_win.ensure((size_t)nj * sizeof(G1Xyzz)));
   MH_TRY(c.tr_sums.ensure(64));
-  std::vector<msm::FbWin> desc(WT);
+  std::vector<msmfb::FbWin> desc(WT);
   std::vector<F::FbBlk> blk;
   std::vector<u32> ptot(WT);
   {
@@ -300,7 +300,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
       u64 off = jobs.ent_off[k];
       for (u32 v = 0; v < nparts; v++) {
         const u32 gw = k * nparts + v;
-        msm::FbWin& d = desc[gw];
+        msmfb::FbWin& d = desc[gw];
         d.off = off; d.cnt = ptot[gw]; d.ntiles = (u32)((d.cnt + tile - 1) / tile); d.bh_off = bho;
         off += d.cnt; bho += (u64)d.ntiles * nb; xcd_tiles[gw & 7] += d.ntiles;
       }
@@ -313,9 +313,9 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
       for (u32 gw = x; gw < WT; gw += 8)
         for (u32 t = 0; t < desc[gw].ntiles; t++) blk[(k++ << 3) | x] = F::FbBlk{gw, t};
     }
-    MH_HIP(hipMemcpyAsync(c.fb_desc.ptr, desc.data(), (size_t)WT * sizeof(msm::FbWin), hipMemcpyHostToDevice, s));
+    MH_HIP(hipMemcpyAsync(c.fb_desc.ptr, desc.data(), (size_t)WT * sizeof(msmfb::FbWin), hipMemcpyHostToDevice, s));
     if (grid_tiles) MH_HIP(hipMemcpyAsync(c.fb_blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
-    const msm::FbWin* fbw = (const msm::FbWin*)c.fb_desc.ptr;
+    const msmfb::FbWin* fbw = (const msmfb::FbWin*)c.fb_desc.ptr;
     const F::FbBlk* dblk = (const F::FbBlk*)c.fb_blk.ptr;
     const size_t lds = (size_t)nb * 4;
     if (grid_tiles) {
@@ -335,18 +335,16 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     MH_HIP(hipStreamSynchronize(s));
     const u64 avg = ent / WB + 1;
     if (mx > 4096 && (u64)mx > 32 * avg) { skewed = true; return MH_OK; }
-    msm::Jobs none;
-    memset(&none, 0, sizeof(none));
     {
       ProfScope pa(c, PF_MSM_ACCUM);
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
-      hipLaunchKernelGGL(msm::accum_kernel<true>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, none, fbw, (const G1Affine*)bs.d_table,
+      hipLaunchKernelGGL(F::accum30_kernel, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                          (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (G1Xyzz*)c.msm_buckets.ptr,
-                         (u32*)c.msm_pend.ptr, nb, 1u, (u64)WB);
+                         (u32*)c.msm_pend.ptr, nb, (u64)WB);
     }
-    hipLaunchKernelGGL(msm::fixup_kernel<true>, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, none, fbw, (const G1Affine*)bs.d_table,
+    hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                        (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr, (G1Xyzz*)c.msm_buckets.ptr,
-                       nb, 1u, (u64)WB);
+                       nb, (u64)WB);
     // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
     hipLaunchKernelGGL(msm::reduce1_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const G1Xyzz*)c.msm_buckets.ptr,
                        (G1Xyzz*)c.msm_seg.ptr, nbt, nseg, (u32)nj);
@@ -372,37 +370,65 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
 }
 
 // Build the window table of a base set: level j = 2^{start_j} * P (c-bit windows tiling 256 bits), affine.
+// Automatic window width: bucket load ~ W * n / 2^(c-1) stays near 100 for MSMs as long as the base set and ~25 for
+// the quarter-length ones that dominate a Marlin proof.  With point-sharding over `world` GPUs every rank multiplies
+// 1/world of each MSM, so the width follows n / world (the bucket reduction does not shrink with the shard).
+static uint32_t g_fb_world = 1;
+static uint32_t auto_window_bits(size_t n) {
+  static const int env_c = [] { const char* e = getenv("MH_FB_C"); return e ? atoi(e) : 0; }();
+  if (env_c) return (uint32_t)env_c;
+  size_t eff = n / g_fb_world;
+  u32 lg = 0;
+  while ((1ull << lg) < eff) lg++;
+  int cc = (int)lg - 2;
+  if (cc == 17) cc = 16;               // 17 tiles 256 bits with 16 windows of 16 bits: same digits as 16, twice the buckets
+  return (uint32_t)(cc > msmfb::MAX_C ? msmfb::MAX_C : (cc < 8 ? 8 : cc));
+}
+
 int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   if (bs.d_table) { (void)hipFree(bs.d_table); bs.d_table = nullptr; bs.tab_c = bs.tab_W = 0; }
   if (bs.n == 0) return MH_OK;
-  if (cbits == 0) {
-    static const int env_c = [] { const char* e = getenv("MH_FB_C"); return e ? atoi(e) : 0; }();
-    if (env_c) cbits = (uint32_t)env_c;
-    else {
-      u32 lg = 0;
-      while ((1ull << lg) < bs.n) lg++;
-      int cc = (int)lg - 2;
-      cbits = (uint32_t)(cc > 20 ? 20 : (cc < 8 ? 8 : cc));
-    }
-  }
+  bs.tab_auto = cbits == 0;
+  if (cbits == 0) cbits = auto_window_bits(bs.n);
   if (cbits < 4 || cbits > (uint32_t)msmfb::MAX_C) return fail(MH_EINVAL, "mh_bases_precompute: window width must be in [4, 20]");
   msm::Windows win;
   const u32 W = msm::make_windows(cbits, win);
   if ((u64)W * bs.n >= (1ull << 31)) return fail(MH_EINVAL, "mh_bases_precompute: table too large for 31-bit entry indices");
   void* tab = nullptr;
-  hipError_t e = hipMalloc(&tab, (size_t)W * bs.n * PT_B);
+  const size_t pt30 = sizeof(msmfb::G1Aff30);
+  hipError_t e = hipMalloc(&tab, (size_t)W * bs.n * pt30);
   if (e != hipSuccess) return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the window table failed");
+  // two standard-form levels ping-pong through scratch while the chain of doublings runs
+  void* tmp = nullptr;
+  e = hipMalloc(&tmp, 2 * bs.n * PT_B);
+  if (e != hipSuccess) { (void)hipFree(tab); return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the doubling scratch failed"); }
   hipStream_t s = c.stream;
-  MH_HIP(hipMemcpyAsync(tab, bs.d_points, bs.n * PT_B, hipMemcpyDeviceToDevice, s));
-  for (u32 j = 1; j < W; j++)
-    hipLaunchKernelGGL(msmfb::table_level_kernel, dim3((unsigned)((bs.n + 127) / 128)), dim3(128), 0, s,
-                       (const G1Affine*)((const char*)tab + (size_t)(j - 1) * bs.n * PT_B), (G1Affine*)((char*)tab + (size_t)j * bs.n * PT_B),
-                       (u64)bs.n, (u32)win.bits[j - 1]);
-  MH_HIP(hipGetLastError());
-  MH_HIP(hipStreamSynchronize(s));
+  const unsigned grid = (unsigned)((bs.n + 127) / 128);
+  const G1Affine* prev = (const G1Affine*)bs.d_points;
+  for (u32 j = 0; j < W; j++) {
+    G1Affine* next_std = (G1Affine*)((char*)tmp + (size_t)(j & 1) * bs.n * PT_B);
+    hipLaunchKernelGGL(msmfb::table_level_kernel, dim3(grid), dim3(128), 0, s, prev, next_std,
+                       (msmfb::G1Aff30*)((char*)tab + (size_t)j * bs.n * pt30), (u64)bs.n, j ? (u32)win.bits[j - 1] : 0u);
+    if (j) prev = next_std;
+  }
+  hipError_t le = hipGetLastError();
+  hipError_t se = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  if (le != hipSuccess || se != hipSuccess) { (void)hipFree(tab); return fail(MH_EHIP, "mh_bases_precompute: table kernels failed"); }
   bs.d_table = tab; bs.tab_c = cbits; bs.tab_W = W;
   return MH_OK;
 }
+
+// sharded proving changed the number of ranks: rebuild the automatically sized tables for the new shard length
+int fb_set_world(Context& c, uint32_t world) {
+  g_fb_world = world < 1 ? 1 : world;
+  for (auto& kv : c.bases) {
+    BaseSet& bs = kv.second;
+    if (bs.d_table && bs.tab_auto && auto_window_bits(bs.n) != bs.tab_c) MH_TRY(bases_precompute(c, bs, 0));
+  }
+  return MH_OK;
+}
+
 
 // A batch of independent MSMs through one launch sequence.  d_bases[j]: G1Affine[n_j]; d_scalars[j]: Fr[n_j];
 // out_xyz: njobs x 18 limbs (Jacobian).  Jobs with n_j == 0 yield the identity.
@@ -509,13 +535,11 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
           // (forcing 2 resident blocks per CU to make the block count an integral number of rounds was measured
           //  and is not faster than letting 3 reside: 15.3 vs 14.6 ms at 2^22)
           const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
-          hipLaunchKernelGGL(msm::accum_kernel<false>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, jobs, (const msm::FbWin*)nullptr,
-                             (const G1Affine*)nullptr, (u32*)c.msm_sorted.ptr,
+          hipLaunchKernelGGL(msm::accum_kernel, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, jobs, (u32*)c.msm_sorted.ptr,
                              (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (G1Xyzz*)c.msm_buckets.ptr,
                              (u32*)c.msm_pend.ptr, p.nb, p.W, (u64)WB);
         }
-        hipLaunchKernelGGL(msm::fixup_kernel<false>, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, jobs, (const msm::FbWin*)nullptr,
-                           (const G1Affine*)nullptr, (const u32*)c.msm_sorted.ptr,
+        hipLaunchKernelGGL(msm::fixup_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, jobs, (const u32*)c.msm_sorted.ptr,
                            (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr, (G1Xyzz*)c.msm_buckets.ptr, p.nb, p.W, (u64)WB);
       } else {
         ProfScope pa(c, PF_MSM_ACCUM);

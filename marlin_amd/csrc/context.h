@@ -60,6 +60,7 @@ struct BaseSet {
   // fixed-base window table (mh_bases_precompute): G1Affine[tab_W][n], level j = 2^{start_j} * points; level 0 is a copy
   void* d_table = nullptr;
   uint32_t tab_c = 0, tab_W = 0;
+  bool tab_auto = false;     // width chosen by the library (re-chosen when the shard count changes)
 };
 
 enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_COUNT = 4 };

@@ -12,6 +12,8 @@ int msm_batch_device(Context& c, int njobs, const void* const* d_bases, const vo
                      uint64_t* out_xyz);
 // fixed-base window table for a base set (msm_fb.cuh); window_bits = 0 picks a width from the set's size
 int bases_precompute(Context& c, BaseSet& bs, uint32_t window_bits);
+// multi-GPU point sharding over `world` ranks: re-size the automatically sized window tables
+int fb_set_world(Context& c, uint32_t world);
 // twiddle table (tw[2^(l-1) + e] = omega_{2^l}^e) covering at least log_n levels
 int ensure_twiddles_public(Context& c, uint32_t log_n);
 }  // namespace mh

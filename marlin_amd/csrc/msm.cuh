@@ -275,18 +275,9 @@ __global__ __launch_bounds__(HIST_THREADS) void scatter_kernel(Jobs jobs, const 
 // (A persistent variant that handed buckets to lanes dynamically was slower: lanes refilling a bucket stall the
 // lanes that are adding, through the dependent loads of the refill path.)
 constexpr int ACC_TPB = 256;
-// Virtual window of the fixed-base path (msm_fb.cuh): a variable-length run of the entry arrays
-struct FbWin { u64 off; u64 bh_off; u32 cnt; u32 ntiles; };
-// FB = false: bucket gid = (job * W + w) * nb + b, list inside the job's window region, bases per job;
-// FB = true : gid = gw * nb + b with gw a virtual window described by fbw[gw]; entries index the precomputed table
-template <bool FB>
-__global__ __launch_bounds__(ACC_TPB) void accum_kernel(Jobs jobs, const FbWin* __restrict__ fbw, const G1Affine* __restrict__ table,
-                                                        u32* __restrict__ sorted_all,
-                                                        const u32* __restrict__ base, const u32* __restrict__ tot,
-                                                        G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u32 nb, u32 W,
-                                                        u64 WB) {
-  __shared__ u32 keys[ACC_TPB];
-  const u64 lo = (u64)blockIdx.x * ACC_TPB;
+// thread -> bucket of the block's ACC_TPB consecutive buckets [lo, lo + ACC_TPB), largest bucket first (see above);
+// keys: ACC_TPB words of LDS
+__device__ __forceinline__ u64 balanced_bucket(u32* keys, const u32* __restrict__ tot, u64 lo, u64 WB) {
   {
     u64 g = lo + threadIdx.x;
     u32 c = g < WB ? tot[g] : 0;
@@ -306,19 +297,20 @@ __global__ __launch_bounds__(ACC_TPB) void accum_kernel(Jobs jobs, const FbWin* 
       __syncthreads();
     }
   }
-  const u64 gid = lo + (keys[threadIdx.x] & 255u);
+  return lo + (keys[threadIdx.x] & 255u);
+}
+
+__global__ __launch_bounds__(ACC_TPB) void accum_kernel(Jobs jobs, u32* __restrict__ sorted_all,
+                                                        const u32* __restrict__ base, const u32* __restrict__ tot,
+                                                        G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u32 nb, u32 W,
+                                                        u64 WB) {
+  __shared__ u32 keys[ACC_TPB];
+  const u64 gid = balanced_bucket(keys, tot, (u64)blockIdx.x * ACC_TPB, WB);
   if (gid >= WB) return;
-  const G1Affine* __restrict__ bases;
-  u32* lst;
-  if (FB) {
-    bases = table;
-    lst = sorted_all + fbw[gid / nb].off + base[gid];
-  } else {
-    const u32 job = (u32)(gid / ((u64)W * nb));
-    const u32 w = (u32)((gid / nb) % W);
-    bases = jobs.bases[job];
-    lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
-  }
+  const u32 job = (u32)(gid / ((u64)W * nb));
+  const u32 w = (u32)((gid / nb) % W);
+  const G1Affine* __restrict__ bases = jobs.bases[job];
+  u32* lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
   const u32 cnt = tot[gid];
   if (cnt == 0) { g1_store_xyzz(buckets + gid, G1Xyzz::identity()); pend[gid] = 0; return; }
   G1Xyzz acc;
@@ -351,26 +343,17 @@ __global__ __launch_bounds__(ACC_TPB) void accum_kernel(Jobs jobs, const FbWin* 
 }
 
 // deferred entries (see accum_kernel): full group law, one thread per bucket that has any
-template <bool FB>
-__global__ __launch_bounds__(64) void fixup_kernel(Jobs jobs, const FbWin* __restrict__ fbw, const G1Affine* __restrict__ table,
-                                                   const u32* __restrict__ sorted_all,
+__global__ __launch_bounds__(64) void fixup_kernel(Jobs jobs, const u32* __restrict__ sorted_all,
                                                    const u32* __restrict__ base, const u32* __restrict__ pend,
                                                    G1Xyzz* __restrict__ buckets, u32 nb, u32 W, u64 WB) {
   u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= WB) return;
   const u32 np = pend[gid];
   if (np == 0) return;
-  const G1Affine* __restrict__ bases;
-  const u32* lst;
-  if (FB) {
-    bases = table;
-    lst = sorted_all + fbw[gid / nb].off + base[gid];
-  } else {
-    const u32 job = (u32)(gid / ((u64)W * nb));
-    const u32 w = (u32)((gid / nb) % W);
-    bases = jobs.bases[job];
-    lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
-  }
+  const u32 job = (u32)(gid / ((u64)W * nb));
+  const u32 w = (u32)((gid / nb) % W);
+  const G1Affine* __restrict__ bases = jobs.bases[job];
+  const u32* lst = sorted_all + jobs.ent_off[job] + (u64)w * jobs.n[job] + base[gid];
   G1Xyzz acc = g1_load_xyzz(buckets + gid);
   for (u32 k = 0; k < np; k++) {
     u32 e = lst[k];

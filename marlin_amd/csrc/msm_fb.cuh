@@ -22,10 +22,40 @@
 // followed by msm.cuh's accumulate (entries index the table), fix-up and segment reduction with W = 1.
 #pragma once
 #include "msm.cuh"
+#include "fq30.cuh"
 
 namespace msmfb {
-using msm::FbWin;
 using msm::Windows;
+
+// Virtual window: a variable-length run of the entry arrays holding the entries of 2^PART_BITS consecutive buckets
+struct FbWin { u64 off; u64 bh_off; u32 cnt; u32 ntiles; };
+
+// Table point: affine, coordinates as 30-bit-limb Montgomery residues (fq30.cuh), each coordinate padded to a
+// multiple of four words (BLS12-381: 2 x 64 B, one cache line per coordinate)
+constexpr int LIMB_SLOTS = (Fq30::NL + 3) & ~3;
+struct G1Aff30 { u32 x[LIMB_SLOTS]; u32 y[LIMB_SLOTS]; };
+
+__device__ __forceinline__ Fq30 load30(const u32* __restrict__ p) {
+  u32 w[LIMB_SLOTS];
+#pragma unroll
+  for (int i = 0; i < LIMB_SLOTS; i += 4) {
+    uint4 q = *reinterpret_cast<const uint4*>(p + i);
+    w[i] = q.x; w[i + 1] = q.y; w[i + 2] = q.z; w[i + 3] = q.w;
+  }
+  Fq30 r;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) r.v[i] = w[i];
+  return r;
+}
+__device__ __forceinline__ void store30(u32* p, const Fq30& a) {
+#pragma unroll
+  for (int i = 0; i < LIMB_SLOTS; i += 4) {
+    uint4 q;
+    q.x = i < Fq30::NL ? a.v[i] : 0; q.y = i + 1 < Fq30::NL ? a.v[i + 1] : 0;
+    q.z = i + 2 < Fq30::NL ? a.v[i + 2] : 0; q.w = i + 3 < Fq30::NL ? a.v[i + 3] : 0;
+    *reinterpret_cast<uint4*>(p + i) = q;
+  }
+}
 
 constexpr int MAX_C = 20;          // 2^19 buckets = 256 partitions x 2^11
 constexpr int PART_BITS = 11;      // buckets per virtual window = 2^11
@@ -74,22 +104,29 @@ struct FbJobs {
   u32 njobs;
 };
 
-// ---- table: level j from level j-1 by `bits` doublings, back to affine ---------------------------------
-__global__ __launch_bounds__(128) void table_level_kernel(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next, u64 n, u32 bits) {
+// ---- table -----------------------------------------------------------------------------------------------
+// level j from level j-1 by `bits` doublings (bits = 0: level 0, the points themselves); the standard-form
+// result feeds the next level, the 30-bit-limb form is what the accumulation reads
+__global__ __launch_bounds__(128) void table_level_kernel(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next_std,
+                                                          G1Aff30* __restrict__ next30, u64 n, u32 bits) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1Affine p = g1_load_affine(prev + i);
-  G1Xyzz a;
-  g1_dbl_affine(a, p.x, p.y);
-  for (u32 k = 1; k < bits; k++) g1_dbl(a);
-  // x = X / ZZ, y = Y / ZZZ with ZZ^3 = ZZZ^2: 1/ZZ = ZZ^2 / ZZZ^2
-  Fq iz = ff_inv(a.zzz);
-  Fq izz = ff_mul(ff_sqr(a.zz), ff_sqr(iz));
-  G1Affine r;
-  r.x = ff_mul(a.x, izz);
-  r.y = ff_mul(a.y, iz);
-  ff_store(&next[i].x, r.x);
-  ff_store(&next[i].y, r.y);
+  G1Affine r = p;
+  if (bits) {
+    G1Xyzz a;
+    g1_dbl_affine(a, p.x, p.y);
+    for (u32 k = 1; k < bits; k++) g1_dbl(a);
+    // x = X / ZZ, y = Y / ZZZ with ZZ^3 = ZZZ^2: 1/ZZ = ZZ^2 / ZZZ^2
+    Fq iz = ff_inv(a.zzz);
+    Fq izz = ff_mul(ff_sqr(a.zz), ff_sqr(iz));
+    r.x = ff_mul(a.x, izz);
+    r.y = ff_mul(a.y, iz);
+    ff_store(&next_std[i].x, r.x);
+    ff_store(&next_std[i].y, r.y);
+  }
+  store30(next30[i].x, f30_from_fq(r.x));
+  store30(next30[i].y, f30_from_fq(r.y));
 }
 
 // ---- partition pass ------------------------------------------------------------------------------------
@@ -306,6 +343,80 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __re
   __syncthreads();
   u32* out = sorted + d.off;
   for (u32 idx = t; idx < cnt; idx += SORT_THREADS) out[gdst[sbkt[idx]] + idx] = stage[idx];
+}
+
+// ---- accumulate: thread per bucket, XYZZ += table point, all in 30-bit limbs -----------------------------------
+// Same structure as msm::accum_kernel (first entry seeds the accumulator, collisions are deferred to the fix-up,
+// bucket sizes are sorted inside the block), with the lazily reduced arithmetic of fq30.cuh.  Value bounds in units of
+// p (a product of u and v is below 1 + u v / 630): table x < 1, +-y <= 2, zz, zzz <= 1.1; X1 <= 6.2, Y1 <= 3.2 are
+// loop invariants: P = U2 - X1 + 8p <= 9.1, R = S2 - Y1 + 4p <= 5.1, PP, PPP, Q, R^2 <= 1.2,
+// X3 = R^2 - PPP + 2p - 2Q + 3p <= 6.2, Y3 = R (Q - X3 + 8p) - Y1 PPP + 2p <= 3.2.
+__global__ __launch_bounds__(msm::ACC_TPB) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
+                                                               u32* __restrict__ sorted_all, const u32* __restrict__ base,
+                                                               const u32* __restrict__ tot, G1Xyzz* __restrict__ buckets,
+                                                               u32* __restrict__ pend, u32 nb, u64 WB) {
+  __shared__ u32 keys[msm::ACC_TPB];
+  const u64 gid = msm::balanced_bucket(keys, tot, (u64)blockIdx.x * msm::ACC_TPB, WB);
+  if (gid >= WB) return;
+  u32* lst = sorted_all + fbw[gid / nb].off + base[gid];
+  const u32 cnt = tot[gid];
+  if (cnt == 0) { g1_store_xyzz(buckets + gid, G1Xyzz::identity()); pend[gid] = 0; return; }
+  Fq30 zero;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) zero.v[i] = 0;
+  Fq30 X1, Y1, ZZ, ZZZ;
+  {
+    const u32 e = lst[0];
+    const G1Aff30* q = table + (e & 0x7fffffffu);
+    X1 = load30(q->x);
+    Y1 = load30(q->y);
+    if (e & 0x80000000u) Y1 = f30_sub<2>(zero, Y1);
+#pragma unroll
+    for (int i = 0; i < Fq30::NL; i++) { ZZ.v[i] = Fq30Params::ONE[i]; ZZZ.v[i] = Fq30Params::ONE[i]; }
+  }
+  u32 np = 0;
+  for (u32 k = 1; k < cnt; k++) {
+    const u32 e = lst[k];
+    const G1Aff30* q = table + (e & 0x7fffffffu);
+    const Fq30 x2 = load30(q->x);
+    Fq30 y2 = load30(q->y);
+    if (e & 0x80000000u) y2 = f30_sub<2>(zero, y2);
+    const Fq30 P = f30_sub<8>(f30_mul(x2, ZZ), X1);
+    if (__builtin_expect(f30_maybe_zero(P), 0)) { lst[np++] = e; continue; }   // np <= k: never overtakes the read cursor
+    const Fq30 R = f30_sub<4>(f30_mul(y2, ZZZ), Y1);
+    Fq30 PP = f30_sqr(P);
+    ZZ = f30_mul(ZZ, PP);
+    const Fq30 Q = f30_mul(X1, PP);
+    PP = f30_mul(P, PP);                 // PPP
+    ZZZ = f30_mul(ZZZ, PP);
+    Y1 = f30_mul(Y1, PP);                // Y1 * PPP
+    X1 = f30_sub<3>(f30_sub<2>(f30_sqr(R), PP), f30_dbl(Q));
+    Y1 = f30_sub<2>(f30_mul(R, f30_sub<8>(Q, X1)), Y1);
+  }
+  G1Xyzz acc;
+  acc.x = f30_to_fq(X1); acc.y = f30_to_fq(Y1); acc.zz = f30_to_fq(ZZ); acc.zzz = f30_to_fq(ZZZ);
+  g1_store_xyzz(buckets + gid, acc);
+  pend[gid] = np;
+}
+
+// deferred entries: complete group law in the standard representation, one thread per bucket that has any
+__global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
+                                                     const u32* __restrict__ sorted_all, const u32* __restrict__ base,
+                                                     const u32* __restrict__ pend, G1Xyzz* __restrict__ buckets, u32 nb, u64 WB) {
+  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= WB) return;
+  const u32 np = pend[gid];
+  if (np == 0) return;
+  const u32* lst = sorted_all + fbw[gid / nb].off + base[gid];
+  G1Xyzz acc = g1_load_xyzz(buckets + gid);
+  for (u32 k = 0; k < np; k++) {
+    const u32 e = lst[k];
+    const G1Aff30* q = table + (e & 0x7fffffffu);
+    Fq x = f30_to_fq(load30(q->x)), y = f30_to_fq(load30(q->y));
+    if (e & 0x80000000u) y = ff_neg(y);
+    g1_madd(acc, x, y);
+  }
+  g1_store_xyzz(buckets + gid, acc);
 }
 
 }  // namespace msmfb

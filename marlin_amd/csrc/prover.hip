@@ -441,7 +441,9 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
   if (world < 1 || rank < 0 || rank >= world) return fail(MH_EINVAL, "mh_marlin_set_shard: bad rank/world");
   if (world > 1 && !allgather) return fail(MH_EINVAL, "mh_marlin_set_shard: all_gather callback required for world > 1");
   g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
-  return MH_OK;
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  return fb_set_world(c, (uint32_t)world);      // no-op without uploaded base sets (and without a device)
 }
 // host-only hook: runs the registered all_gather once (used by the CPU gloo test of the callback plumbing)
 int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv) {

@@ -82,6 +82,43 @@ __global__ void k_ffadd(F* out, const F* in, int iters) {
   for (int it = 0; it < iters; it++) { F z = ff_add(x, y); y = ff_sub(x, z); x = z; }
   ff_store(out + tid, x);
 }
+#include "../marlin_amd/csrc/fq30.cuh"
+__global__ void k_mul30(Fq30* out, const Fq* in, int iters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  Fq30 x = f30_split(ff_load(in + tid)), y = f30_split(ff_load(in + tid + 1));
+  for (int it = 0; it < iters; it++) { Fq30 z = f30_mul(x, y); y = x; x = z; }
+  out[tid] = x;
+}
+__global__ void k_addsub30(Fq30* out, const Fq* in, int iters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  Fq30 x = f30_split(ff_load(in + tid)), y = f30_split(ff_load(in + tid + 1));
+  for (int it = 0; it < iters; it++) { Fq30 z = f30_add(x, y); y = f30_sub<8>(x, z); x = f30_mul(z, y); }
+  out[tid] = x;
+}
+// correctness: (a * b) through both representations must agree
+__global__ void k_check30(u32* bad, const Fq* in, int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  Fq a = ff_load(in + tid), b = ff_load(in + tid + 1);
+  // inputs are arbitrary 380-bit integers: reduce them once so that both are < p
+  a = ff_mul(a, Fq::one()); b = ff_mul(b, Fq::one());
+  Fq want = ff_mul(a, b);
+  Fq30 a30 = f30_from_fq(a), b30 = f30_from_fq(b);
+  Fq30 c30 = f30_mul(a30, b30);
+  // exercise lazy add/sub:  (c + a) - a, and 8p-offset subtraction
+  Fq30 d30 = f30_sub<2>(f30_add(c30, a30), a30);
+  Fq got = f30_to_fq(d30);
+  // also (a - b) * (a + b) == a^2 - b^2
+  Fq30 e30 = f30_mul(f30_sub<2>(a30, b30), f30_add(a30, b30));
+  Fq30 f30v = f30_sub<2>(f30_sqr(a30), f30_sqr(b30));
+  Fq ge = f30_to_fq(e30), gf = f30_to_fq(f30v);
+  Fq z = ff_sub(a, a);
+  bool ok = true;
+  for (int i = 0; i < Fq::N; i++) ok = ok && got.v[i] == want.v[i] && ge.v[i] == gf.v[i];
+  ok = ok && f30_maybe_zero(f30_sub<2>(a30, a30)) && f30_maybe_zero(f30_sub<8>(f30_add(a30, a30), f30_dbl(a30)));
+  (void)z;
+  if (!ok) atomicAdd(bad, 1u);
+}
 __global__ void k_madd(G1Xyzz* out, const Fq* in, int iters) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   G1Xyzz acc; acc.x = ff_load(in + tid); acc.y = ff_load(in + tid + 1); acc.zz = ff_load(in + tid + 2); acc.zzz = ff_load(in + tid + 3);
@@ -135,6 +172,16 @@ int main() {
   printf("Fq mont mul (12 limb): %8.3f ms  %8.2f Gmul/s\n", ms, (double)nthreads * it / ms / 1e6);
   ms = timeit(k_ffadd<Fq>, dim3(blocks), dim3(threads), 3, (Fq*)dout, (const Fq*)din, it);
   printf("Fq add+sub           : %8.3f ms  %8.2f Gpair/s\n", ms, (double)nthreads * it / ms / 1e6);
+  ms = timeit(k_mul30, dim3(blocks), dim3(threads), 3, (Fq30*)dout, (const Fq*)din, it);
+  printf("Fq 13x30-bit lazy mul: %8.3f ms  %8.2f Gmul/s\n", ms, (double)nthreads * it / ms / 1e6);
+  ms = timeit(k_addsub30, dim3(blocks), dim3(threads), 3, (Fq30*)dout, (const Fq*)din, it);
+  printf("Fq30 add+sub+mul     : %8.3f ms  %8.2f Gtriple/s\n", ms, (double)nthreads * it / ms / 1e6);
+  {
+    u32* dbad; CK(hipMalloc(&dbad, 4)); CK(hipMemset(dbad, 0, 4));
+    hipLaunchKernelGGL(k_check30, dim3(blocks), dim3(threads), 0, 0, dbad, (const Fq*)din, nthreads);
+    u32 hb = 1; CK(hipMemcpy(&hb, dbad, 4, hipMemcpyDeviceToHost));
+    printf("Fq30 vs Fq check     : %u mismatches of %d\n", hb, nthreads);
+  }
   it = 64;
   ms = timeit(k_madd, dim3(blocks), dim3(128), 3, (G1Xyzz*)dout, (const Fq*)din, it);
   printf("G1 XYZZ madd         : %8.3f ms  %8.2f Gadd/s\n", ms, (double)blocks * 128 * it / ms / 1e6);
