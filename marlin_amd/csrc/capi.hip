@@ -279,7 +279,8 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   const u32 chunks = nseg >= 4096 ? nseg / 256 : 1;                      // reduce2 in two launches when nseg is large
   MH_TRY(c.msm_seg.ensure((size_t)nj * (nseg + chunks) * sizeof(G1Xyzz)));
   MH_TRY(c.msm_win.ensure((size_t)nj * sizeof(G1Xyzz)));
-  MH_TRY(c.tr_sums.ensure(64));
+  MH_TRY(c.tr_sums.ensure(64 + F::SIZE_BINS * 4));
+  MH_TRY(c.fb_perm.ensure(WB * 4));
   std::vector<msmfb::FbWin> desc(WT);
   std::vector<F::FbBlk> blk;
   std::vector<u32> ptot(WT);
@@ -335,12 +336,19 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     MH_HIP(hipStreamSynchronize(s));
     const u64 avg = ent / WB + 1;
     if (mx > 4096 && (u64)mx > 32 * avg) { skewed = true; return MH_OK; }
+    // buckets ordered by size, largest first
+    u32* d_szh = (u32*)c.tr_sums.ptr + 16;
+    MH_HIP(hipMemsetAsync(d_szh, 0, F::SIZE_BINS * 4, s));
+    hipLaunchKernelGGL(F::size_hist_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u64)WB, d_szh);
+    hipLaunchKernelGGL(F::size_scan_kernel, dim3(1), dim3(1024), 0, s, d_szh);
+    hipLaunchKernelGGL(F::size_perm_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u64)WB, d_szh,
+                       (u32*)c.fb_perm.ptr);
     {
       ProfScope pa(c, PF_MSM_ACCUM);
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
       hipLaunchKernelGGL(F::accum30_kernel, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
-                         (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (G1Xyzz*)c.msm_buckets.ptr,
-                         (u32*)c.msm_pend.ptr, nb, (u64)WB);
+                         (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
+                         (G1Xyzz*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, nb, (u64)WB);
     }
     hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                        (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr, (G1Xyzz*)c.msm_buckets.ptr,
@@ -674,7 +682,7 @@ int mh_shutdown(void) {
   c.tr_sums.release(); c.tr_ob.release(); c.tr_pre.release(); c.tr_prod.release(); c.tr_scr.release();
   for (auto& kv : c.bases) { if (kv.second.d_points) (void)hipFree(kv.second.d_points); if (kv.second.d_table) (void)hipFree(kv.second.d_table); }
   c.bases.clear();
-  c.fb_val.release(); c.fb_pc.release(); c.fb_ptot.release(); c.fb_desc.release(); c.fb_blk.release();
+  c.fb_val.release(); c.fb_pc.release(); c.fb_ptot.release(); c.fb_desc.release(); c.fb_blk.release(); c.fb_perm.release();
   if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }
   for (auto& r : c.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   c.prof.clear();

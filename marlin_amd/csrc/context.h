@@ -84,7 +84,7 @@ struct Context {
   std::map<uint64_t, BaseSet> bases;
   uint64_t next_handle = 1;
   Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win, msm_pend;
-  Scratch fb_val, fb_pc, fb_ptot, fb_desc, fb_blk;   // fixed-base path (msm_fb.cuh)
+  Scratch fb_val, fb_pc, fb_ptot, fb_desc, fb_blk, fb_perm;   // fixed-base path (msm_fb.cuh)
   uint64_t n_fb_groups = 0, n_vb_groups = 0;  // job groups that ran on the fixed-base / variable-base path
   Scratch tr_off[3], tr_cnt[2], tr_p[2], tr_sums, tr_ob, tr_pre, tr_prod, tr_scr;   // pair-tree accumulation
 

@@ -345,19 +345,57 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __re
   for (u32 idx = t; idx < cnt; idx += SORT_THREADS) out[gdst[sbkt[idx]] + idx] = stage[idx];
 }
 
+// ---- bucket order: largest first -------------------------------------------------------------------------------
+// A wave of the accumulate kernel runs as long as its largest bucket.  msm::accum_kernel sorts bucket sizes inside each
+// block of 256; here all buckets of the launch are ordered by size with a counting sort (sizes are small integers), so
+// the 64 lanes of every wave get equal trip counts (to within one), blocks start in longest-first order and the tail
+// of the launch consists of the smallest buckets.
+constexpr int SIZE_BINS = 1024;    // sizes >= 1023 share the last bin
+__global__ __launch_bounds__(1024) void size_hist_kernel(const u32* __restrict__ tot, u64 WB, u32* __restrict__ ghist) {
+  __shared__ u32 lh[SIZE_BINS];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 g = (u64)blockIdx.x * 1024 + threadIdx.x;
+  if (g < WB) { u32 sz = tot[g]; atomicAdd(&lh[sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1], 1u); }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], lh[threadIdx.x]);
+}
+// counts -> first position of each size in descending order
+__global__ __launch_bounds__(1024) void size_scan_kernel(u32* __restrict__ ghist) {
+  __shared__ u32 a[SIZE_BINS];
+  __shared__ u32 tmp[32];
+  a[threadIdx.x] = ghist[SIZE_BINS - 1 - threadIdx.x];
+  __syncthreads();
+  block_excl_scan2(a, SIZE_BINS, tmp);
+  ghist[SIZE_BINS - 1 - threadIdx.x] = a[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__ tot, u64 WB, u32* __restrict__ gcur, u32* __restrict__ perm) {
+  __shared__ u32 lh[SIZE_BINS];
+  __shared__ u32 lbase[SIZE_BINS];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 g = (u64)blockIdx.x * 1024 + threadIdx.x;
+  u32 bin = 0, rank = 0;
+  if (g < WB) { u32 sz = tot[g]; bin = sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1; rank = atomicAdd(&lh[bin], 1u); }
+  __syncthreads();
+  if (lh[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&gcur[threadIdx.x], lh[threadIdx.x]);
+  __syncthreads();
+  if (g < WB) perm[lbase[bin] + rank] = (u32)g;
+}
+
 // ---- accumulate: thread per bucket, XYZZ += table point, all in 30-bit limbs -----------------------------------
-// Same structure as msm::accum_kernel (first entry seeds the accumulator, collisions are deferred to the fix-up,
-// bucket sizes are sorted inside the block), with the lazily reduced arithmetic of fq30.cuh.  Value bounds in units of
+// Same structure as msm::accum_kernel (first entry seeds the accumulator, collisions are deferred to the fix-up), buckets
+// taken in the size order computed above, with the lazily reduced arithmetic of fq30.cuh.  Value bounds in units of
 // p (a product of u and v is below 1 + u v / 630): table x < 1, +-y <= 2, zz, zzz <= 1.1; X1 <= 6.2, Y1 <= 3.2 are
 // loop invariants: P = U2 - X1 + 8p <= 9.1, R = S2 - Y1 + 4p <= 5.1, PP, PPP, Q, R^2 <= 1.2,
 // X3 = R^2 - PPP + 2p - 2Q + 3p <= 6.2, Y3 = R (Q - X3 + 8p) - Y1 PPP + 2p <= 3.2.
 __global__ __launch_bounds__(msm::ACC_TPB) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                                u32* __restrict__ sorted_all, const u32* __restrict__ base,
-                                                               const u32* __restrict__ tot, G1Xyzz* __restrict__ buckets,
-                                                               u32* __restrict__ pend, u32 nb, u64 WB) {
-  __shared__ u32 keys[msm::ACC_TPB];
-  const u64 gid = msm::balanced_bucket(keys, tot, (u64)blockIdx.x * msm::ACC_TPB, WB);
-  if (gid >= WB) return;
+                                                               const u32* __restrict__ tot, const u32* __restrict__ perm,
+                                                               G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u32 nb, u64 WB) {
+  const u64 slot = (u64)blockIdx.x * msm::ACC_TPB + threadIdx.x;
+  if (slot >= WB) return;
+  const u64 gid = perm[slot];
   u32* lst = sorted_all + fbw[gid / nb].off + base[gid];
   const u32 cnt = tot[gid];
   if (cnt == 0) { g1_store_xyzz(buckets + gid, G1Xyzz::identity()); pend[gid] = 0; return; }
