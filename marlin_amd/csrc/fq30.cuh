@@ -29,25 +29,14 @@ struct Fq30 {
 
 constexpr u32 M30 = (1u << 30) - 1;
 
-// a * b / R' mod p, lazily reduced: for a, b < 20 p the result is < 2 p.  Limbs of a and b must be < 2^30.
-__device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
+// Montgomery reduction of a double-length value given as 2 NL normalised 30-bit limbs: t / R' mod p, lazily reduced.
+__device__ __forceinline__ Fq30 f30_redc(const u32* t) {
   constexpr int NL = Fq30::NL;
   using PP = Fq30Params;
-  u32 t[2 * NL];
-  u64 acc = 0;
-  // product columns: at most NL products of < 2^60 each plus a carry < 2^35
-#pragma unroll
-  for (int k = 0; k < 2 * NL - 1; k++) {
-#pragma unroll
-    for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) acc += (u64)a.v[i] * b.v[k - i];
-    t[k] = (u32)acc & M30;
-    acc >>= 30;
-  }
-  t[2 * NL - 1] = (u32)acc;
-  // Montgomery reduction, column by column: m_k clears the low 30 bits of column k
   u32 m[NL];
   Fq30 r;
-  acc = 0;
+  u64 acc = 0;
+  // column by column: m_k clears the low 30 bits of column k
 #pragma unroll
   for (int k = 0; k < NL; k++) {
     acc += t[k];
@@ -67,7 +56,42 @@ __device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
   }
   return r;
 }
-__device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) { return f30_mul(a, a); }
+
+// a * b / R' mod p, lazily reduced: for a, b < 20 p the result is < 2 p.  Limbs of a and b must be < 2^30.
+__device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
+  constexpr int NL = Fq30::NL;
+  u32 t[2 * NL];
+  u64 acc = 0;
+  // product columns: at most NL products of < 2^60 each plus a carry < 2^35
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) acc += (u64)a.v[i] * b.v[k - i];
+    t[k] = (u32)acc & M30;
+    acc >>= 30;
+  }
+  t[2 * NL - 1] = (u32)acc;
+  return f30_redc(t);
+}
+// a^2 / R': the cross products once, against the doubled limbs (2 a_i < 2^31: a column still sums to < 2^64)
+__device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
+  constexpr int NL = Fq30::NL;
+  u32 a2[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;
+  u32 t[2 * NL];
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) acc += (u64)a2[i] * a.v[k - i];
+    if ((k & 1) == 0) acc += (u64)a.v[k >> 1] * a.v[k >> 1];
+    t[k] = (u32)acc & M30;
+    acc >>= 30;
+  }
+  t[2 * NL - 1] = (u32)acc;
+  return f30_redc(t);
+}
 
 // a + b (no reduction)
 __device__ __forceinline__ Fq30 f30_add(const Fq30& a, const Fq30& b) {
@@ -95,6 +119,20 @@ __device__ __forceinline__ Fq30 f30_sub(const Fq30& a, const Fq30& b) {
   return r;
 }
 __device__ __forceinline__ Fq30 f30_dbl(const Fq30& a) { return f30_add(a, a); }
+// a - 2 b + K p in one carry pass; requires 2 b <= K p
+template <int K>
+__device__ __forceinline__ Fq30 f30_sub2(const Fq30& a, const Fq30& b) {
+  using PP = Fq30Params;
+  Fq30 r;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) {
+    const u32 kp = K == 2 ? PP::P2[i] : (K == 3 ? PP::P3[i] : (K == 4 ? PP::P4[i] : PP::P8[i]));
+    int s = (int)(a.v[i] - 2 * b.v[i]) + (int)kp + c;      // in [-2^31, 2^31)
+    if (i < Fq30::NL - 1) { r.v[i] = (u32)s & M30; c = s >> 30; } else r.v[i] = (u32)s;
+  }
+  return r;
+}
 
 // cheap necessary condition for a == 0 mod p (a < 2^9 p): a = j p implies a * p^-1 = j mod 2^30.  False positives
 // (probability ~2^-21) only send an entry through the complete addition law.

@@ -388,8 +388,8 @@ __global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__
 // taken in the size order computed above, with the lazily reduced arithmetic of fq30.cuh.  Value bounds in units of
 // p (a product of u and v is below 1 + u v / 630): table x < 1, +-y <= 2, zz, zzz <= 1.1; X1 <= 6.2, Y1 <= 3.2 are
 // loop invariants: P = U2 - X1 + 8p <= 9.1, R = S2 - Y1 + 4p <= 5.1, PP, PPP, Q, R^2 <= 1.2,
-// X3 = R^2 - PPP + 2p - 2Q + 3p <= 6.2, Y3 = R (Q - X3 + 8p) - Y1 PPP + 2p <= 3.2.
-__global__ __launch_bounds__(msm::ACC_TPB) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
+// X3 = (R^2 - PPP + 2p) - 2Q + 3p <= 6.2, Y3 = R (Q - X3 + 8p) - Y1 PPP + 2p <= 3.2.
+__global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                                u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                                const u32* __restrict__ tot, const u32* __restrict__ perm,
                                                                G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u32 nb, u64 WB) {
@@ -413,8 +413,10 @@ __global__ __launch_bounds__(msm::ACC_TPB) void accum30_kernel(const FbWin* __re
     for (int i = 0; i < Fq30::NL; i++) { ZZ.v[i] = Fq30Params::ONE[i]; ZZZ.v[i] = Fq30Params::ONE[i]; }
   }
   u32 np = 0;
+  u32 e_next = cnt > 1 ? lst[1] : 0;
   for (u32 k = 1; k < cnt; k++) {
-    const u32 e = lst[k];
+    const u32 e = e_next;
+    if (k + 1 < cnt) e_next = lst[k + 1];           // one iteration ahead: takes the list load off the critical path
     const G1Aff30* q = table + (e & 0x7fffffffu);
     const Fq30 x2 = load30(q->x);
     Fq30 y2 = load30(q->y);
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(msm::ACC_TPB) void accum30_kernel(const FbWin* __re
     PP = f30_mul(P, PP);                 // PPP
     ZZZ = f30_mul(ZZZ, PP);
     Y1 = f30_mul(Y1, PP);                // Y1 * PPP
-    X1 = f30_sub<3>(f30_sub<2>(f30_sqr(R), PP), f30_dbl(Q));
+    X1 = f30_sub2<3>(f30_sub<2>(f30_sqr(R), PP), Q);
     Y1 = f30_sub<2>(f30_mul(R, f30_sub<8>(Q, X1)), Y1);
   }
   G1Xyzz acc;
