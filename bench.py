@@ -30,7 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_MAD_PEAK_TOPS = 30.0        # measured v_mad_u64_u32 lane-ops/s (profiles/r01_microbench.txt)
+VALU_ISSUE_PEAK_TOPS = 39.3      # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one VALU lane-op per lane and clock
+# instructions of one bucket addition (XYZZ += affine, 8 M + 2 S on 13 x 30-bit limbs), counted in the ISA of the loop
+# body of msmfb::accum30_kernel (profiles/r01k_accum_loop_isa.txt, tools/loop_isa_stats.py); the variable-base kernel (32-bit limbs) has 7839
+ACCUM_VALU_PER_ADD = {"fixed-base": 5614, "variable-base": 7839}
+ACCUM_MAD_PER_ADD = {"fixed-base": 3224, "variable-base": 2880}
 
 
 def rand_fr_np(rng, n):
@@ -228,24 +232,34 @@ def main():
             traffic = json.load(open(pmc)).get("msm_accum_bytes_per_launch")
         except Exception:
             traffic = None
-    # secondary view: the kernel's real bound is the integer multiplier.  One mixed addition = 10 Fq multiplications
-    # = 2880 v_mad_u64_u32; the window plan issues W additions per input pair.
-    W_windows = 16
+    # secondary view: the kernel's real bound is VALU issue.  The window plan issues W bucket additions per input pair
+    # (W = 13 with the fixed-base table at c = 20, 16 on the variable-base path at c = 16).
+    tab_c, tab_w = (0, 0)
+    if hasattr(wl, "srs"):
+        tab_c, tab_w, _ = wl.srs.powers_of_g.table_info()
+    path = "fixed-base" if tab_w else "variable-base"
+    W_windows = tab_w or 16
     madds_per_s = (msm_pairs_rank * W_windows * args.steps) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
-    valu = {"bound": "valu-int32-mad", "achieved": round(madds_per_s * 2880 / 1e12, 3), "peak": VALU_MAD_PEAK_TOPS, "unit": "T v_mad_u64_u32/s",
-            "frac": round(madds_per_s * 2880 / 1e12 / VALU_MAD_PEAK_TOPS, 4), "mixed_adds_per_s": round(madds_per_s / 1e9, 3),
-            "note": "peak = measured v_mad_u64_u32 issue rate (profiles/r01_microbench.txt); Fq-mul-limited ceiling is 60 Gmul/s = 5.7 G mixed adds/s"}
-    roofline = {"bound": "hbm", "kernel": "msm::accum_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    valu_rate = madds_per_s * ACCUM_VALU_PER_ADD[path] / 1e12
+    valu = {"bound": "valu-issue", "kernel": "msmfb::accum30_kernel" if tab_w else "msm::accum_kernel",
+            "achieved": round(valu_rate, 3), "peak": VALU_ISSUE_PEAK_TOPS, "unit": "T VALU lane-instr/s",
+            "frac": round(valu_rate / VALU_ISSUE_PEAK_TOPS, 4), "bucket_adds_per_s": round(madds_per_s / 1e9, 3),
+            "windows": W_windows, "window_bits": tab_c or 16, "valu_instr_per_add": ACCUM_VALU_PER_ADD[path],
+            "v_mad_u64_u32_per_add": ACCUM_MAD_PER_ADD[path],
+            "note": "achieved = bucket additions/s x VALU instructions of the loop body; every VALU instruction of this "
+                    "kernel issues at about one lane-op per lane and clock (profiles/r01_microbench.txt)"}
+    roofline = {"bound": "hbm", "kernel": valu["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_launch_ms, 4),
-                "note": "MSM is integer-VALU bound (~7k VALU instr per 128 B of input per window), see DESIGN.md; "
+                "note": "algorithmic bytes = 128 B per (scalar, base) pair (SURVEY.md 8d); the MSM is VALU-issue bound "
+                        "(~5.6k VALU instr per bucket addition, %d additions per pair), see roofline_valu and DESIGN.md; "
                         "NTT family: %.1f GB/s algorithmic" % (
-                            (wl.alg_ntt_bytes * args.steps) / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0)}
+                            W_windows, (wl.alg_ntt_bytes * args.steps) / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0)}
 
     out = {
         "metric": "marlin_prove_constraints_per_sec", "value": round(value, 1), "unit": "constraints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32-limb Montgomery (Fr 256-bit, Fq 384-bit)",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32-limb Montgomery integers (Fr 256-bit in 8 x 32; Fq 384-bit in 12 x 32 and 13 x 30 bits)",
         "data": "synthetic",
         "config": {"workload": ("marlin-prove: full Marlin::prove (AHP rounds + KZG10 commit/open + Fiat-Shamir), "
                                 if workload == "marlin-prove" else
@@ -266,7 +280,7 @@ def main():
     out["config"]["pc"] = {"marlin": "MarlinKZG10", "sonic": "SonicKZG10"}[args.pc]
     out["config"]["workload"] = out["config"]["workload"].replace("BLS12-381, MarlinKZG10", "%s, %s" % (curve_name, out["config"]["pc"]))
     if _L.CURVE != "bls12_381" or args.pc != "marlin":
-        out["dtype"] = "u32-limb Montgomery (Fr 256-bit, Fq %d-bit)" % (64 * _L.FQ_LIMBS)
+        out["dtype"] = "u32-limb Montgomery integers (Fr 256-bit, Fq %d-bit)" % (64 * _L.FQ_LIMBS)
         args.no_cpu_baseline = True          # the C restatement covers the headline configuration only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -88,11 +88,13 @@ int mh_bases_download(uint64_t handle, size_t offset, size_t n, uint64_t* xy_mon
 int mh_bases_free(uint64_t handle);
 int mh_bases_len(uint64_t handle, size_t* n_out);
 /* Fixed-base acceleration for a base set that is multiplied again and again (the SRS): precomputes the shifts
- * 2^{start_j} * P of all window positions (W x n affine points of device memory; W = 13 at window_bits = 20), after
+ * 2^{start_j} * P of all window positions (W x n affine points of 128 B in device memory -- 96 B for BN254 --; W = 13 at window_bits = 20), after
  * which every MSM against this handle with enough scalars runs Pippenger over ONE shared bucket set.  window_bits
  * in [4, 20], 0 = choose from n.  Results are unchanged (an MSM has one answer).  mh_marlin_index calls this for
  * powers_of_g.  No counterpart in the reference (arkworks recomputes nothing across calls). */
 int mh_bases_precompute(uint64_t handle, uint32_t window_bits);
+/* window_bits / number of windows / device bytes of the handle's window table; all 0 when it has none. */
+int mh_bases_table_info(uint64_t handle, uint32_t* window_bits, uint32_t* windows, uint64_t* table_bytes);
 /* How many job groups (<= 8 MSMs launched together) have run on the fixed-base path / on the variable-base path
  * since mh_init: lets a caller (and the tests) see which algorithm served its MSMs. */
 int mh_msm_path_counts(uint64_t* fixed_base_groups, uint64_t* variable_base_groups);

@@ -145,6 +145,12 @@ class Bases:
         _lib.check(_L().mh_bases_precompute(self.handle, int(window_bits)), "mh_bases_precompute")
         return self
 
+    def table_info(self):
+        """(window_bits, windows, table_bytes) of the fixed-base table, zeros if none (mh_bases_table_info)."""
+        c, w, b = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        _lib.check(_L().mh_bases_table_info(self.handle, C.byref(c), C.byref(w), C.byref(b)), "mh_bases_table_info")
+        return c.value, w.value, b.value
+
     def download(self, offset=0, n=None):
         n = self.n - offset if n is None else n
         out = np.zeros((n, 2 * _fql()), dtype=np.uint64)

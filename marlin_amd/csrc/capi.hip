@@ -876,6 +876,17 @@ int mh_bases_precompute(uint64_t handle, uint32_t window_bits) {
   return bases_precompute(c, it->second, window_bits);
 }
 
+int mh_bases_table_info(uint64_t handle, uint32_t* window_bits, uint32_t* windows, uint64_t* table_bytes) {
+  LOCKED_CTX();
+  auto it = c.bases.find(handle);
+  if (it == c.bases.end()) return fail(MH_EINVAL, "mh_bases_table_info: unknown handle");
+  const BaseSet& bs = it->second;
+  if (window_bits) *window_bits = bs.d_table ? bs.tab_c : 0;
+  if (windows) *windows = bs.d_table ? bs.tab_W : 0;
+  if (table_bytes) *table_bytes = bs.d_table ? (uint64_t)bs.tab_W * bs.n * sizeof(msmfb::G1Aff30) : 0;
+  return MH_OK;
+}
+
 int mh_msm_path_counts(uint64_t* fixed_base_groups, uint64_t* variable_base_groups) {
   LOCKED_CTX();
   if (fixed_base_groups) *fixed_base_groups = c.n_fb_groups;
