@@ -365,13 +365,15 @@ __global__ __launch_bounds__(64) void fixup_kernel(Jobs jobs, const u32* __restr
 }
 
 // ---- 7. reduce1: thread per (window, segment) ----------------------------------------
+// seg = buckets per segment: SEG on the variable-base path; the fixed-base path shortens the segments when a launch
+// would otherwise have fewer threads than the chip has lanes (2 + ~27 / seg additions per bucket, but no idle SIMDs)
 __global__ __launch_bounds__(64) void reduce1_kernel(const G1Xyzz* __restrict__ buckets, G1Xyzz* __restrict__ segsum,
-                                                     u32 nb, u32 nseg, u32 W) {
+                                                     u32 nb, u32 nseg, u32 W, u32 seg) {
   u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= W * nseg) return;
   u32 w = gid / nseg, s = gid % nseg;
-  u32 lo = s * SEG;
-  u32 hi = lo + SEG; if (hi > nb) hi = nb;
+  u32 lo = s * seg;
+  u32 hi = lo + seg; if (hi > nb) hi = nb;
   G1Xyzz running = G1Xyzz::identity(), acc = G1Xyzz::identity();
   const G1Xyzz* B = buckets + (u64)w * nb;
   for (u32 b = hi; b-- > lo;) {
