@@ -274,7 +274,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   MH_TRY(c.fb_blk.ensure(8 * max_tiles_total * sizeof(F::FbBlk)));
   MH_TRY(c.msm_bh.ensure(max_tiles_total * nb * 4));
   MH_TRY(c.msm_tot.ensure(WB * 4)); MH_TRY(c.msm_base.ensure(WB * 4)); MH_TRY(c.msm_pend.ensure(WB * 4));
-  MH_TRY(c.msm_buckets.ensure(WB * sizeof(G1Xyzz)));
+  MH_TRY(c.msm_buckets.ensure(WB * sizeof(F::G1Xyzz30)));
   // segment length of the bucket reduction: >= 49152 threads per launch (measured best: 31.2 ms vs 36.1 ms with SEG fixed,
   // 32.7 ms at 65536, per 3 proofs), at most SEG buckets each; MH_FB_SEG_THREADS overrides
   u32 seg = msm::SEG;
@@ -353,13 +353,13 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
       hipLaunchKernelGGL(F::accum30_kernel, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                          (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
-                         (G1Xyzz*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, nb, (u64)WB);
+                         (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, nb, (u64)WB);
     }
     hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
-                       (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr, (G1Xyzz*)c.msm_buckets.ptr,
+                       (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr, (F::G1Xyzz30*)c.msm_buckets.ptr,
                        nb, (u64)WB);
     // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
-    hipLaunchKernelGGL(msm::reduce1_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const G1Xyzz*)c.msm_buckets.ptr,
+    hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)c.msm_buckets.ptr,
                        (G1Xyzz*)c.msm_seg.ptr, nbt, nseg, (u32)nj, seg);
     if (chunks > 1) {
       G1Xyzz* mid = (G1Xyzz*)c.msm_seg.ptr + (size_t)nj * nseg;
@@ -383,9 +383,10 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
 }
 
 // Build the window table of a base set: level j = 2^{start_j} * P (c-bit windows tiling 256 bits), affine.
-// Automatic window width: bucket load ~ W * n / 2^(c-1) stays near 100 for MSMs as long as the base set and ~25 for
-// the quarter-length ones that dominate a Marlin proof.  With point-sharding over `world` GPUs every rank multiplies
-// 1/world of each MSM, so the width follows n / world (the bucket reduction does not shrink with the shard).
+// Automatic window width: lg(n) - 1, at most 20 (measured on the prover: 2^20-point SRS 51.0 / 42.4 / 40.7 / 44.4 ms per
+// proof at c = 16 / 18 / 19 / 20; 2^22-point SRS 115.8 / 113.2 ms at c = 19 / 20).  With point-sharding over `world` GPUs
+// every rank multiplies 1/world of each MSM, so the width follows n / world (the bucket reduction does not shrink with
+// the shard).
 static uint32_t g_fb_world = 1;
 static uint32_t auto_window_bits(size_t n) {
   static const int env_c = [] { const char* e = getenv("MH_FB_C"); return e ? atoi(e) : 0; }();
@@ -393,8 +394,8 @@ static uint32_t auto_window_bits(size_t n) {
   size_t eff = n / g_fb_world;
   u32 lg = 0;
   while ((1ull << lg) < eff) lg++;
-  int cc = (int)lg - 2;
-  if (cc == 17) cc = 16;               // 17 tiles 256 bits with 16 windows of 16 bits: same digits as 16, twice the buckets
+  int cc = (int)lg - 1;
+  if (cc == 17) cc = 18;               // 17 tiles 256 bits with 16 windows of 16 bits: same digits as 16, twice the buckets
   return (uint32_t)(cc > msmfb::MAX_C ? msmfb::MAX_C : (cc < 8 ? 8 : cc));
 }
 

@@ -345,6 +345,82 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __re
   for (u32 idx = t; idx < cnt; idx += SORT_THREADS) out[gdst[sbkt[idx]] + idx] = stage[idx];
 }
 
+// ---- XYZZ points on 30-bit limbs (buckets between accumulate and the segment reduction) -------------------------
+// Bounds kept by every operation below (units of p): X <= 6.2, Y <= 3.2, ZZ, ZZZ <= 1.1; the identity is ZZ = 0
+// exactly (a ZZ computed by the formulas is a product of non-zero residues).
+struct X30 { Fq30 x, y, zz, zzz; };
+struct G1Xyzz30 { u32 c[4][LIMB_SLOTS]; };
+
+__device__ __forceinline__ bool x30_is_identity(const X30& a) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) o |= a.zz.v[i];
+  return o == 0;
+}
+__device__ __forceinline__ X30 x30_identity() {
+  X30 r;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) { r.x.v[i] = 0; r.y.v[i] = 0; r.zz.v[i] = 0; r.zzz.v[i] = 0; }
+  return r;
+}
+__device__ __forceinline__ X30 x30_load(const G1Xyzz30* p) {
+  X30 r;
+  r.x = load30(p->c[0]); r.y = load30(p->c[1]); r.zz = load30(p->c[2]); r.zzz = load30(p->c[3]);
+  return r;
+}
+__device__ __forceinline__ void x30_store(G1Xyzz30* p, const X30& a) {
+  store30(p->c[0], a.x); store30(p->c[1], a.y); store30(p->c[2], a.zz); store30(p->c[3], a.zzz);
+}
+__device__ __forceinline__ G1Xyzz x30_to_std(const X30& a) {
+  G1Xyzz r;
+  if (x30_is_identity(a)) return G1Xyzz::identity();
+  r.x = f30_to_fq(a.x); r.y = f30_to_fq(a.y); r.zz = f30_to_fq(a.zz); r.zzz = f30_to_fq(a.zzz);
+  return r;
+}
+__device__ __forceinline__ X30 x30_from_std(const G1Xyzz& a) {
+  X30 r;
+  r.x = f30_from_fq(a.x); r.y = f30_from_fq(a.y); r.zz = f30_from_fq(a.zz); r.zzz = f30_from_fq(a.zzz);
+  return r;
+}
+// complete addition through the standard representation: the rare equal-x cases
+__device__ __noinline__ void x30_add_slow(X30& acc, const X30& b) {
+  G1Xyzz a = x30_to_std(acc), bb = x30_to_std(b);
+  g1_add(a, bb);
+  acc = x30_from_std(a);
+}
+// acc += b   [EFD add-2008-s]  12M + 2S
+__device__ __noinline__ void x30_add(X30& acc, const X30& b) {
+  if (x30_is_identity(b)) return;
+  if (x30_is_identity(acc)) { acc = b; return; }
+  const Fq30 U1 = f30_mul(acc.x, b.zz);
+  const Fq30 S1 = f30_mul(acc.y, b.zzz);
+  const Fq30 P = f30_sub<2>(f30_mul(b.x, acc.zz), U1);
+  if (__builtin_expect(f30_maybe_zero(P), 0)) { x30_add_slow(acc, b); return; }
+  const Fq30 R = f30_sub<2>(f30_mul(b.y, acc.zzz), S1);
+  Fq30 PP = f30_sqr(P);
+  const Fq30 Q = f30_mul(U1, PP);
+  acc.zz = f30_mul(f30_mul(acc.zz, b.zz), PP);
+  PP = f30_mul(P, PP);                                  // PPP
+  acc.zzz = f30_mul(f30_mul(acc.zzz, b.zzz), PP);
+  acc.x = f30_sub2<3>(f30_sub<2>(f30_sqr(R), PP), Q);
+  acc.y = f30_sub<2>(f30_mul(R, f30_sub<8>(Q, acc.x)), f30_mul(S1, PP));
+}
+// a = 2 a   [EFD dbl-2008-s-1, a = 0]; a point of G1 has odd order, so 2 a is never the identity
+__device__ __noinline__ void x30_dbl(X30& a) {
+  if (x30_is_identity(a)) return;
+  const Fq30 U = f30_dbl(a.y);
+  const Fq30 V = f30_sqr(U);
+  const Fq30 W = f30_mul(U, V);
+  const Fq30 S = f30_mul(a.x, V);
+  const Fq30 XX = f30_sqr(a.x);
+  const Fq30 M = f30_add(f30_dbl(XX), XX);
+  const Fq30 X3 = f30_sub2<3>(f30_sqr(M), S);
+  a.y = f30_sub<2>(f30_mul(M, f30_sub<8>(S, X3)), f30_mul(W, a.y));
+  a.zz = f30_mul(V, a.zz);
+  a.zzz = f30_mul(W, a.zzz);
+  a.x = X3;
+}
+
 // ---- bucket order: largest first -------------------------------------------------------------------------------
 // A wave of the accumulate kernel runs as long as its largest bucket.  msm::accum_kernel sorts bucket sizes inside each
 // block of 256; here all buckets of the launch are ordered by size with a counting sort (sizes are small integers), so
@@ -392,13 +468,13 @@ __global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__
 __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                                u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                                const u32* __restrict__ tot, const u32* __restrict__ perm,
-                                                               G1Xyzz* __restrict__ buckets, u32* __restrict__ pend, u32 nb, u64 WB) {
+                                                               G1Xyzz30* __restrict__ buckets, u32* __restrict__ pend, u32 nb, u64 WB) {
   const u64 slot = (u64)blockIdx.x * msm::ACC_TPB + threadIdx.x;
   if (slot >= WB) return;
   const u64 gid = perm[slot];
   u32* lst = sorted_all + fbw[gid / nb].off + base[gid];
   const u32 cnt = tot[gid];
-  if (cnt == 0) { g1_store_xyzz(buckets + gid, G1Xyzz::identity()); pend[gid] = 0; return; }
+  if (cnt == 0) { x30_store(buckets + gid, x30_identity()); pend[gid] = 0; return; }
   Fq30 zero;
 #pragma unroll
   for (int i = 0; i < Fq30::NL; i++) zero.v[i] = 0;
@@ -433,22 +509,20 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(3,
     X1 = f30_sub2<3>(f30_sub<2>(f30_sqr(R), PP), Q);
     Y1 = f30_sub<2>(f30_mul(R, f30_sub<8>(Q, X1)), Y1);
   }
-  G1Xyzz acc;
-  acc.x = f30_to_fq(X1); acc.y = f30_to_fq(Y1); acc.zz = f30_to_fq(ZZ); acc.zzz = f30_to_fq(ZZZ);
-  g1_store_xyzz(buckets + gid, acc);
+  store30(buckets[gid].c[0], X1); store30(buckets[gid].c[1], Y1); store30(buckets[gid].c[2], ZZ); store30(buckets[gid].c[3], ZZZ);
   pend[gid] = np;
 }
 
 // deferred entries: complete group law in the standard representation, one thread per bucket that has any
 __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                      const u32* __restrict__ sorted_all, const u32* __restrict__ base,
-                                                     const u32* __restrict__ pend, G1Xyzz* __restrict__ buckets, u32 nb, u64 WB) {
+                                                     const u32* __restrict__ pend, G1Xyzz30* __restrict__ buckets, u32 nb, u64 WB) {
   u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= WB) return;
   const u32 np = pend[gid];
   if (np == 0) return;
   const u32* lst = sorted_all + fbw[gid / nb].off + base[gid];
-  G1Xyzz acc = g1_load_xyzz(buckets + gid);
+  G1Xyzz acc = x30_to_std(x30_load(buckets + gid));
   for (u32 k = 0; k < np; k++) {
     const u32 e = lst[k];
     const G1Aff30* q = table + (e & 0x7fffffffu);
@@ -456,7 +530,36 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
     if (e & 0x80000000u) y = ff_neg(y);
     g1_madd(acc, x, y);
   }
-  g1_store_xyzz(buckets + gid, acc);
+  x30_store(buckets + gid, x30_from_std(acc));
+}
+
+// ---- reduce1: thread per (job, segment of `seg` buckets), on 30-bit limbs ------------------------------------------
+// sum_b (b + 1) B_b over the job's single bucket set: running sums inside the segment plus (first bucket index) x
+// (segment total) by double-and-add; the result goes to msm::reduce2_kernel in the standard representation.
+__global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restrict__ buckets, G1Xyzz* __restrict__ segsum, u32 nb,
+                                                        u32 nseg, u32 njobs, u32 seg) {
+  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= njobs * nseg) return;
+  const u32 w = gid / nseg, s = gid % nseg;
+  const u32 lo = s * seg;
+  u32 hi = lo + seg; if (hi > nb) hi = nb;
+  X30 running = x30_identity(), acc = x30_identity();
+  const G1Xyzz30* B = buckets + (u64)w * nb;
+  for (u32 b = hi; b-- > lo;) {
+    X30 t = x30_load(B + b);
+    x30_add(running, t);
+    x30_add(acc, running);
+  }
+  if (lo) {
+    X30 m = x30_identity();
+    const int top = 31 - __clz(lo);
+    for (int bit = top; bit >= 0; bit--) {
+      x30_dbl(m);
+      if ((lo >> bit) & 1) x30_add(m, running);
+    }
+    x30_add(acc, m);
+  }
+  g1_store_xyzz(segsum + gid, x30_to_std(acc));
 }
 
 }  // namespace msmfb
