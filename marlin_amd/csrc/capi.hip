@@ -457,8 +457,23 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
   hipStream_t s = c.stream;
   // MH_MSM_ALGO = xyzz | tree forces that accumulation on the variable-base path (and disables the fixed-base tables)
   static const int forced = [] { const char* e = getenv("MH_MSM_ALGO"); return !e ? 0 : (std::string(e) == "tree" ? 2 : 1); }();
-  for (size_t g0 = 0; g0 < live.size(); g0 += msm::MAX_JOBS) {
-    const int nj = (int)std::min<size_t>(msm::MAX_JOBS, live.size() - g0);
+  size_t g_next = 0;
+  for (size_t g0 = 0; g0 < live.size(); g0 = g_next) {
+    // a group: up to MAX_JOBS jobs whose entries (windows x scalars) fit 32-bit offsets
+    int nj = 0;
+    {
+      u64 ent_est = 0;
+      while (nj < msm::MAX_JOBS && g0 + nj < live.size()) {
+        const size_t n = ns[live[g0 + nj]];
+        size_t o = 0;
+        const BaseSet* tb = forced == 0 ? find_table(c, d_bases[live[g0 + nj]], n, o) : nullptr;
+        const u64 e = (u64)(tb ? tb->tab_W : msm::make_plan(n).W) * n;
+        if (nj && ent_est + e >= (1ull << 32) - (1ull << 26)) break;
+        ent_est += e;
+        nj++;
+      }
+    }
+    g_next = g0 + nj;
     size_t nmax = 0, nsum = 0;
     for (int k = 0; k < nj; k++) { size_t n = ns[live[g0 + k]]; nmax = std::max(nmax, n); nsum += n; }
     // fixed-base path: every job of the group lies inside one base set with a window table, and the shared bucket

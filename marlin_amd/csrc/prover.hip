@@ -483,7 +483,10 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
   // MH_FB=0 keeps the variable-base path.
   {
     static const bool fb_on = [] { const char* e = getenv("MH_FB"); return !e || atoi(e) != 0; }();
-    if (fb_on && !sg->second.d_table) MH_TRY(bases_precompute(c, sg->second, 0));
+    if (fb_on && !sg->second.d_table) {
+      int rc = bases_precompute(c, sg->second, 0);
+      if (rc != MH_OK && rc != MH_ENOMEM) return rc;      // no room for the table: the variable-base path serves this key
+    }
   }
 
   std::unique_ptr<ProverKey> pkp(new ProverKey());

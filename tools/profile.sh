@@ -11,6 +11,27 @@ cd /tmp
 CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+# per-dispatch durations of the accumulate kernel: kernel_stats averages over index + warm-up + timed launches, the
+# bench's roofline over the timed ones only (the last 4 x steps dispatches)
+python3 - "$OUT" <<'PY'
+import csv, glob, json, sys
+out = sys.argv[1]
+rows = []
+for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "accum30_kernel" in r["Kernel_Name"] or "msm::accum_kernel" in r["Kernel_Name"]:
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+rows.sort()
+d = [x[1] / 1e6 for x in rows]
+steps = 2
+timed = d[-4 * steps:]
+json.dump({"kernel": "bucket accumulation (msmfb::accum30_kernel)", "dispatch_ms_in_launch_order": [round(x, 3) for x in d],
+           "avg_ms_all_dispatches": round(sum(d) / max(1, len(d)), 3),
+           "avg_ms_timed_region": round(sum(timed) / max(1, len(timed)), 3),
+           "note": "timed region = the last 4 x %d dispatches (4 batched MSM launches per prove: rounds 1-3 and the openings); "
+                   "earlier dispatches belong to Marlin::index (larger batches) and the warm-up prove" % steps},
+          open(out + "/accum_dispatches.json", "w"), indent=1)
+PY
 CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD1 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $CMD1 > $OUT/pmc_write.log 2>&1
