@@ -10,6 +10,7 @@
 // challenges and the 3-coefficient hiding polynomials live on the host; every O(n) object lives
 // on the device and is only ever touched by the kernels in ntt.cuh / msm.cuh / poly.cuh.
 #include <algorithm>
+#include <future>
 #include <memory>
 #include "drivers.h"
 #include "ff.cuh"
@@ -364,14 +365,19 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
       jobs.push_back({pts + off * PT_B, q.poly, q.len});
       if (q.hiding) for (int k = 0; k < 3; k++) rands[i].rand.blind.push_back(fsh::fr_rand(*rng));
     }
-    std::vector<HG1> res;
-    MH_TRY(sharded_msm_batch(c, jobs, res));
-    for (size_t i = 0; i < reqs.size(); i++) {
-      HG1 cm = res[i];
+    // the 3-coefficient hiding MSMs run on host threads while the device works on the batch
+    std::vector<std::future<HG1>> hid(reqs.size());
+    for (size_t i = 0; i < reqs.size(); i++)
       if (reqs[i].hiding) {
         const HG1Affine* gp = !reqs[i].has_bound ? pk.gamma_g : (reqs[i].bound == pk.H - 2 ? pk.gamma_g_h : pk.gamma_g_k);
-        cm = cm.add(small_msm(gp, rands[i].rand.blind));
+        hid[i] = std::async(std::launch::async, small_msm, gp, std::cref(rands[i].rand.blind));
       }
+    std::vector<HG1> res;
+    int rc_batch = sharded_msm_batch(c, jobs, res);
+    if (rc_batch != MH_OK) { for (auto& f : hid) if (f.valid()) f.wait(); return rc_batch; }
+    for (size_t i = 0; i < reqs.size(); i++) {
+      HG1 cm = res[i];
+      if (reqs[i].hiding) cm = cm.add(hid[i].get());
       comms[i].comm = cm.to_affine();
       comms[i].has_shifted = false;
     }
@@ -391,16 +397,24 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
       if (q.hiding) for (int k = 0; k < 3; k++) rands[i].shifted.blind.push_back(fsh::fr_rand(*rng));
     }
   }
+  // the 3-coefficient hiding MSMs run on host threads while the device works on the batch
+  std::vector<std::future<HG1>> hid(reqs.size()), hid_sh(reqs.size());
+  for (size_t i = 0; i < reqs.size(); i++)
+    if (reqs[i].hiding) {
+      hid[i] = std::async(std::launch::async, small_msm, (const HG1Affine*)pk.gamma_g, std::cref(rands[i].rand.blind));
+      if (reqs[i].has_bound) hid_sh[i] = std::async(std::launch::async, small_msm, (const HG1Affine*)pk.gamma_g, std::cref(rands[i].shifted.blind));
+    }
   std::vector<HG1> res;
-  MH_TRY(sharded_msm_batch(c, jobs, res));
+  int rc_batch = sharded_msm_batch(c, jobs, res);
+  if (rc_batch != MH_OK) { for (auto& f : hid) if (f.valid()) f.wait(); for (auto& f : hid_sh) if (f.valid()) f.wait(); return rc_batch; }
   size_t j = 0;
   for (size_t i = 0; i < reqs.size(); i++) {
     HG1 cm = res[j++];
-    if (reqs[i].hiding) cm = cm.add(small_msm(pk.gamma_g, rands[i].rand.blind));
+    if (reqs[i].hiding) cm = cm.add(hid[i].get());
     comms[i].comm = cm.to_affine();
     if (reqs[i].has_bound) {
       HG1 sh = res[j++];
-      if (reqs[i].hiding) sh = sh.add(small_msm(pk.gamma_g, rands[i].shifted.blind));
+      if (reqs[i].hiding) sh = sh.add(hid_sh[i].get());
       comms[i].shifted = sh.to_affine();
     }
   }
@@ -965,19 +979,30 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
   MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
   MH_TRY(lincomb(c, S[6], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
-  std::vector<HG1> om;
-  MH_TRY(sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts + (pk.srs_max_degree - (H - 2)) * PT_B, S[4], g1_len - 1},
-                               {srs_pts, S[5], K - 1}, {srs_pts + (pk.srs_max_degree - (K - 2)) * PT_B, S[6], g2_len - 1}}, om));
+  // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b); its witness and the shifted
+  // one are multiplied on host threads while the device runs the batch
+  std::vector<HFr> r;
+  host_axpy(r, HFr::one(), rd_g1.rand.blind);
   {
-    HG1 wacc = om[0];
-    // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b)
-    std::vector<HFr> r;
-    host_axpy(r, HFr::one(), rd_g1.rand.blind);
     std::vector<HFr> r_outer; host_axpy(r_outer, c_za_lc, rd_za.rand.blind); host_axpy(r_outer, c_w_lc, rd_w.rand.blind);
     host_axpy(r, xi_pow(2), r_outer);
-    host_axpy(r, xi_pow(4), rd_zb.rand.blind);
-    if (!host_is_zero(r)) {
-      wacc = wacc.add(small_msm(pk.gamma_g, host_div_linear(r, beta)));
+  }
+  host_axpy(r, xi_pow(4), rd_zb.rand.blind);
+  const bool r_nonzero = !host_is_zero(r);
+  const std::vector<HFr> rw = r_nonzero ? host_div_linear(r, beta) : std::vector<HFr>();
+  std::vector<HFr> srw; host_axpy(srw, xi_pow(1), host_div_linear(rd_g1.shifted.blind, beta));
+  std::future<HG1> f_rw, f_srw = std::async(std::launch::async, small_msm, (const HG1Affine*)pk.gamma_g, std::cref(srw));
+  if (r_nonzero) f_rw = std::async(std::launch::async, small_msm, (const HG1Affine*)pk.gamma_g, std::cref(rw));
+  std::vector<HG1> om;
+  {
+    int rc_batch = sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts + (pk.srs_max_degree - (H - 2)) * PT_B, S[4], g1_len - 1},
+                                         {srs_pts, S[5], K - 1}, {srs_pts + (pk.srs_max_degree - (K - 2)) * PT_B, S[6], g2_len - 1}}, om);
+    if (rc_batch != MH_OK) { f_srw.wait(); if (f_rw.valid()) f_rw.wait(); return rc_batch; }
+  }
+  {
+    HG1 wacc = om[0];
+    if (r_nonzero) {
+      wacc = wacc.add(f_rw.get());
       rv_beta = host_eval(r, beta); has_rv_beta = true;
     }
     HG1 sw = om[1];
@@ -985,8 +1010,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     // the hiding witness is always Some(..) on this path, so random_v is always Some(shifted_r(point))
     std::vector<HFr> sr; host_axpy(sr, xi_pow(1), rd_g1.shifted.blind);
     {
-      std::vector<HFr> srw; host_axpy(srw, xi_pow(1), host_div_linear(rd_g1.shifted.blind, beta));
-      sw = sw.add(small_msm(pk.gamma_g, srw));
+      sw = sw.add(f_srw.get());
       HFr srv = host_eval(sr, beta);
       rv_beta = has_rv_beta ? rv_beta + srv : srv; has_rv_beta = true;
     }
