@@ -2,11 +2,12 @@
 //
 // The bases of every KZG10 commitment are the SAME powers of tau (ark-poly-commit kzg10 `commit` on
 // `powers_of_g[offset..]`; reference call sites /root/reference src/lib.rs:125,172,193,213,292), so the shifts
-// 2^{start_j} * P_i of all W window positions are computed once per base set (`mh_bases_precompute`, 13 x 96 B per
+// 2^{start_j} * P_i of all W window positions are computed once per base set (`mh_bases_precompute`, 13 x 128 B per
 // point at c = 20 -- HBM capacity is what MI355X has plenty of) and every (scalar, window) digit becomes an entry
 // "add table point T[j][i] to bucket |digit|".  All windows then share ONE set of 2^(c-1) buckets, the bucket
 // reduction no longer scales with the number of windows, and c can grow past the 16 bits an LDS histogram holds:
-// c = 20 needs 13 bucket additions per scalar instead of 16.
+// c = 20 needs 13 bucket additions per scalar instead of 16.  Table points, bucket accumulators and the bucket
+// reduction use the 30-bit-limb field arithmetic of fq30.cuh.
 //
 // Sorting 13 n entries by a 19-bit bucket id is done in two levels:
 //   count/pscan/pstart/split : partition the entries by the top bits of the bucket id into <= 256 "virtual windows"
@@ -19,7 +20,8 @@
 // store per entry to ~random lines; the L2s cannot keep that many partial lines open, and HBM sees ~8x the payload
 // (profiles/pmc_traffic.json; measured the same way for this path before the LDS staging: 2.6 GB written per launch
 // for 0.33 GB of entries).
-// followed by msm.cuh's accumulate (entries index the table), fix-up and segment reduction with W = 1.
+// followed by the ordering of all buckets by size, the accumulate kernel (entries index the table), the fix-up of deferred
+// collisions, and the segment reduction over the single bucket set of each MSM.
 #pragma once
 #include "msm.cuh"
 #include "fq30.cuh"
