@@ -215,3 +215,34 @@ def test_msm_fixed_base_offsets_batch_and_edges(gpu, bases4k):
     assert gpu.msm_path_counts() == (fb0, vb0 + 1)
     with pytest.raises(gpu.MarlinHipError):
         gpu.Bases(big[:64]).precompute(23)
+
+
+def test_fixed_base_table_info_and_shard_resize(gpu, bases4k):
+    """automatic window width = lg(n) - 1 (<= 20), 128-byte table points; mh_marlin_set_shard re-sizes automatically
+    sized tables for the shard length and leaves explicitly sized ones alone; results do not change."""
+    import ctypes as C
+    from marlin_amd import _lib
+    pts, dl = bases4k
+    n = 1 << 15
+    big = np.tile(points_to_np(pts), (n // 4096, 1))
+    dlb = [dl[i % 4096] for i in range(n)]
+    B = gpu.Bases(big)
+    assert B.table_info() == (0, 0, 0)
+    B.precompute()
+    c, w, nbytes = B.table_info()
+    pt = 128 if F.FQ_LIMBS64 == 6 else 96
+    assert (c, w, nbytes) == (14, (256 + 13) // 14, ((256 + 13) // 14) * n * pt)
+    Bx = gpu.Bases(big).precompute(9)
+    sc = rand_fr(n, 4242)
+    want = EC.scalar_mul(EC.G1_GEN, sum(s * a for s, a in zip(sc, dlb)) % F.R_MOD)
+    assert jac_np_to_affine(gpu.msm(B, fr_to_np(sc))) == want
+    L = _lib.load()
+    cb_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+    cb = cb_t(lambda *a: -1)                       # never called: plain mh_msm does not shard
+    try:
+        _lib.check(L.mh_marlin_set_shard(0, 4, C.cast(cb, C.c_void_p), None), "mh_marlin_set_shard")
+        assert B.table_info()[0] == 12 and Bx.table_info()[0] == 9
+        assert jac_np_to_affine(gpu.msm(B, fr_to_np(sc))) == want
+    finally:
+        _lib.check(L.mh_marlin_set_shard(0, 1, None, None), "mh_marlin_set_shard")
+    assert B.table_info()[0] == 14

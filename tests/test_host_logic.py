@@ -69,3 +69,42 @@ def test_host_field_and_group_ops():
     assert bytes(out) == MR.commitment_bytes((EC.G1_GEN, None))
     L.ht_put_commitment(C.c_void_p(g.ctypes.data), 1, C.c_void_p(xy2.ctypes.data), out)
     assert bytes(out) == MR.commitment_bytes((EC.G1_GEN, (p2,)))
+
+
+def test_fq30_constants_are_current_and_consistent(tmp_path):
+    """fq30_consts.inc (30-bit-limb base field of the fixed-base accumulation) is what gen_fq30.py generates, and
+    its numbers satisfy the identities the device code relies on."""
+    import re
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "marlin_amd", "csrc")
+    out = tmp_path / "fq30.inc"
+    subprocess.run([sys.executable, os.path.join(csrc, "gen_fq30.py"), str(out)], check=True)
+    txt = out.read_text()
+    assert txt == open(os.path.join(csrc, "fq30_consts.inc")).read()
+
+    def arr(block, name):
+        m = re.search(r"%s\[\d+\] = \{([^}]*)\}" % name, block)
+        return [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+
+    for curve, p, l32 in (("BLS12_381", 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab, 12),
+                          ("BN254", 21888242871839275222246405745257275088696311157297823662689037894645226208583, 8)):
+        block = txt[txt.index("struct Fq30Params_" + curve):]
+        block = block[:block.index("\n};")]
+        nl = int(re.search(r"NL = (\d+)", block).group(1))
+        val30 = lambda v: sum(x << (30 * i) for i, x in enumerate(v))
+        val32 = lambda v: sum(x << (32 * i) for i, x in enumerate(v))
+        assert val30(arr(block, "P")) == p and all(x < 1 << 30 for x in arr(block, "P"))
+        for k in (2, 3, 4, 8):
+            assert val30(arr(block, "P%d" % k)) == k * p
+        pinv = int(re.search(r"PINV = 0x([0-9a-f]+)u", block).group(1), 16)
+        pinv_pos = int(re.search(r"PINV_POS = 0x([0-9a-f]+)u", block).group(1), 16)
+        assert (pinv * p + 1) % (1 << 30) == 0 and (pinv_pos * p) % (1 << 30) == 1
+        r30, r32 = 1 << (30 * nl), 1 << (32 * l32)
+        assert val30(arr(block, "ONE")) == r30 % p
+        # mont32(x * R32, TO30) = x * R30 ; mont32(x * R30, FROM30) = x * R32   (mont32(a, b) = a b / R32)
+        x = 0x1234567890abcdef1234567890abcdef % p
+        assert (x * r32 % p) * val32(arr(block, "TO30")) * pow(r32, -1, p) % p == x * r30 % p
+        assert (x * r30 % p) * val32(arr(block, "FROM30")) * pow(r32, -1, p) % p == x * r32 % p
+        # lazy-reduction head room: the product of two values below 20 p stays below 2 p
+        assert (20 * p) * (20 * p) // r30 + p < 2 * p
