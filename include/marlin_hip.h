@@ -162,6 +162,10 @@ int mh_marlin_get_poly(uint64_t pk, const char* label, uint64_t* out, size_t cap
 int mh_prof_enable(int on);
 int mh_prof_reset(void);
 int mh_prof_get(int family, double* total_ms_out, uint64_t* launches_out);
+/* Device self-test of the 30-bit-limb base-field arithmetic used by the fixed-base MSM path against the 32-bit
+ * Montgomery arithmetic: n pseudo-random operand pairs (field operations, XYZZ doubling / addition incl. the equal-x
+ * path); *mismatches_out = number of operand pairs with any disagreement (0 expected). */
+int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out);
 
 #ifdef __cplusplus
 }

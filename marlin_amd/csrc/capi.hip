@@ -1006,6 +1006,37 @@ int mh_prof_reset(void) {
   for (int i = 0; i < PF_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; }
   return MH_OK;
 }
+int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out) {
+  LOCKED_CTX();
+  if (!mismatches_out) return fail(MH_EINVAL, "mh_selftest_fq30: null output");
+  if (n == 0 || n > (1ull << 26)) return fail(MH_EINVAL, "mh_selftest_fq30: n must be in [1, 2^26]");
+  // operands: xorshift words with the top limb masked below 2^28 (any value; the kernel reduces them below p)
+  std::vector<u32> h((size_t)(n + 1) * (FQ_L * 2));
+  uint64_t x = seed * 0x9e3779b97f4a7c15ull + 0x1234567ull;
+  for (size_t i = 0; i < h.size(); i++) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    h[i] = (u32)(x >> 16);
+    if (i % (FQ_L * 2) == FQ_L * 2 - 1) h[i] &= 0x0fffffffu;
+  }
+  // a few structured operands: 0, 1, small values, all-ones limbs
+  for (size_t k = 0; k < std::min<size_t>(n + 1, 6); k++) {
+    u32* e = h.data() + k * (FQ_L * 2);
+    for (size_t l = 0; l < FQ_L * 2; l++) e[l] = k == 5 ? (l == FQ_L * 2 - 1 ? 0x0fffffffu : 0xffffffffu) : 0;
+    if (k >= 1 && k < 5) e[0] = (u32)k;
+  }
+  MH_TRY(c.io.ensure(h.size() * 4 + 64));
+  u32* d_bad = (u32*)((char*)c.io.ptr + h.size() * 4);
+  MH_HIP(hipMemcpyAsync(c.io.ptr, h.data(), h.size() * 4, hipMemcpyHostToDevice, c.stream));
+  MH_HIP(hipMemsetAsync(d_bad, 0, 4, c.stream));
+  hipLaunchKernelGGL(msmfb::selftest30_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c.stream, (const Fq*)c.io.ptr, (u64)n, d_bad);
+  MH_HIP(hipGetLastError());
+  u32 bad = 0;
+  MH_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  *mismatches_out = bad;
+  return MH_OK;
+}
+
 int mh_prof_get(int family, double* total_ms_out, uint64_t* launches_out) {
   LOCKED_CTX();
   if (family < 0 || family >= PF_COUNT) return fail(MH_EINVAL, "mh_prof_get: bad family");

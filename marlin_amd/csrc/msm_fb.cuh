@@ -564,4 +564,46 @@ __global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restri
   g1_store_xyzz(segsum + gid, x30_to_std(acc));
 }
 
+// ---- self-test of the 30-bit arithmetic against ff.cuh (mh_selftest_fq30) ----------------------------------------
+// in: n + 1 arbitrary 32-bit-limb integers; every thread checks, for a = in[i], b = in[i + 1] (reduced below p first):
+// a b through both representations; (c + a) - a; (a - b)(a + b) = a^2 - b^2 with the dedicated squaring; a - 2b;
+// XYZZ doubling and addition of a pseudo-point against g1_dbl / g1_add (pure algebra: the formulas never test curve
+// membership); the zero filter on multiples of p.
+__global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ in, u64 n, u32* __restrict__ bad) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fq a = ff_mul(ff_load(in + i), Fq::one()), b = ff_mul(ff_load(in + i + 1), Fq::one());
+  const Fq30 a30 = f30_from_fq(a), b30 = f30_from_fq(b);
+  bool ok = true;
+  auto same = [&](const Fq& x, const Fq& y) { for (int k = 0; k < Fq::N; k++) ok = ok && x.v[k] == y.v[k]; };
+  const Fq30 c30 = f30_mul(a30, b30);
+  same(f30_to_fq(c30), ff_mul(a, b));
+  same(f30_to_fq(f30_sub<2>(f30_add(c30, a30), a30)), ff_mul(a, b));
+  same(f30_to_fq(f30_mul(f30_sub<2>(a30, b30), f30_add(a30, b30))), f30_to_fq(f30_sub<2>(f30_sqr(a30), f30_sqr(b30))));
+  same(f30_to_fq(f30_sqr(a30)), ff_sqr(a));
+  same(f30_to_fq(f30_sub2<3>(a30, b30)), ff_sub(a, ff_dbl(b)));
+  same(f30_to_fq(f30_sub<8>(f30_dbl(a30), b30)), ff_sub(ff_dbl(a), b));
+  ok = ok && f30_maybe_zero(f30_sub<2>(a30, a30)) && f30_maybe_zero(f30_sub<8>(f30_add(a30, a30), f30_dbl(a30)));
+  // group formulas on pseudo-points
+  G1Xyzz p, q;
+  p.x = a; p.y = b; p.zz = ff_sqr(b); p.zzz = ff_mul(p.zz, b);
+  q.x = b; q.y = ff_add(a, b); q.zz = ff_sqr(a); q.zzz = ff_mul(q.zz, a);
+  if (!p.zz.is_zero() && !q.zz.is_zero()) {
+    X30 p30 = x30_from_std(p), q30 = x30_from_std(q);
+    G1Xyzz d = p; g1_dbl(d);
+    X30 d30 = p30; x30_dbl(d30);
+    G1Xyzz ds = x30_to_std(d30);
+    same(ds.x, d.x); same(ds.y, d.y); same(ds.zz, d.zz); same(ds.zzz, d.zzz);
+    G1Xyzz s = p; g1_add(s, q);
+    X30 s30 = p30; x30_add(s30, q30);
+    G1Xyzz ss = x30_to_std(s30);
+    same(ss.x, s.x); same(ss.y, s.y); same(ss.zz, s.zz); same(ss.zzz, s.zzz);
+    // equal x: the slow path (doubling)
+    X30 e30 = p30; x30_add(e30, p30);
+    G1Xyzz es = x30_to_std(e30);
+    same(es.x, d.x); same(es.y, d.y); same(es.zz, d.zz); same(es.zzz, d.zzz);
+  }
+  if (!ok) atomicAdd(bad, 1u);
+}
+
 }  // namespace msmfb

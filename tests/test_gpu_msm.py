@@ -246,3 +246,14 @@ def test_fixed_base_table_info_and_shard_resize(gpu, bases4k):
     finally:
         _lib.check(L.mh_marlin_set_shard(0, 1, None, None), "mh_marlin_set_shard")
     assert B.table_info()[0] == 14
+
+
+def test_fq30_device_selftest(gpu):
+    """the 30-bit-limb field / group arithmetic of the fixed-base path agrees with the 32-bit Montgomery arithmetic on
+    2^18 pseudo-random operand pairs plus structured ones (mh_selftest_fq30)."""
+    import ctypes as C
+    from marlin_amd import _lib
+    for seed in (1, 2):
+        bad = C.c_uint64(123)
+        _lib.check(_lib.load().mh_selftest_fq30(1 << 18, seed, C.byref(bad)), "mh_selftest_fq30")
+        assert bad.value == 0
