@@ -329,8 +329,8 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
                          (u32*)c.msm_bh.ptr, nb, (u32)tile);
     }
     hipLaunchKernelGGL(F::colscan_kernel, dim3((nb + 255) / 256, WT), dim3(256), 0, s, fbw, (u32*)c.msm_bh.ptr, (u32*)c.msm_tot.ptr, nb);
-    u32* d_max = (u32*)c.tr_sums.ptr;
-    MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
+    u32* d_max = (u32*)c.tr_sums.ptr;                  // [0] largest bucket, [1] buckets with deferred entries
+    MH_HIP(hipMemsetAsync(d_max, 0, 8, s));
     hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, nb, d_max);
     if (grid_tiles) {
       hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::scatter_lds_bytes(nb), s, fbw, dblk, (const u32*)key,
@@ -353,11 +353,11 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
       hipLaunchKernelGGL(F::accum30_kernel, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                          (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
-                         (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, nb, (u64)WB);
+                         (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB);
     }
-    hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
-                       (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr, (F::G1Xyzz30*)c.msm_buckets.ptr,
-                       nb, (u64)WB);
+    hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 4096)), dim3(64), 0, s, fbw,
+                       (const F::G1Aff30*)bs.d_table, (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr,
+                       (const u32*)(d_max + 1), (F::G1Xyzz30*)c.msm_buckets.ptr, nb, (u64)WB);
     // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
     hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)c.msm_buckets.ptr,
                        (G1Xyzz*)c.msm_seg.ptr, nbt, nseg, (u32)nj, seg);

@@ -470,7 +470,8 @@ __global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__
 __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                                u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                                const u32* __restrict__ tot, const u32* __restrict__ perm,
-                                                               G1Xyzz30* __restrict__ buckets, u32* __restrict__ pend, u32 nb, u64 WB) {
+                                                               G1Xyzz30* __restrict__ buckets, u32* __restrict__ pend,
+                                                               u32* __restrict__ n_deferred, u32 nb, u64 WB) {
   const u64 slot = (u64)blockIdx.x * msm::ACC_TPB + threadIdx.x;
   if (slot >= WB) return;
   const u64 gid = perm[slot];
@@ -513,16 +514,19 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(3,
   }
   store30(buckets[gid].c[0], X1); store30(buckets[gid].c[1], Y1); store30(buckets[gid].c[2], ZZ); store30(buckets[gid].c[3], ZZZ);
   pend[gid] = np;
+  if (np) atomicAdd(n_deferred, 1u);
 }
 
-// deferred entries: complete group law in the standard representation, one thread per bucket that has any
+// deferred entries: complete group law in the standard representation, one thread per bucket that has any (a small
+// grid-stride launch that returns at once in the usual case of no deferred entry at all)
 __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                      const u32* __restrict__ sorted_all, const u32* __restrict__ base,
-                                                     const u32* __restrict__ pend, G1Xyzz30* __restrict__ buckets, u32 nb, u64 WB) {
-  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= WB) return;
+                                                     const u32* __restrict__ pend, const u32* __restrict__ n_deferred,
+                                                     G1Xyzz30* __restrict__ buckets, u32 nb, u64 WB) {
+  if (*n_deferred == 0) return;
+  for (u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x; gid < WB; gid += (u64)gridDim.x * blockDim.x) {
   const u32 np = pend[gid];
-  if (np == 0) return;
+  if (np == 0) continue;
   const u32* lst = sorted_all + fbw[gid / nb].off + base[gid];
   G1Xyzz acc = x30_to_std(x30_load(buckets + gid));
   for (u32 k = 0; k < np; k++) {
@@ -533,6 +537,7 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
     g1_madd(acc, x, y);
   }
   x30_store(buckets + gid, x30_from_std(acc));
+  }
 }
 
 // ---- reduce1: thread per (job, segment of `seg` buckets), on 30-bit limbs ------------------------------------------
