@@ -58,6 +58,42 @@ __global__ __launch_bounds__(TPB) void mul_sub_mul_kernel(Fr* __restrict__ out, 
   ff_store(out + i, ff_sub(x, y));
 }
 
+// b[i] <- ec * a[i] * b[i] + ea * a[i] + eb * b[i]: the evaluations of summed_z_m = eta_a z_a + eta_b z_b + eta_c z_a z_b
+// (prover.rs:467-471) on the 4H domain from those of z_a and z_b
+__global__ __launch_bounds__(TPB) void summed_evals_kernel(Fr* __restrict__ b, const Fr* __restrict__ a, FrArg ea, FrArg eb,
+                                                           FrArg ec, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr va = ff_load(a + i), vb = ff_load(b + i);
+  Fr r = ff_mul(ff_mul(va, vb), ec.v);
+  r = ff_add(r, ff_add(ff_mul(va, ea.v), ff_mul(vb, eb.v)));
+  ff_store(b + i, r);
+}
+
+// out[i] = in[i] * g^(+-i) with g^i = hi[i >> 11] * lo[i & 2047]: moves a coefficient vector to / from the coset g K
+// (evaluations of p on g K = transform of the coefficients p_i g^i)
+constexpr int COSET_LO_BITS = 11;
+__global__ __launch_bounds__(TPB) void twist_kernel(Fr* __restrict__ out, const Fr* __restrict__ in, const Fr* __restrict__ hi,
+                                                    const Fr* __restrict__ lo, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr gi = ff_mul(ff_load(hi + (i >> COSET_LO_BITS)), ff_load(lo + (i & ((1u << COSET_LO_BITS) - 1))));
+  ff_store(out + i, ff_mul(ff_load(in + i), gi));
+}
+
+// evaluations of h_2 on the coset g K (prover.rs:640-690 restated on a coset, see prover.hip):
+// out = ((ea va + eb vb + ec vc) - (alpha beta - alpha row - beta col + row_col) * f) * scale
+__global__ __launch_bounds__(TPB) void h2_coset_kernel(Fr* __restrict__ out, const Fr* __restrict__ f, const Fr* __restrict__ va,
+                                                       const Fr* __restrict__ vb, const Fr* __restrict__ vc, const Fr* __restrict__ row,
+                                                       const Fr* __restrict__ col, const Fr* __restrict__ row_col, FrArg ea, FrArg eb,
+                                                       FrArg ec, FrArg alpha, FrArg beta, FrArg alpha_beta, FrArg scale, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr a = ff_add(ff_add(ff_mul(ea.v, ff_load(va + i)), ff_mul(eb.v, ff_load(vb + i))), ff_mul(ec.v, ff_load(vc + i)));
+  Fr b = ff_add(ff_sub(ff_sub(alpha_beta.v, ff_mul(alpha.v, ff_load(row + i))), ff_mul(beta.v, ff_load(col + i))), ff_load(row_col + i));
+  ff_store(out + i, ff_mul(ff_sub(a, ff_mul(b, ff_load(f + i))), scale.v));
+}
+
 // out[i] = s * a[i]
 __global__ __launch_bounds__(TPB) void scale_kernel(Fr* __restrict__ out, const Fr* __restrict__ a, FrArg s, u64 n) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -67,6 +67,9 @@ struct ProverKey {
   // index (device)
   DBuf ev_row, ev_col, ev_row_col, ev_val_a, ev_val_b, ev_val_c;       // evals on K
   DBuf p_row, p_col, p_a_val, p_b_val, p_c_val, p_row_col;            // coefficient form (K each)
+  DBuf cs_row, cs_col, cs_row_col, cs_val_a, cs_val_b, cs_val_c;       // evals on the coset g K (third round)
+  DBuf gpow_hi, gpow_lo, ginv_hi, ginv_lo;                             // g^(+-i) = hi[i >> 11] * lo[i & 2047]
+  HFr coset_g;                                                         // g, with g^K != 1
   Csr A, B;
   DBuf t_items, t_erow, t_ecoef, t_item_ptr, t_group_ptr;
   uint64_t t_nitems = 0, t_ngroups = 0; bool t_has_coef = false;
@@ -80,7 +83,8 @@ struct ProverKey {
   std::map<std::string, std::pair<const Fr*, uint64_t>> last_polys;   // prover oracles of the last proof (label -> ptr, len)
   void free_all() {
     DBuf* all[] = {&ev_row, &ev_col, &ev_row_col, &ev_val_a, &ev_val_b, &ev_val_c, &p_row, &p_col, &p_a_val, &p_b_val, &p_c_val,
-                   &p_row_col, &A.row_ptr, &A.col, &A.val, &B.row_ptr, &B.col, &B.val, &t_items, &t_erow, &t_ecoef, &t_item_ptr, &t_group_ptr,
+                   &p_row_col, &cs_row, &cs_col, &cs_row_col, &cs_val_a, &cs_val_b, &cs_val_c, &gpow_hi, &gpow_lo, &ginv_hi, &ginv_lo,
+                   &A.row_ptr, &A.col, &A.val, &B.row_ptr, &B.col, &B.val, &t_items, &t_erow, &t_ecoef, &t_item_ptr, &t_group_ptr,
                    &z, &za_ev, &zb_ev, &xpoly, &w, &za, &zb, &mask, &t, &g1, &h1, &g2, &h2, &outer, &inner, &small, &scal};
     for (auto* b : all) b->release();
     for (auto& s : S) s.release();
@@ -599,6 +603,35 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     MH_TRY(h2d(c, evs[q]->p, hv[q]->data(), K * 32));
     MH_TRY(ntt_device(c, evs[q]->p, pls[q]->p, pk.logK, 1));          // interpolate (constraint_systems.rs:234-239)
   }
+  // ---- the same six polynomials on the coset g K: the third round evaluates h_2 there (see mh_marlin_prove) ------
+  {
+    HFr g = HFr::from_u64(7);
+    while (g.pow_u64(K) == HFr::one()) g = g + HFr::one();
+    pk.coset_g = g;
+    const uint64_t LO = 1ull << poly::COSET_LO_BITS, nhi = (K + LO - 1) / LO;
+    std::vector<uint64_t> lo(4 * LO), hi(4 * nhi), ilo(4 * LO), ihi(4 * nhi);
+    const HFr ginv = g.inv(), gL = g.pow_u64(LO), gLinv = ginv.pow_u64(LO);
+    HFr a = HFr::one(), b = HFr::one();
+    for (uint64_t j = 0; j < LO; j++) { memcpy(&lo[4 * j], a.v, 32); memcpy(&ilo[4 * j], b.v, 32); a = a * g; b = b * ginv; }
+    a = HFr::one(); b = HFr::one();
+    for (uint64_t j = 0; j < nhi; j++) { memcpy(&hi[4 * j], a.v, 32); memcpy(&ihi[4 * j], b.v, 32); a = a * gL; b = b * gLinv; }
+    MH_TRY(pk.gpow_lo.alloc(LO * 32)); MH_TRY(pk.ginv_lo.alloc(LO * 32)); MH_TRY(pk.gpow_hi.alloc(nhi * 32)); MH_TRY(pk.ginv_hi.alloc(nhi * 32));
+    MH_TRY(h2d(c, pk.gpow_lo.p, lo.data(), LO * 32)); MH_TRY(h2d(c, pk.ginv_lo.p, ilo.data(), LO * 32));
+    MH_TRY(h2d(c, pk.gpow_hi.p, hi.data(), nhi * 32)); MH_TRY(h2d(c, pk.ginv_hi.p, ihi.data(), nhi * 32));
+    MH_HIP(hipStreamSynchronize(c.stream));
+    DBuf* css[6] = {&pk.cs_row, &pk.cs_col, &pk.cs_val_a, &pk.cs_val_b, &pk.cs_val_c, &pk.cs_row_col};
+    DBuf tmp;
+    MH_TRY(tmp.alloc(K * 32));
+    for (int q = 0; q < 6; q++) {
+      int rc = css[q]->alloc(K * 32);
+      if (rc != MH_OK) { tmp.release(); return rc; }
+      KLAUNCH(poly::twist_kernel, K, tmp.fr(), (const Fr*)pls[q]->p, (const Fr*)pk.gpow_hi.p, (const Fr*)pk.gpow_lo.p, (u64)K);
+      rc = ntt_device(c, tmp.p, css[q]->p, pk.logK, 0);
+      if (rc != MH_OK) { tmp.release(); return rc; }
+    }
+    MH_HIP(hipStreamSynchronize(c.stream));
+    tmp.release();
+  }
   MH_HIP(hipStreamSynchronize(c.stream));
   // ---- index commitments: PC::commit(ck, index.iter(), None) (lib.rs:123-126) ----------------------------
   pk.index_comms.resize(6);
@@ -821,10 +854,11 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   MH_TRY(d2d(c, S[3], pk.zb.fr(), za_len)); MH_TRY(zero_tail(c, S[3], za_len, H4));
   MH_TRY(ntt_device(c, S[2], S[0], lg4H, 0));
   MH_TRY(ntt_device(c, S[3], S[1], lg4H, 0));
-  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_kernel, H4, S[0], (const Fr*)S[0], (const Fr*)S[1], (u64)H4); }
-  MH_TRY(ntt_device(c, S[0], S[2], lg4H, 1));                               // z_c = z_a * z_b  (2H+1 coefficients)
-  const uint64_t zc_len = 2 * H + 1;
-  MH_TRY(lincomb(c, S[3], zc_len, {{S[2], zc_len, eta_c}, {pk.za.fr(), za_len, eta_a}, {pk.zb.fr(), za_len, eta_b}}));   // summed_z_m
+  // The reference forms z_c = z_a * z_b (two forward transforms, a pointwise product, one inverse: prover.rs:467),
+  // summed_z_m = eta_a z_a + eta_b z_b + eta_c z_c (468-471), and later evaluates summed_z_m on the same 4H domain
+  // (533).  deg z_c = 2H + 2 < 4H, so those evaluations ARE eta_c z_a z_b + eta_a z_a + eta_b z_b pointwise: the inverse
+  // and the forward transform in between cancel exactly and are not executed.  S[1] <- evaluations of summed_z_m.
+  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::summed_evals_kernel, H4, S[1], (const Fr*)S[0], arg(eta_a), arg(eta_b), arg(eta_c), (u64)H4); }
   // r_alpha_x evals on H (mod.rs:311-318)
   HFr vH_alpha = v_h(alpha);
   { ProfScope ps(c, PF_GLUE);
@@ -843,9 +877,9 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   // z = w * v_X + x  (prover.rs:503-516)
   const uint64_t z_len = w_len + X;
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::z_poly_kernel, z_len, S[7], (const Fr*)pk.w.fr(), (u64)w_len, (u64)X, (const Fr*)pk.xpoly.fr(), (u64)X); }
-  // q_1 (prover.rs:520-547): four forward transforms on the 4H domain, pointwise, one inverse
+  // q_1 (prover.rs:520-547): forward transforms on the 4H domain (summed_z_m's is known, see above), pointwise, one inverse
   MH_TRY(zero_tail(c, S[5], H, H4)); MH_TRY(ntt_device(c, S[5], S[0], lg4H, 0));         // r_alpha
-  MH_TRY(zero_tail(c, S[3], zc_len, H4)); MH_TRY(ntt_device(c, S[3], S[1], lg4H, 0));    // summed_z_m
+  // summed_z_m: already in S[1]
   MH_TRY(zero_tail(c, S[7], z_len, H4)); MH_TRY(ntt_device(c, S[7], S[2], lg4H, 0));     // z
   MH_TRY(d2d(c, S[6], pk.t.fr(), H)); MH_TRY(zero_tail(c, S[6], H, H4)); MH_TRY(ntt_device(c, S[6], S[4], lg4H, 0));   // t
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_sub_mul_kernel, H4, S[0], (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2], (const Fr*)S[4], (u64)H4); }
@@ -873,15 +907,16 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   while (v_h(beta).is_zero()) beta = fs.rand_fr();                              // verifier.rs:82-91
 
   // ---------------- third round (prover.rs:588-706) ----------------------------------------------------------
-  const uint32_t lg2K = lgK + 1; const uint64_t K2 = 2 * K;
   HFr vH_beta = v_h(beta);
   HFr vv = vH_alpha * vH_beta;
   HFr ea = eta_a * vv, eb = eta_b * vv, ec = eta_c * vv;
-  MH_TRY(lincomb(c, S[0], K, {{pk.p_a_val.fr(), K, ea}, {pk.p_b_val.fr(), K, eb}, {pk.p_c_val.fr(), K, ec}}));    // a_poly
+  // The reference interpolates b (655) and f (681) from their evaluations on K, multiplies them through three
+  // transforms of size 2K (685) and divides a - b f by v_K (686).  The quotient h_2 is the same polynomial whichever way
+  // it is computed, and a - b f vanishes on K by construction of f (f(k) = a(k) / b(k)), so here it is evaluated on the
+  // coset g K, where v_K is the constant g^K - 1:  a = sum_M e_M val_M and b = alpha beta - alpha row - beta col + row_col
+  // are combinations of index polynomials whose coset evaluations are part of the key, f needs one forward transform,
+  // h_2 one inverse -- three transforms of size K instead of two of size K and three of size 2K.
   HFr alpha_beta = alpha * beta;
-  { ProfScope ps(c, PF_GLUE);
-    KLAUNCH(poly::b_evals_kernel, K, S[1], (const Fr*)pk.ev_row.p, (const Fr*)pk.ev_col.p, (const Fr*)pk.ev_row_col.p, arg(alpha), arg(beta), arg(alpha_beta), (u64)K); }
-  MH_TRY(ntt_device(c, S[1], S[2], lgK, 1));                                    // b_poly
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::denom_kernel, K, S[1], (const Fr*)pk.ev_row.p, (const Fr*)pk.ev_col.p, arg(alpha), arg(beta), (u64)K);
     KLAUNCH(poly::batch_inverse_kernel, (K + poly::INV_CH - 1) / poly::INV_CH, S[1], S[3], (u64)K, arg(HFr::one()), 0);
@@ -889,13 +924,17 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   MH_TRY(ntt_device(c, S[3], S[4], lgK, 1));                                    // f
   MH_TRY(d2d(c, pk.g2.fr(), S[4] + 1, K - 1));                                  // g_2 = f / X
   const uint64_t g2_len = K - 1;
-  MH_TRY(zero_tail(c, S[2], K, K2)); MH_TRY(ntt_device(c, S[2], S[5], lg2K, 0));
-  MH_TRY(zero_tail(c, S[4], K, K2)); MH_TRY(ntt_device(c, S[4], S[6], lg2K, 0));
-  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_kernel, K2, S[5], (const Fr*)S[5], (const Fr*)S[6], (u64)K2); }
-  MH_TRY(ntt_device(c, S[5], S[6], lg2K, 1));                                   // b * f
-  HFr minus_one = HFr::one().neg();
-  MH_TRY(lincomb(c, S[5], K2, {{S[0], K, HFr::one()}, {S[6], K2, minus_one}}));    // a - b f
-  MH_TRY(div_vanishing(c, pk.h2.fr(), S[5], K2, K, S[7]));                         // h_2
+  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, K, S[5], (const Fr*)S[4], (const Fr*)pk.gpow_hi.p, (const Fr*)pk.gpow_lo.p, (u64)K); }
+  MH_TRY(ntt_device(c, S[5], S[6], lgK, 0));                                    // f on g K
+  {
+    HFr vk_inv = (pk.coset_g.pow_u64(K) - HFr::one()).inv();
+    ProfScope ps(c, PF_GLUE);
+    KLAUNCH(poly::h2_coset_kernel, K, S[5], (const Fr*)S[6], (const Fr*)pk.cs_val_a.p, (const Fr*)pk.cs_val_b.p, (const Fr*)pk.cs_val_c.p,
+            (const Fr*)pk.cs_row.p, (const Fr*)pk.cs_col.p, (const Fr*)pk.cs_row_col.p, arg(ea), arg(eb), arg(ec), arg(alpha), arg(beta),
+            arg(alpha_beta), arg(vk_inv), (u64)K);
+  }
+  MH_TRY(ntt_device(c, S[5], S[6], lgK, 1));
+  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, K, pk.h2.fr(), (const Fr*)S[6], (const Fr*)pk.ginv_hi.p, (const Fr*)pk.ginv_lo.p, (u64)K); }
   const uint64_t h2_len = K - 1;
   tr.mark("AHP::Prover::ThirdRound");
   std::vector<fsh::Commitment> cm3; std::vector<PolyRand> rd3;
