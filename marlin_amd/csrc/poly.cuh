@@ -175,6 +175,38 @@ __global__ __launch_bounds__(TPB) void batch_inverse_kernel(Fr* __restrict__ dat
   }
 }
 
+// Two-level variant for large n: thread t of a block walks the elements base + t + TPB * j (coalesced), the per-thread
+// totals are inverted by batch_inverse_kernel (a factor INV_CH fewer Fermat inversions), and a backward sweep applies them.
+// scratch: n elements; totals: one per thread.
+__global__ __launch_bounds__(TPB) void binv_fwd_kernel(const Fr* __restrict__ data, Fr* __restrict__ scratch, Fr* __restrict__ totals, u64 n) {
+  const u64 base = (u64)blockIdx.x * (TPB * INV_CH) + threadIdx.x;
+  Fr acc = Fr::one();
+  for (int j = 0; j < INV_CH; j++) {
+    const u64 i = base + (u64)TPB * j;
+    if (i >= n) break;
+    Fr v = ff_load(data + i);
+    ff_store(scratch + i, acc);
+    if (!v.is_zero()) acc = ff_mul(acc, v);
+  }
+  ff_store(totals + (u64)blockIdx.x * TPB + threadIdx.x, acc);
+}
+__global__ __launch_bounds__(TPB) void binv_bwd_kernel(Fr* __restrict__ data, const Fr* __restrict__ scratch,
+                                                       const Fr* __restrict__ inv_totals, u64 n, FrArg scale, int do_scale) {
+  const u64 base = (u64)blockIdx.x * (TPB * INV_CH) + threadIdx.x;
+  if (base >= n) return;
+  Fr inv = ff_load(inv_totals + (u64)blockIdx.x * TPB + threadIdx.x);
+  if (do_scale) inv = ff_mul(inv, scale.v);
+  int last = (int)((n - 1 - base) / TPB);
+  if (last > INV_CH - 1) last = INV_CH - 1;
+  for (int j = last; j >= 0; j--) {
+    const u64 i = base + (u64)TPB * j;
+    Fr v = ff_load(data + i);
+    if (v.is_zero()) continue;
+    ff_store(data + i, ff_mul(inv, ff_load(scratch + i)));
+    inv = ff_mul(inv, v);
+  }
+}
+
 // b evals on K (prover.rs:650-654): alpha*beta - alpha*row - beta*col + row_col
 __global__ __launch_bounds__(TPB) void b_evals_kernel(Fr* __restrict__ out, const Fr* __restrict__ row,
                                                       const Fr* __restrict__ col, const Fr* __restrict__ row_col,

@@ -123,6 +123,24 @@ int get_fr(Context& c, HFr* out, const Fr* src) {
   return MH_OK;
 }
 
+// ark_ff::batch_inversion (+ optional scaling) of n elements in place; scratch: n + n / 16 + 64 elements
+int batch_inverse(Context& c, Fr* data, Fr* scratch, uint64_t n, const HFr& scale, int do_scale) {
+  ProfScope ps(c, PF_GLUE);
+  const uint64_t tile = (uint64_t)poly::TPB * poly::INV_CH;
+  if (n < 4 * tile) {
+    KLAUNCH(poly::batch_inverse_kernel, (n + poly::INV_CH - 1) / poly::INV_CH, data, scratch, (u64)n, arg(scale), do_scale);
+    return MH_OK;
+  }
+  const uint64_t nblk = (n + tile - 1) / tile, nt = nblk * poly::TPB;
+  Fr* totals = scratch + n;
+  Fr* scratch2 = totals + nt;
+  hipLaunchKernelGGL(poly::binv_fwd_kernel, dim3((unsigned)nblk), dim3(poly::TPB), 0, c.stream, (const Fr*)data, scratch, totals, (u64)n);
+  KLAUNCH(poly::batch_inverse_kernel, (nt + poly::INV_CH - 1) / poly::INV_CH, totals, scratch2, (u64)nt, arg(HFr::one()), 0);
+  hipLaunchKernelGGL(poly::binv_bwd_kernel, dim3((unsigned)nblk), dim3(poly::TPB), 0, c.stream, data, (const Fr*)scratch, (const Fr*)totals,
+                     (u64)n, arg(scale), do_scale);
+  return MH_OK;
+}
+
 struct Term { const Fr* p; uint64_t len; HFr coef; };
 int lincomb(Context& c, Fr* out, uint64_t n, const std::vector<Term>& terms) {
   poly::LinComb lc;
@@ -863,7 +881,8 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   HFr vH_alpha = v_h(alpha);
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::x_minus_elements_kernel, H, S[4], tw, arg(alpha), lgH);
-    KLAUNCH(poly::batch_inverse_kernel, (H + poly::INV_CH - 1) / poly::INV_CH, S[4], S[5], (u64)H, arg(vH_alpha), 1); }
+  }
+  MH_TRY(batch_inverse(c, S[4], S[5], H, vH_alpha, 1));
   MH_TRY(ntt_device(c, S[4], S[5], lgH, 1));                                 // r_alpha_poly
   // t (prover.rs:411-428)
   { ProfScope ps(c, PF_GLUE);
@@ -919,7 +938,9 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   HFr alpha_beta = alpha * beta;
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::denom_kernel, K, S[1], (const Fr*)pk.ev_row.p, (const Fr*)pk.ev_col.p, arg(alpha), arg(beta), (u64)K);
-    KLAUNCH(poly::batch_inverse_kernel, (K + poly::INV_CH - 1) / poly::INV_CH, S[1], S[3], (u64)K, arg(HFr::one()), 0);
+  }
+  MH_TRY(batch_inverse(c, S[1], S[3], K, HFr::one(), 0));
+  { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::f_evals_kernel, K, S[3], (const Fr*)S[1], (const Fr*)pk.ev_val_a.p, (const Fr*)pk.ev_val_b.p, (const Fr*)pk.ev_val_c.p, arg(ea), arg(eb), arg(ec), (u64)K); }
   MH_TRY(ntt_device(c, S[3], S[4], lgK, 1));                                    // f
   MH_TRY(d2d(c, pk.g2.fr(), S[4] + 1, K - 1));                                  // g_2 = f / X
