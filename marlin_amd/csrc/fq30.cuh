@@ -28,9 +28,10 @@ struct Fq30 {
 };
 
 constexpr u32 M30 = (1u << 30) - 1;
+#include "fq30_mul_gen.inc"
 
 // Montgomery reduction of a double-length value given as 2 NL normalised 30-bit limbs: t / R' mod p, lazily reduced.
-__device__ __forceinline__ Fq30 f30_redc(const u32* t) {
+__device__ __forceinline__ Fq30 f30_redc_cxx(const u32* t) {
   constexpr int NL = Fq30::NL;
   using PP = Fq30Params;
   u32 m[NL];
@@ -58,7 +59,7 @@ __device__ __forceinline__ Fq30 f30_redc(const u32* t) {
 }
 
 // a * b / R' mod p, lazily reduced: for a, b < 20 p the result is < 2 p.  Limbs of a and b must be < 2^30.
-__device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
+__device__ __forceinline__ Fq30 f30_mul_cxx(const Fq30& a, const Fq30& b) {
   constexpr int NL = Fq30::NL;
   u32 t[2 * NL];
   u64 acc = 0;
@@ -71,10 +72,10 @@ __device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
     acc >>= 30;
   }
   t[2 * NL - 1] = (u32)acc;
-  return f30_redc(t);
+  return f30_redc_cxx(t);
 }
 // a^2 / R': the cross products once, against the doubled limbs (2 a_i < 2^31: a column still sums to < 2^64)
-__device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
+__device__ __forceinline__ Fq30 f30_sqr_cxx(const Fq30& a) {
   constexpr int NL = Fq30::NL;
   u32 a2[NL];
 #pragma unroll
@@ -90,7 +91,31 @@ __device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
     acc >>= 30;
   }
   t[2 * NL - 1] = (u32)acc;
-  return f30_redc(t);
+  return f30_redc_cxx(t);
+}
+
+// The versions the kernels use: the same column sums and reduction, generated with ONE inline-asm statement of
+// v_mad_u64_u32 per column (fq30_mul_gen.inc): hipcc otherwise splits every column into several accumulator chains and
+// joins them with ~40 extra 64-bit additions per multiplication.  Limb-for-limb identical to the *_cxx versions
+// (checked by mh_selftest_fq30).
+#ifdef MH_CURVE_BN254
+#define F30_GEN(fn) fn##_BN254
+#else
+#define F30_GEN(fn) fn##_BLS12_381
+#endif
+__device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
+  u32 t[2 * Fq30::NL];
+  Fq30 r;
+  F30_GEN(f30_cols_mul)(t, a.v, b.v);
+  F30_GEN(f30_redc)(r.v, t);
+  return r;
+}
+__device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
+  u32 t[2 * Fq30::NL];
+  Fq30 r;
+  F30_GEN(f30_cols_sqr)(t, a.v);
+  F30_GEN(f30_redc)(r.v, t);
+  return r;
 }
 
 // a + b (no reduction)

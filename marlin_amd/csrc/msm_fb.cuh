@@ -583,6 +583,10 @@ __global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ 
   auto same = [&](const Fq& x, const Fq& y) { for (int k = 0; k < Fq::N; k++) ok = ok && x.v[k] == y.v[k]; };
   const Fq30 c30 = f30_mul(a30, b30);
   same(f30_to_fq(c30), ff_mul(a, b));
+  {
+    const Fq30 cx = f30_mul_cxx(a30, b30), sx = f30_sqr_cxx(a30), sg = f30_sqr(a30);
+    for (int k = 0; k < Fq30::NL; k++) ok = ok && cx.v[k] == c30.v[k] && sx.v[k] == sg.v[k];
+  }
   same(f30_to_fq(f30_sub<2>(f30_add(c30, a30), a30)), ff_mul(a, b));
   same(f30_to_fq(f30_mul(f30_sub<2>(a30, b30), f30_add(a30, b30))), f30_to_fq(f30_sub<2>(f30_sqr(a30), f30_sqr(b30))));
   same(f30_to_fq(f30_sqr(a30)), ff_sqr(a));

@@ -79,9 +79,11 @@ def test_fq30_constants_are_current_and_consistent(tmp_path):
     import sys
     csrc = os.path.join(ROOT, "marlin_amd", "csrc")
     out = tmp_path / "fq30.inc"
-    subprocess.run([sys.executable, os.path.join(csrc, "gen_fq30.py"), str(out)], check=True)
+    out2 = tmp_path / "fq30_mul.inc"
+    subprocess.run([sys.executable, os.path.join(csrc, "gen_fq30.py"), str(out), str(out2)], check=True)
     txt = out.read_text()
     assert txt == open(os.path.join(csrc, "fq30_consts.inc")).read()
+    assert out2.read_text() == open(os.path.join(csrc, "fq30_mul_gen.inc")).read()
 
     def arr(block, name):
         m = re.search(r"%s\[\d+\] = \{([^}]*)\}" % name, block)

@@ -83,6 +83,55 @@ __global__ void k_ffadd(F* out, const F* in, int iters) {
   ff_store(out + tid, x);
 }
 #include "../marlin_amd/csrc/fq30.cuh"
+// experiment: the same multiplication with every product issued as an inline-asm v_mad_u64_u32 on ONE accumulator per
+// column (hipcc otherwise splits the column sums into several chains and adds them up with v_lshl_add_u64)
+__device__ __forceinline__ void mad64(u64& acc, u32 a, u32 b) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void mad64s(u64& acc, u32 a, u32 k) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc");
+}
+__device__ __forceinline__ Fq30 f30_mul_asm(const Fq30& a, const Fq30& b) {
+  constexpr int NL = Fq30::NL;
+  using PP = Fq30Params;
+  u32 t[2 * NL];
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) mad64(acc, a.v[i], b.v[k - i]);
+    t[k] = (u32)acc & M30;
+    acc >>= 30;
+  }
+  t[2 * NL - 1] = (u32)acc;
+  u32 m[NL];
+  Fq30 r;
+  acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    acc += t[k];
+#pragma unroll
+    for (int i = 0; i < k; i++) mad64s(acc, m[i], PP::P[k - i]);
+    m[k] = ((u32)acc * PP::PINV) & M30;
+    mad64s(acc, m[k], PP::P[0]);
+    acc >>= 30;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL; k++) {
+    acc += t[k];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) mad64s(acc, m[i], PP::P[k - i]);
+    if (k < 2 * NL - 1) { r.v[k - NL] = (u32)acc & M30; acc >>= 30; }
+    else r.v[k - NL] = (u32)acc;
+  }
+  return r;
+}
+__global__ void k_mul30asm(Fq30* out, const Fq* in, int iters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  Fq30 x = f30_split(ff_load(in + tid)), y = f30_split(ff_load(in + tid + 1));
+  for (int it = 0; it < iters; it++) { Fq30 z = f30_mul_asm(x, y); y = x; x = z; }
+  out[tid] = x;
+}
 __global__ void k_mul30(Fq30* out, const Fq* in, int iters) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   Fq30 x = f30_split(ff_load(in + tid)), y = f30_split(ff_load(in + tid + 1));
@@ -174,6 +223,8 @@ int main() {
   printf("Fq add+sub           : %8.3f ms  %8.2f Gpair/s\n", ms, (double)nthreads * it / ms / 1e6);
   ms = timeit(k_mul30, dim3(blocks), dim3(threads), 3, (Fq30*)dout, (const Fq*)din, it);
   printf("Fq 13x30-bit lazy mul: %8.3f ms  %8.2f Gmul/s\n", ms, (double)nthreads * it / ms / 1e6);
+  ms = timeit(k_mul30asm, dim3(blocks), dim3(threads), 3, (Fq30*)dout, (const Fq*)din, it);
+  printf("Fq 13x30 mul, asm mads: %8.3f ms  %8.2f Gmul/s\n", ms, (double)nthreads * it / ms / 1e6);
   ms = timeit(k_addsub30, dim3(blocks), dim3(threads), 3, (Fq30*)dout, (const Fq*)din, it);
   printf("Fq30 add+sub+mul     : %8.3f ms  %8.2f Gtriple/s\n", ms, (double)nthreads * it / ms / 1e6);
   {
