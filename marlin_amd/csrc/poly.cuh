@@ -94,6 +94,13 @@ __global__ __launch_bounds__(TPB) void h2_coset_kernel(Fr* __restrict__ out, con
   ff_store(out + i, ff_mul(ff_sub(a, ff_mul(b, ff_load(f + i))), scale.v));
 }
 
+// dst[off + i] += v[i]: folds a second coefficient vector, whose bases are the same SRS shifted by `off`, into one MSM
+__global__ __launch_bounds__(TPB) void add_shifted_kernel(Fr* __restrict__ dst, const Fr* __restrict__ v, u64 off, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ff_store(dst + off + i, ff_add(ff_load(dst + off + i), ff_load(v + i)));
+}
+
 // out[i] = s * a[i]
 __global__ __launch_bounds__(TPB) void scale_kernel(Fr* __restrict__ out, const Fr* __restrict__ a, FrArg s, u64 n) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1053,11 +1053,35 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   std::vector<HFr> srw; host_axpy(srw, xi_pow(1), host_div_linear(rd_g1.shifted.blind, beta));
   std::future<HG1> f_rw, f_srw = std::async(std::launch::async, small_msm, (const HG1Affine*)pk.gamma_g, std::cref(srw));
   if (r_nonzero) f_rw = std::async(std::launch::async, small_msm, (const HG1Affine*)pk.gamma_g, std::cref(rw));
-  std::vector<HG1> om;
+  // The reference multiplies witness and shifted witness separately (kzg10::open on powers and on shifted_powers) and
+  // adds the two commitments (marlin_pc open: w = w + shifted_w).  shifted_powers(d) is the same SRS array from index
+  // max_degree - d, so the sum is ONE multi-scalar multiplication with the shifted witness's coefficients added at
+  // that offset: at gamma the offset is max_degree - (K - 2) (1 for this circuit: the two 4M-point MSMs collapse into
+  // one), at beta the ranges do not overlap but one job replaces two.
+  const uint64_t off_b = pk.srs_max_degree - (H - 2), off_g = pk.srs_max_degree - (K - 2);
+  const uint64_t wb_len = mask_len - 1, swb_len = g1_len - 1, wg_len = K - 1, swg_len = g2_len - 1;
+  const uint64_t mb_len = std::max(wb_len, off_b + swb_len), mg_len = std::max(wg_len, off_g + swg_len);
+  // (an SRS much larger than this index needs puts the shifted range beyond the scratch vectors: then the two stay apart)
+  const bool merge_b = mb_len <= pk.S[1].bytes / 32, merge_g = mg_len <= pk.S[5].bytes / 32;
+  if (merge_b) MH_TRY(zero_tail(c, S[1], wb_len, mb_len));
+  if (merge_g) MH_TRY(zero_tail(c, S[5], wg_len, mg_len));
+  { ProfScope ps(c, PF_GLUE);
+    if (merge_b) KLAUNCH(poly::add_shifted_kernel, swb_len, S[1], (const Fr*)S[4], (u64)off_b, (u64)swb_len);
+    if (merge_g) KLAUNCH(poly::add_shifted_kernel, swg_len, S[5], (const Fr*)S[6], (u64)off_g, (u64)swg_len); }
+  std::vector<HG1> om;                       // [0] witness at beta (+ shifted), [1] witness at gamma (+ shifted)
   {
-    int rc_batch = sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts + (pk.srs_max_degree - (H - 2)) * PT_B, S[4], g1_len - 1},
-                                         {srs_pts, S[5], K - 1}, {srs_pts + (pk.srs_max_degree - (K - 2)) * PT_B, S[6], g2_len - 1}}, om);
+    std::vector<MsmJob> jobs;
+    jobs.push_back({srs_pts, S[1], merge_b ? mb_len : wb_len});
+    jobs.push_back({srs_pts, S[5], merge_g ? mg_len : wg_len});
+    if (!merge_b) jobs.push_back({srs_pts + off_b * PT_B, S[4], swb_len});
+    if (!merge_g) jobs.push_back({srs_pts + off_g * PT_B, S[6], swg_len});
+    std::vector<HG1> res;
+    int rc_batch = sharded_msm_batch(c, jobs, res);
     if (rc_batch != MH_OK) { f_srw.wait(); if (f_rw.valid()) f_rw.wait(); return rc_batch; }
+    om = {res[0], res[1]};
+    size_t nx = 2;
+    if (!merge_b) om[0] = om[0].add(res[nx++]);
+    if (!merge_g) om[1] = om[1].add(res[nx++]);
   }
   {
     HG1 wacc = om[0];
@@ -1065,7 +1089,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
       wacc = wacc.add(f_rw.get());
       rv_beta = host_eval(r, beta); has_rv_beta = true;
     }
-    HG1 sw = om[1];
+    HG1 sw = HG1::identity();     // the device part of the shifted witness is inside om[0]
     // open_with_witness_polynomial(shifted_powers, point, shifted_r, shifted_w, Some(shifted_r_witness)):
     // the hiding witness is always Some(..) on this path, so random_v is always Some(shifted_r(point))
     std::vector<HFr> sr; host_axpy(sr, xi_pow(1), rd_g1.shifted.blind);
@@ -1076,7 +1100,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     }
     w_beta = wacc.add(sw).to_affine();
   }
-  w_gamma = om[2].add(om[3]).to_affine();
+  w_gamma = om[1].to_affine();
   // at gamma nothing is hiding, but the degree-bounded g_2 goes through open_with_witness_polynomial with
   // Some(empty witness): random_v = Some(0) [ark-poly-commit marlin_pc::open, SURVEY B-4]
   has_rv_gamma = true;
