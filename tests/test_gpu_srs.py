@@ -57,3 +57,40 @@ def test_commit_full_size_properties(gpu, log_n):
     hi = sc.copy(); hi[:, :2] = 0
     s = EC.add(jac_np_to_affine(gpu.msm(B, lo, montgomery=False)), jac_np_to_affine(gpu.msm(B, hi, montgomery=False)))
     assert full is not None and EC.is_on_curve(full) and full == s
+
+
+@pytest.mark.parametrize("log_n", [13, 20, 22])
+def test_fixed_base_commit_full_size(gpu, log_n):
+    """the same known-tau and linearity properties through the fixed-base path (window table with the automatic width:
+    12 / 19 / 20 bits), plus equality with the variable-base result on dense scalars and on a vector with a long zero
+    gap (the shape of an opening proof's merged witness)."""
+    n = 1 << log_n
+    r = F.R_MOD
+    B = gpu.Bases.srs_powers(fr_to_np([TAU])[0], n)
+    rng = np.random.default_rng(100 + log_n)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 61) - 1)
+    gap = sc.copy(); gap[n // 4: 3 * n // 4] = 0
+    vb_full = jac_np_to_affine(gpu.msm(B, sc, montgomery=False))
+    vb_gap = jac_np_to_affine(gpu.msm(B, gap, montgomery=False))
+    B.precompute()
+    assert B.table_info()[0] == min(20, log_n - 1)
+    fb0, vb0 = gpu.msm_path_counts()
+    assert jac_np_to_affine(gpu.msm(B, sc, montgomery=False)) == vb_full
+    assert jac_np_to_affine(gpu.msm(B, gap, montgomery=False)) == vb_gap
+    idx = [0, 1, 2, n // 3, n // 2 + 1, n - 2, n - 1]
+    vals = rand_fr(len(idx), 5)
+    # a sparse vector is too lightly loaded for the shared bucket set and takes the variable-base path; a dense one with
+    # known structure exercises the table: p(X) = sum_i c X^i has p(tau) = c (tau^n - 1) / (tau - 1)
+    cval = vals[0]
+    const = np.tile(fr_to_np([cval]), (n, 1))
+    want = cval * (pow(TAU, n, r) - 1) * pow(TAU - 1, -1, r) % r
+    got = jac_np_to_affine(gpu.msm(B, const))
+    assert got == EC.scalar_mul(EC.G1_GEN, want)
+    # halves
+    lo = sc.copy(); lo[n // 2:] = 0
+    hi = sc.copy(); hi[:n // 2] = 0
+    s = EC.add(jac_np_to_affine(gpu.msm(B, lo, montgomery=False)), jac_np_to_affine(gpu.msm(B, hi, montgomery=False)))
+    assert s == vb_full
+    fb1, vb1 = gpu.msm_path_counts()
+    assert fb1 - fb0 >= 4          # dense, gap and the halves ran on the table (the constant vector is skewed -> fallback)
