@@ -235,10 +235,10 @@ def main():
             traffic = json.load(open(pmc)).get("msm_accum_bytes_per_launch")
         except Exception:
             traffic = None
-    # NTT bytes: the transforms this workload executes (the prover runs 17 of the reference's 30, see workload.ntt_executed)
+    # NTT bytes: the transforms this workload executes (the prover runs 16 of the reference's 30, see workload.ntt_executed)
     if workload == "marlin-prove":
         from marlin_amd import workload as _W
-        ntt_bytes, ntt_what = _W.executed_ntt_bytes(wl.N), "17 executed transforms (64 B per point; the reference's 30 would be %.2f GB)" % (wl.alg_ntt_bytes / 1e9)
+        ntt_bytes, ntt_what = _W.executed_ntt_bytes(wl.N), "16 executed transforms (64 B per point; the reference's 30 would be %.2f GB)" % (wl.alg_ntt_bytes / 1e9)
     else:
         ntt_bytes, ntt_what = wl.alg_ntt_bytes, "30 transforms of the inventory (64 B per point)"
     # secondary view: the kernel's real bound is VALU issue.  The window plan issues W bucket additions per input pair

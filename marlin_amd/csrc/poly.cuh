@@ -138,6 +138,34 @@ __global__ __launch_bounds__(TPB) void spmv_kernel(Fr* __restrict__ out, const u
   ff_store(out + r, acc);
 }
 
+// p[0] -= r, p[n] = r: adds r * (X^n - 1) to a polynomial with n coefficients (the hiding term r * v_H of
+// prover.rs:352,360,366) without a host round trip
+__global__ void blind_vanishing_kernel(Fr* __restrict__ p, u64 n, FrArg r) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ff_store(p, ff_sub(ff_load(p), r.v));
+    ff_store(p + n, r.v);
+  }
+}
+
+// out[i] = sum_k coef[k] omega^(i k), i < n = 2^log_n, for a polynomial with few coefficients (x_poly of a small public
+// input, prover.rs:326): Horner at omega^i instead of a size-n transform
+__global__ __launch_bounds__(TPB) void eval_small_poly_kernel(Fr* __restrict__ out, const Fr* __restrict__ coef, u32 ncoef,
+                                                              const Fr* __restrict__ tw, u32 log_n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 n = 1ull << log_n;
+  if (i >= n) return;
+  Fr w;
+  if (log_n == 0) w = Fr::one();
+  else {
+    u64 half = n >> 1;
+    w = ff_load(tw + half + (i & (half - 1)));
+    if (i >= half) w = ff_neg(w);
+  }
+  Fr acc = ff_load(coef + ncoef - 1);
+  for (u32 k = ncoef - 1; k-- > 0;) acc = ff_add(ff_mul(acc, w), ff_load(coef + k));
+  ff_store(out + i, acc);
+}
+
 // out[i] = x - omega^i, i < n (n = 2^log_n), omega^i read from the NTT twiddle table (level log_n
 // holds omega^e for e < n/2; omega^(e + n/2) = -omega^e).     (mod.rs:313: elements().map(|y| x - y))
 __global__ __launch_bounds__(TPB) void x_minus_elements_kernel(Fr* __restrict__ out, const Fr* __restrict__ tw,

@@ -819,24 +819,25 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   tr.mark("AHP::Prover::Init (z_A, z_B)");
   // ---------------- first round (prover.rs:309-409) -----------------------------------------------------------
   MH_TRY(ntt_device(c, pk.z.fr(), pk.xpoly.fr(), lgX, 1));              // x_poly = interpolate(formatted input)
-  MH_TRY(d2d(c, S[0], pk.xpoly.fr(), X)); MH_TRY(zero_tail(c, S[0], X, H));
-  MH_TRY(ntt_device(c, S[0], S[1], lgH, 0));                            // x_evals = domain_h.fft(x_poly)
+  if (X <= 16) {                                                        // x_evals = domain_h.fft(x_poly): Horner per point
+    ProfScope ps(c, PF_GLUE);
+    KLAUNCH(poly::eval_small_poly_kernel, H, S[1], (const Fr*)pk.xpoly.fr(), (u32)X, tw, lgH);
+  } else {
+    MH_TRY(d2d(c, S[0], pk.xpoly.fr(), X)); MH_TRY(zero_tail(c, S[0], X, H));
+    MH_TRY(ntt_device(c, S[0], S[1], lgH, 0));
+  }
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::w_evals_kernel, H, S[2], (const Fr*)(pk.z.fr() + X), (u64)nw, (const Fr*)S[1], (u64)H, (u64)(H / X)); }
   MH_TRY(ntt_device(c, S[2], S[3], lgH, 1));
   // + r * v_H: the reference multiplies by FFT (prover.rs:352); the product is exactly [-r, 0.., 0, r]
   HFr r_w = fsh::fr_rand(zk);
-  {
-    HFr c0; MH_TRY(get_fr(c, &c0, S[3])); c0 = c0 - r_w;
-    MH_TRY(set_fr(c, S[3], c0)); MH_TRY(set_fr(c, S[3] + H, r_w));
-  }
+  hipLaunchKernelGGL(poly::blind_vanishing_kernel, dim3(1), dim3(64), 0, c.stream, S[3], (u64)H, arg(r_w));
   const uint64_t w_len = H + 1 - X;                                       // (w + r v_H) / v_X, remainder zero
   MH_TRY(div_vanishing(c, pk.w.fr(), S[3], H + 1, X, S[4]));
   auto blind_h = [&](Fr* dst, const Fr* evals, HFr* r_out) -> int {
     MH_TRY(ntt_device(c, evals, dst, lgH, 1));
     HFr r = fsh::fr_rand(zk); *r_out = r;
-    HFr c0; MH_TRY(get_fr(c, &c0, dst)); c0 = c0 - r;
-    MH_TRY(set_fr(c, dst, c0)); MH_TRY(set_fr(c, dst + H, r));
+    hipLaunchKernelGGL(poly::blind_vanishing_kernel, dim3(1), dim3(64), 0, c.stream, dst, (u64)H, arg(r));
     return MH_OK;
   };
   HFr r_za, r_zb;

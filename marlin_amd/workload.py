@@ -34,19 +34,21 @@ def ntt_inventory(H, K=None, X=2):
 
 
 def ntt_executed(H, K=None, X=2):
-    """[(log2 size, inverse?, what)]: the transforms mh_marlin_prove actually runs for the same proof (17 of the 30).
+    """[(log2 size, inverse?, what)]: the transforms mh_marlin_prove actually runs for the same proof (16 of the 30).
     Not executed, with identical outputs: the nine 2H transforms behind `const * v_H` (the product is known in closed
     form); the inverse of z_a*z_b and the forward transform of summed_z_m on the same 4H domain (they cancel: the
     evaluations are eta_c z_a z_b + eta_a z_a + eta_b z_b pointwise); the interpolation of b and the three 2K transforms
-    of b*f -- h_2 is evaluated on the coset g K instead (one forward and one inverse transform of size K)."""
+    of b*f -- h_2 is evaluated on the coset g K instead (one forward and one inverse transform of size K); the H-point
+    evaluation of x_poly when the public input has at most 16 elements (Horner per point)."""
     K = 4 * H if K is None else K
     lg = lambda n: n.bit_length() - 1
-    ex = [(lg(X), True, "x_poly"), (lg(H), False, "x_evals"), (lg(H), True, "w"), (lg(H), True, "z_a"), (lg(H), True, "z_b")]
+    ex = [(lg(X), True, "x_poly")] + ([(lg(H), False, "x_evals")] if X > 16 else [])
+    ex += [(lg(H), True, "w"), (lg(H), True, "z_a"), (lg(H), True, "z_b")]
     ex += [(lg(4 * H), False, "z_a on 4H"), (lg(4 * H), False, "z_b on 4H"), (lg(H), True, "r_alpha"), (lg(H), True, "t"),
            (lg(X), True, "x_poly")]
     ex += [(lg(4 * H), False, "r_alpha on 4H"), (lg(4 * H), False, "z on 4H"), (lg(4 * H), False, "t on 4H"), (lg(4 * H), True, "rhs")]
     ex += [(lg(K), True, "f"), (lg(K), False, "f on the coset g K"), (lg(K), True, "h_2 from the coset g K")]
-    assert len(ex) == 17
+    assert len(ex) == (17 if X > 16 else 16)
     return ex
 
 
