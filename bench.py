@@ -222,7 +222,7 @@ def main():
     glue_ms, _ = M.prof_get(3)
     # pairs the timed launches really process: the prover folds each opening's shifted witness into the witness MSM
     from marlin_amd import workload as W
-    msms_run = W.msm_executed(wl.N) if workload == "marlin-prove" and args.pc == "marlin" else wl.msms
+    msms_run = W.msm_executed(wl.N, pc=args.pc) if workload == "marlin-prove" else wl.msms
     msm_pairs_rank = sum((abs(n) * (rank + 1)) // world - (abs(n) * rank) // world for n, _ in msms_run)
     # the MSMs of a commit round run as one batched launch: bytes per launch = all pairs of the step / launches of the step
     bytes_per_launch = 128.0 * msm_pairs_rank * args.steps / max(1, acc_launches)

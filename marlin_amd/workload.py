@@ -68,13 +68,17 @@ def msm_inventory(H, K=None, X=2):
     return big, small
 
 
-def msm_executed(H, K=None, X=2):
-    """[(n_pairs, what)]: the large MSMs mh_marlin_prove runs (MarlinKZG10).  The 11 commitments are those of
+def msm_executed(H, K=None, X=2, pc="marlin"):
+    """[(n_pairs, what)]: the large MSMs mh_marlin_prove runs (MarlinKZG10; pc="sonic": SonicKZG10, one commitment per
+    polynomial -- against the shifted powers when degree-bounded -- and one witness MSM per opening point).  The 11 commitments are those of
     msm_inventory; each opening proof is ONE MSM, because the reference's `w + shifted_w` is the multi-scalar product
     of the witness coefficients plus the shifted witness's coefficients at offset max_degree - bound on the same SRS
     (at gamma the offset is 1 for this circuit, so 2 x 4H pairs become 4H)."""
     K = 4 * H if K is None else K
     big, _ = msm_inventory(H, K, X)
+    if pc == "sonic":
+        ex = [b for b in big[:11] if "shifted" not in b[1]]
+        return ex + [(3 * H - 1, "open@beta witness"), (K - 1, "open@gamma witness")]
     D = max(3 * H - 1, K - 1)                     # AHPForR1CS::max_degree for this shape (mod.rs:71-93, zk_bound 1)
     ex = big[:11]
     ex.append((max(3 * H - 1, D - (H - 2) + H - 2), "lib.rs:292 open@beta witness + shifted witness (g_1)"))
