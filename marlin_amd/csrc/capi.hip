@@ -58,17 +58,17 @@ static void plan_passes(uint32_t log_n, uint32_t* bits, int* npass) {
 }
 
 static int launch_pass(Context& c, const Fr* x, Fr* y, uint32_t log_n, uint32_t B, uint32_t logP, uint32_t flags,
-                       const Fr& ninv) {
+                       const Fr& ninv, uint64_t in_len) {
   uint32_t logc = log_n - B;
   if (logc > (uint32_t)ntt::MAX_LOGC) logc = ntt::MAX_LOGC;
   uint64_t blocks = (1ull << (log_n - B)) >> logc;
   size_t lds = ntt::pass_lds_bytes(B, (int)logc);
   dim3 grid((unsigned)blocks), block(ntt::THREADS);
   switch (logc) {
-    case 0: hipLaunchKernelGGL(ntt::pass_kernel<0>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv); break;
-    case 1: hipLaunchKernelGGL(ntt::pass_kernel<1>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv); break;
-    case 2: hipLaunchKernelGGL(ntt::pass_kernel<2>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv); break;
-    default: hipLaunchKernelGGL(ntt::pass_kernel<3>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv); break;
+    case 0: hipLaunchKernelGGL(ntt::pass_kernel<0>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv, (u64)in_len); break;
+    case 1: hipLaunchKernelGGL(ntt::pass_kernel<1>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv, (u64)in_len); break;
+    case 2: hipLaunchKernelGGL(ntt::pass_kernel<2>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv, (u64)in_len); break;
+    default: hipLaunchKernelGGL(ntt::pass_kernel<3>, grid, block, lds, c.stream, x, y, (const Fr*)c.tw, log_n, B, logP, flags, ninv, (u64)in_len); break;
   }
   MH_HIP(hipGetLastError());
   return MH_OK;
@@ -86,12 +86,18 @@ static int ntt_set_attrs() {
   return MH_OK;
 }
 
-// d_in may equal d_out.
 int ntt_device(Context& c, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
+  return ntt_device_len(c, d_in, 1ull << log_n, d_out, log_n, inverse);
+}
+
+// d_in may equal d_out.  d_in holds in_len <= 2^log_n elements, the rest of the domain is zero.
+int ntt_device_len(Context& c, const void* d_in, uint64_t in_len, void* d_out, uint32_t log_n, int inverse) {
   if (log_n > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "log_n exceeds the two-adicity of Fr");
   size_t bytes = (size_t)32 << log_n;
+  if (in_len > (1ull << log_n)) return fail(MH_EINVAL, "ntt: input longer than the domain");
   if (log_n == 0) {
-    if (d_in != d_out) MH_HIP(hipMemcpyAsync(d_out, d_in, 32, hipMemcpyDeviceToDevice, c.stream));
+    if (in_len == 0) MH_HIP(hipMemsetAsync(d_out, 0, 32, c.stream));
+    else if (d_in != d_out) MH_HIP(hipMemcpyAsync(d_out, d_in, 32, hipMemcpyDeviceToDevice, c.stream));
     return MH_OK;
   }
   MH_TRY(ensure_twiddles(c, log_n));
@@ -116,10 +122,10 @@ int ntt_device(Context& c, const void* d_in, void* d_out, uint32_t log_n, int in
     if (p == np - 1 && (const void*)dst == (const void*)src) {
       MH_TRY(c.ntt_tmp[0].ensure(bytes));
       dst = (Fr*)c.ntt_tmp[0].ptr;
-      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, (inverse && p == np - 1) ? 1u : 0u, ninv));
+      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, (inverse && p == np - 1) ? 1u : 0u, ninv, p == 0 ? in_len : (1ull << log_n)));
       MH_HIP(hipMemcpyAsync(d_out, dst, bytes, hipMemcpyDeviceToDevice, c.stream));
     } else {
-      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, (inverse && p == np - 1) ? 1u : 0u, ninv));
+      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, (inverse && p == np - 1) ? 1u : 0u, ninv, p == 0 ? in_len : (1ull << log_n)));
     }
     src = dst;
     logP += bits[p];

@@ -5,6 +5,8 @@
 namespace mh {
 // NTT over Fr on device buffers (d_in may equal d_out); see ntt.cuh.
 int ntt_device(Context& c, const void* d_in, void* d_out, uint32_t log_n, int inverse);
+// the same for an input of in_len <= 2^log_n elements that stands for a zero-padded vector (no padded copy needed)
+int ntt_device_len(Context& c, const void* d_in, uint64_t in_len, void* d_out, uint32_t log_n, int inverse);
 // MSM: d_bases = G1Affine[n] (Montgomery), d_scalars = Fr[n]; out = Jacobian X||Y||Z (18 u64, Montgomery).
 int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mont, size_t n, uint64_t* out_xyz);
 // a batch of independent MSMs through one launch sequence; out_xyz: njobs x 18 limbs

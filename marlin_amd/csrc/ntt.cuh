@@ -61,10 +61,12 @@ __global__ void build_twiddles(Fr* tw, u32 max_log, Fr root32 /* the 2^FR_TWO_AD
 // One Stockham pass.  x, y: n = 2^log_n elements.  B stages, P = 2^logP = product of
 // the previous passes' radices.  flags bit0: this is the last pass of an inverse
 // transform (negate index, multiply by ninv).
+// in_len: elements of x at index >= in_len are read as zero (a shorter coefficient vector transformed on a larger
+// domain needs no padded copy); n for every pass but the first.
 template <int LOGC>
 __global__ __launch_bounds__(THREADS) void pass_kernel(const Fr* __restrict__ x, Fr* __restrict__ y,
                                                        const Fr* __restrict__ tw, u32 log_n, u32 B, u32 logP,
-                                                       u32 flags, Fr ninv) {
+                                                       u32 flags, Fr ninv, u64 in_len) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   constexpr int C = 1 << LOGC;
   const u32 R = 1u << B;
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(THREADS) void pass_kernel(const Fr* __restrict__ x,
   for (u32 idx = tid; idx < (R << LOGC); idx += THREADS) {
     u32 c = idx & (C - 1);
     u32 r = idx >> LOGC;
-    Fr v = ff_load(x + (jbase + c) + (u64)r * stride);
+    const u64 gi = (jbase + c) + (u64)r * stride;
+    Fr v = gi < in_len ? ff_load(x + gi) : Fr::zero();
     u32 rr = B ? (__brev(r) >> (32 - B)) : 0;
     lds_store(smem, lds_index(rr, c, LOGC), v);
   }

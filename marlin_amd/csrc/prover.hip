@@ -869,10 +869,8 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
 
   // ---------------- second round (prover.rs:443-570) ---------------------------------------------------------
   const uint32_t lg4H = lgH + 2; const uint64_t H4 = 4 * H;
-  MH_TRY(d2d(c, S[2], pk.za.fr(), za_len)); MH_TRY(zero_tail(c, S[2], za_len, H4));
-  MH_TRY(d2d(c, S[3], pk.zb.fr(), za_len)); MH_TRY(zero_tail(c, S[3], za_len, H4));
-  MH_TRY(ntt_device(c, S[2], S[0], lg4H, 0));
-  MH_TRY(ntt_device(c, S[3], S[1], lg4H, 0));
+  MH_TRY(ntt_device_len(c, pk.za.fr(), za_len, S[0], lg4H, 0));
+  MH_TRY(ntt_device_len(c, pk.zb.fr(), za_len, S[1], lg4H, 0));
   // The reference forms z_c = z_a * z_b (two forward transforms, a pointwise product, one inverse: prover.rs:467),
   // summed_z_m = eta_a z_a + eta_b z_b + eta_c z_c (468-471), and later evaluates summed_z_m on the same 4H domain
   // (533).  deg z_c = 2H + 2 < 4H, so those evaluations ARE eta_c z_a z_b + eta_a z_a + eta_b z_b pointwise: the inverse
@@ -898,10 +896,10 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   const uint64_t z_len = w_len + X;
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::z_poly_kernel, z_len, S[7], (const Fr*)pk.w.fr(), (u64)w_len, (u64)X, (const Fr*)pk.xpoly.fr(), (u64)X); }
   // q_1 (prover.rs:520-547): forward transforms on the 4H domain (summed_z_m's is known, see above), pointwise, one inverse
-  MH_TRY(zero_tail(c, S[5], H, H4)); MH_TRY(ntt_device(c, S[5], S[0], lg4H, 0));         // r_alpha
+  MH_TRY(ntt_device_len(c, S[5], H, S[0], lg4H, 0));                                     // r_alpha
   // summed_z_m: already in S[1]
-  MH_TRY(zero_tail(c, S[7], z_len, H4)); MH_TRY(ntt_device(c, S[7], S[2], lg4H, 0));     // z
-  MH_TRY(d2d(c, S[6], pk.t.fr(), H)); MH_TRY(zero_tail(c, S[6], H, H4)); MH_TRY(ntt_device(c, S[6], S[4], lg4H, 0));   // t
+  MH_TRY(ntt_device_len(c, S[7], z_len, S[2], lg4H, 0));                                 // z
+  MH_TRY(ntt_device_len(c, pk.t.fr(), H, S[4], lg4H, 0));                                // t
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_sub_mul_kernel, H4, S[0], (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2], (const Fr*)S[4], (u64)H4); }
   MH_TRY(ntt_device(c, S[0], S[1], lg4H, 1));                                  // rhs
   MH_TRY(lincomb(c, S[2], H4, {{pk.mask.fr(), mask_len, HFr::one()}, {S[1], H4, HFr::one()}}));      // q_1 = mask + rhs
