@@ -100,6 +100,16 @@ __global__ __launch_bounds__(TPB) void add_shifted_kernel(Fr* __restrict__ dst, 
   if (i >= n) return;
   ff_store(dst + off + i, ff_add(ff_load(dst + off + i), ff_load(v + i)));
 }
+// dst[off + i] += s * v[i]
+__global__ __launch_bounds__(TPB) void axpy_shifted_kernel(Fr* __restrict__ dst, const Fr* __restrict__ v, FrArg s, u64 off, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ff_store(dst + off + i, ff_add(ff_load(dst + off + i), ff_mul(s.v, ff_load(v + i))));
+}
+// p[0] += v
+__global__ void add_const_kernel(Fr* __restrict__ p, FrArg v) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) ff_store(p, ff_add(ff_load(p), v.v));
+}
 
 // out[i] = s * a[i]
 __global__ __launch_bounds__(TPB) void scale_kernel(Fr* __restrict__ out, const Fr* __restrict__ a, FrArg s, u64 n) {

@@ -1034,10 +1034,22 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   MH_TRY(div_linear(c, S[3], pk.g1.fr(), g1_len, beta, S[2]));                     // degree-bounded g_1: shifted witness
   MH_TRY(lincomb(c, S[4], g1_len - 1, {{S[3], g1_len - 1, xi_pow(1)}}));
   // --- at gamma: labels g_2, inner_sumcheck -> challenges xi^0 (g_2), xi^1 (g_2 shifted), xi^2
+  const uint64_t off_b = pk.srs_max_degree - (H - 2), off_g = pk.srs_max_degree - (K - 2);
+  // When shifted_powers(K - 2) starts at SRS index 1 (max_degree = K - 1, the usual case) the witness plus the shifted
+  // witness moved up by one coefficient is the quotient of ONE polynomial: with C = g_2 + xi^2 inner,
+  //   (C - C(gamma)) / (X - gamma) + X xi (g_2 - g_2(gamma)) / (X - gamma) = quotient(C + xi X g_2) - xi g_2(gamma),
+  // so a single division serves both (the general offset keeps two divisions and adds the vectors).
+  const bool fuse_g = off_g == 1;
   MH_TRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(2)}}));
-  MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
-  MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
-  MH_TRY(lincomb(c, S[6], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
+  if (fuse_g) {
+    { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::axpy_shifted_kernel, g2_len, S[0], (const Fr*)pk.g2.fr(), arg(xi_pow(1)), (u64)1, (u64)g2_len); }
+    MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
+    hipLaunchKernelGGL(poly::add_const_kernel, dim3(1), dim3(64), 0, c.stream, S[5], arg((xi_pow(1) * g2_gamma).neg()));
+  } else {
+    MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
+    MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
+    MH_TRY(lincomb(c, S[6], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
+  }
   // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b); its witness and the shifted
   // one are multiplied on host threads while the device runs the batch
   std::vector<HFr> r;
@@ -1057,16 +1069,15 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   // max_degree - d, so the sum is ONE multi-scalar multiplication with the shifted witness's coefficients added at
   // that offset: at gamma the offset is max_degree - (K - 2) (1 for this circuit: the two 4M-point MSMs collapse into
   // one), at beta the ranges do not overlap but one job replaces two.
-  const uint64_t off_b = pk.srs_max_degree - (H - 2), off_g = pk.srs_max_degree - (K - 2);
   const uint64_t wb_len = mask_len - 1, swb_len = g1_len - 1, wg_len = K - 1, swg_len = g2_len - 1;
   const uint64_t mb_len = std::max(wb_len, off_b + swb_len), mg_len = std::max(wg_len, off_g + swg_len);
   // (an SRS much larger than this index needs puts the shifted range beyond the scratch vectors: then the two stay apart)
-  const bool merge_b = mb_len <= pk.S[1].bytes / 32, merge_g = mg_len <= pk.S[5].bytes / 32;
+  const bool merge_b = mb_len <= pk.S[1].bytes / 32, merge_g = fuse_g || mg_len <= pk.S[5].bytes / 32;
   if (merge_b) MH_TRY(zero_tail(c, S[1], wb_len, mb_len));
-  if (merge_g) MH_TRY(zero_tail(c, S[5], wg_len, mg_len));
+  if (merge_g && !fuse_g) MH_TRY(zero_tail(c, S[5], wg_len, mg_len));
   { ProfScope ps(c, PF_GLUE);
     if (merge_b) KLAUNCH(poly::add_shifted_kernel, swb_len, S[1], (const Fr*)S[4], (u64)off_b, (u64)swb_len);
-    if (merge_g) KLAUNCH(poly::add_shifted_kernel, swg_len, S[5], (const Fr*)S[6], (u64)off_g, (u64)swg_len); }
+    if (merge_g && !fuse_g) KLAUNCH(poly::add_shifted_kernel, swg_len, S[5], (const Fr*)S[6], (u64)off_g, (u64)swg_len); }
   std::vector<HG1> om;                       // [0] witness at beta (+ shifted), [1] witness at gamma (+ shifted)
   {
     std::vector<MsmJob> jobs;
