@@ -1026,7 +1026,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     w_beta = wacc.to_affine();
     w_gamma = om[1].to_affine();          // nothing hiding at gamma: random_v = None
   } else {
-  // The four MSMs of the two opening proofs (witness + shifted witness at beta and at gamma) run as one batch.
+  // The MSMs of the two opening proofs (witness + shifted witness at beta and at gamma, merged below) run as one batch.
   // --- at beta: labels g_1, outer_sumcheck, t, z_b  -> challenges xi^0 (g_1), xi^1 (g_1 shifted), xi^2, xi^3, xi^4
   MH_TRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(2)},
                                      {pk.t.fr(), H, xi_pow(3)}, {pk.zb.fr(), za_len, xi_pow(4)}}));
