@@ -144,6 +144,7 @@ static int msm_set_attrs() {
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::reduce2_30_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   g_msm_attr_done = true;
   return MH_OK;
 }
@@ -288,7 +289,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   while (seg > 4 && (u64)nj * (nbt / seg) < seg_threads) seg >>= 1;
   const u32 nseg = (nbt + seg - 1) / seg;
   const u32 chunks = nseg >= 4096 ? nseg / 256 : 1;                      // reduce2 in two launches when nseg is large
-  MH_TRY(c.msm_seg.ensure((size_t)nj * (nseg + chunks) * sizeof(G1Xyzz)));
+  MH_TRY(c.msm_seg.ensure((size_t)nj * (nseg + chunks) * sizeof(F::G1Xyzz30)));
   MH_TRY(c.msm_win.ensure((size_t)nj * sizeof(G1Xyzz)));
   MH_TRY(c.tr_sums.ensure(64 + F::SIZE_BINS * 4));
   MH_TRY(c.fb_perm.ensure(WB * 4));
@@ -365,14 +366,18 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
                        (const F::G1Aff30*)bs.d_table, (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr,
                        (const u32*)(d_max + 1), (F::G1Xyzz30*)c.msm_buckets.ptr, nb, (u64)WB);
     // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
+    F::G1Xyzz30* seg30 = (F::G1Xyzz30*)c.msm_seg.ptr;
     hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)c.msm_buckets.ptr,
-                       (G1Xyzz*)c.msm_seg.ptr, nbt, nseg, (u32)nj, seg);
+                       seg30, nbt, nseg, (u32)nj, seg);
+    const size_t r2lds = 256 * sizeof(F::G1Xyzz30);
     if (chunks > 1) {
-      G1Xyzz* mid = (G1Xyzz*)c.msm_seg.ptr + (size_t)nj * nseg;
-      hipLaunchKernelGGL(msm::reduce2_kernel, dim3(chunks, nj), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr, mid, nseg);
-      hipLaunchKernelGGL(msm::reduce2_kernel, dim3(1, nj), dim3(256), 0, s, (const G1Xyzz*)mid, (G1Xyzz*)c.msm_win.ptr, chunks);
+      F::G1Xyzz30* mid = seg30 + (size_t)nj * nseg;
+      hipLaunchKernelGGL(F::reduce2_30_kernel, dim3(chunks, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, mid, (G1Xyzz*)nullptr, nseg, 0);
+      hipLaunchKernelGGL(F::reduce2_30_kernel, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)mid, (F::G1Xyzz30*)nullptr,
+                         (G1Xyzz*)c.msm_win.ptr, chunks, 1);
     } else {
-      hipLaunchKernelGGL(msm::reduce2_kernel, dim3(1, nj), dim3(256), 0, s, (const G1Xyzz*)c.msm_seg.ptr, (G1Xyzz*)c.msm_win.ptr, nseg);
+      hipLaunchKernelGGL(F::reduce2_30_kernel, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, (F::G1Xyzz30*)nullptr,
+                         (G1Xyzz*)c.msm_win.ptr, nseg, 1);
     }
     MH_HIP(hipGetLastError());
   }

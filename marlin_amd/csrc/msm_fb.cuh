@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
 // ---- reduce1: thread per (job, segment of `seg` buckets), on 30-bit limbs ------------------------------------------
 // sum_b (b + 1) B_b over the job's single bucket set: running sums inside the segment plus (first bucket index) x
 // (segment total) by double-and-add; the result goes to msm::reduce2_kernel in the standard representation.
-__global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restrict__ buckets, G1Xyzz* __restrict__ segsum, u32 nb,
+__global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restrict__ buckets, G1Xyzz30* __restrict__ segsum, u32 nb,
                                                         u32 nseg, u32 njobs, u32 seg) {
   u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= njobs * nseg) return;
@@ -566,7 +566,42 @@ __global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restri
     }
     x30_add(acc, m);
   }
-  g1_store_xyzz(segsum + gid, x30_to_std(acc));
+  x30_store(segsum + gid, acc);
+}
+
+// ---- reduce2: tree sums of the segment results, still on 30-bit limbs ------------------------------------------------
+// grid (chunks, jobs): block (k, w) sums elements [k * per, (k + 1) * per) of job w's nseg points.  last = 0: writes a
+// 30-bit point to out30[w * chunks + k] (first of two launches when nseg is large); last = 1: converts the sum to the
+// standard representation for the host (out_std[w * chunks + k]).
+__global__ __launch_bounds__(256) void reduce2_30_kernel(const G1Xyzz30* __restrict__ in, G1Xyzz30* __restrict__ out30,
+                                                         G1Xyzz* __restrict__ out_std, u32 nseg, int last) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds30[];
+  G1Xyzz30* sh = reinterpret_cast<G1Xyzz30*>(lds30);
+  const u32 w = blockIdx.y, chunks = gridDim.x;
+  const u32 per = (nseg + chunks - 1) / chunks;
+  const u32 lo = blockIdx.x * per;
+  u32 hi = lo + per; if (hi > nseg) hi = nseg;
+  X30 acc = x30_identity();
+  for (u32 s = lo + threadIdx.x; s < hi; s += 256) {
+    X30 t = x30_load(in + (u64)w * nseg + s);
+    x30_add(acc, t);
+  }
+  x30_store(sh + threadIdx.x, acc);
+  __syncthreads();
+  for (u32 off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      X30 a = x30_load(sh + threadIdx.x);
+      X30 b = x30_load(sh + threadIdx.x + off);
+      x30_add(a, b);
+      x30_store(sh + threadIdx.x, a);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    X30 r = x30_load(sh);
+    if (last) g1_store_xyzz(out_std + (u64)w * chunks + blockIdx.x, x30_to_std(r));
+    else x30_store(out30 + (u64)w * chunks + blockIdx.x, r);
+  }
 }
 
 // ---- self-test of the 30-bit arithmetic against ff.cuh (mh_selftest_fq30) ----------------------------------------
