@@ -362,7 +362,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
                          (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
                          (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB);
     }
-    hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 4096)), dim3(64), 0, s, fbw,
+    hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw,
                        (const F::G1Aff30*)bs.d_table, (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr,
                        (const u32*)(d_max + 1), (F::G1Xyzz30*)c.msm_buckets.ptr, nb, (u64)WB);
     // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1

@@ -159,9 +159,22 @@ __device__ __forceinline__ Fq30 f30_sub2(const Fq30& a, const Fq30& b) {
   return r;
 }
 
-// cheap necessary condition for a == 0 mod p (a < 2^9 p): a = j p implies a * p^-1 = j mod 2^30.  False positives
-// (probability ~2^-21) only send an entry through the complete addition law.
-__device__ __forceinline__ bool f30_maybe_zero(const Fq30& a) { return ((a.v[0] * Fq30Params::PINV_POS) & M30) < 512u; }
+// a == 0 mod p for a normalised value below 16 p: a = j p implies a * p^-1 = j mod 2^30, so one multiplication rejects
+// all but ~2^-26 of the non-zero values, and those are compared with j p limb by limb (exact: a collision-free proof
+// leaves the accumulate kernel's deferred list empty and the fix-up pass returns at once).
+__device__ __forceinline__ bool f30_is_zero(const Fq30& a) {
+  const u32 j = (a.v[0] * Fq30Params::PINV_POS) & M30;
+  if (__builtin_expect(j >= 16u, 1)) return false;
+  u64 c = 0;
+  bool eq = true;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) {
+    c += (u64)j * Fq30Params::P[i];
+    if (i < Fq30::NL - 1) { eq = eq && a.v[i] == ((u32)c & M30); c >>= 30; }
+    else eq = eq && a.v[i] == (u32)c;
+  }
+  return eq;
+}
 
 // ---- conversions to / from the 32-bit Montgomery form of ff.cuh --------------------------------------------
 __device__ __forceinline__ Fq30 f30_split(const Fq& x) {       // plain regrouping of the bits

@@ -397,7 +397,7 @@ __device__ __noinline__ void x30_add(X30& acc, const X30& b) {
   const Fq30 U1 = f30_mul(acc.x, b.zz);
   const Fq30 S1 = f30_mul(acc.y, b.zzz);
   const Fq30 P = f30_sub<2>(f30_mul(b.x, acc.zz), U1);
-  if (__builtin_expect(f30_maybe_zero(P), 0)) { x30_add_slow(acc, b); return; }
+  if (__builtin_expect(f30_is_zero(P), 0)) { x30_add_slow(acc, b); return; }
   const Fq30 R = f30_sub<2>(f30_mul(b.y, acc.zzz), S1);
   Fq30 PP = f30_sqr(P);
   const Fq30 Q = f30_mul(U1, PP);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(3,
     Fq30 y2 = load30(q->y);
     if (e & 0x80000000u) y2 = f30_sub<2>(zero, y2);
     const Fq30 P = f30_sub<8>(f30_mul(x2, ZZ), X1);
-    if (__builtin_expect(f30_maybe_zero(P), 0)) { lst[np++] = e; continue; }   // np <= k: never overtakes the read cursor
+    if (__builtin_expect(f30_is_zero(P), 0)) { lst[np++] = e; continue; }   // np <= k: never overtakes the read cursor
     const Fq30 R = f30_sub<4>(f30_mul(y2, ZZZ), Y1);
     Fq30 PP = f30_sqr(P);
     ZZ = f30_mul(ZZ, PP);
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ 
   same(f30_to_fq(f30_sqr(a30)), ff_sqr(a));
   same(f30_to_fq(f30_sub2<3>(a30, b30)), ff_sub(a, ff_dbl(b)));
   same(f30_to_fq(f30_sub<8>(f30_dbl(a30), b30)), ff_sub(ff_dbl(a), b));
-  ok = ok && f30_maybe_zero(f30_sub<2>(a30, a30)) && f30_maybe_zero(f30_sub<8>(f30_add(a30, a30), f30_dbl(a30)));
+  ok = ok && f30_is_zero(f30_sub<2>(a30, a30)) && f30_is_zero(f30_sub<8>(f30_add(a30, a30), f30_dbl(a30)));
   // group formulas on pseudo-points
   G1Xyzz p, q;
   p.x = a; p.y = b; p.zz = ff_sqr(b); p.zzz = ff_mul(p.zz, b);

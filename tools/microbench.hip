@@ -164,7 +164,7 @@ __global__ void k_check30(u32* bad, const Fq* in, int n) {
   Fq z = ff_sub(a, a);
   bool ok = true;
   for (int i = 0; i < Fq::N; i++) ok = ok && got.v[i] == want.v[i] && ge.v[i] == gf.v[i];
-  ok = ok && f30_maybe_zero(f30_sub<2>(a30, a30)) && f30_maybe_zero(f30_sub<8>(f30_add(a30, a30), f30_dbl(a30)));
+  ok = ok && f30_is_zero(f30_sub<2>(a30, a30)) && f30_is_zero(f30_sub<8>(f30_add(a30, a30), f30_dbl(a30)));
   (void)z;
   if (!ok) atomicAdd(bad, 1u);
 }
