@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_ISSUE_PEAK_TOPS = 39.3      # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one VALU lane-op per lane and clock
 # instructions of one bucket addition (XYZZ += affine, 8 M + 2 S on 13 x 30-bit limbs), counted in the ISA of the loop
-# body of msmfb::accum30_kernel (profiles/r01l_accum_loop_isa.txt, tools/loop_isa_stats.py); the variable-base kernel (32-bit limbs) has 7839
+# body of msmfb::accum30_kernel (profiles/r01p_accum_loop_isa.txt, tools/loop_isa_stats.py); the variable-base kernel (32-bit limbs) has 7839
 ACCUM_VALU_PER_ADD = {"fixed-base": 5166, "variable-base": 7839}
 ACCUM_MAD_PER_ADD = {"fixed-base": 3224, "variable-base": 2880}
 
