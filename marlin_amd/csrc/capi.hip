@@ -304,7 +304,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     hipLaunchKernelGGL(F::pscan_kernel, dim3(nparts, nj), dim3(1024), 0, s, jobs, (u32*)c.fb_pc.ptr, d_ptot, nparts);
     hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
     hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)c.fb_pc.ptr,
-                       (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S);
+                       (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S);
     MH_HIP(hipMemcpyAsync(ptot.data(), c.fb_ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count

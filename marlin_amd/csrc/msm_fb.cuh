@@ -198,9 +198,10 @@ __global__ __launch_bounds__(MAX_PARTS) void pstart_kernel(const u32* __restrict
 
 // One block = S scalars (the same S as count_kernel): digits -> LDS counters -> local offsets -> entries placed in
 // LDS grouped by partition -> copied out, consecutive lanes to consecutive addresses of each partition's run.
-__global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const u32* __restrict__ pc, const u32* __restrict__ pstart,
-                                                             u32* __restrict__ key, u32* __restrict__ val, u32 W, Windows win,
-                                                             int is_mont, u32 nparts, u32 pshift, u32 tab_n, u32 S) {
+__global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const u32* __restrict__ pc, const u32* __restrict__ ptot,
+                                                             const u32* __restrict__ pstart, u32* __restrict__ key,
+                                                             u32* __restrict__ val, u32 W, Windows win, int is_mont, u32 nparts,
+                                                             u32 pshift, u32 tab_n, u32 S) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* cur = lds;                                  // [MAX_PARTS] counts -> local starts -> cursors
   u32* gdst = lds + MAX_PARTS;                     // [MAX_PARTS] global position of local entry 0 of each partition
@@ -210,25 +211,28 @@ __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const 
   unsigned char* spart = (unsigned char*)(sval + S * W);
   const u32 job = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   if (blk >= jobs.nblk[job]) return;
-  if (t < MAX_PARTS) cur[t] = 0;
+  // this block's entries per partition = difference of consecutive entries of the scanned per-block counts
+  // (count_kernel + pscan_kernel): no second counting pass here
+  u32 my_pre = 0;
+  if (t < MAX_PARTS) {
+    u32 cnt = 0;
+    if (t < nparts) {
+      const u32* row = pc + jobs.pc_off[job] + (u64)t * jobs.nblk[job];
+      my_pre = row[blk];
+      cnt = (blk + 1 < jobs.nblk[job] ? row[blk + 1] : ptot[job * nparts + t]) - my_pre;
+    }
+    cur[t] = cnt;
+  }
+  __syncthreads();
+  block_excl_scan2(cur, MAX_PARTS, tmp);
+  if (t < nparts) gdst[t] = pstart[job * nparts + t] + my_pre - cur[t];
   __syncthreads();
   const u64 n = jobs.n[job];
   const u64 i = (u64)blk * S + t;
   const bool live = t < S && i < n;
-  Fr s;
   if (live) {
-    s = ff_load(jobs.scalars[job] + i);
+    Fr s = ff_load(jobs.scalars[job] + i);
     if (is_mont) s = ff_from_mont(s);
-    msm::for_each_digit(s, W, win, [&](u32, u32 e) {
-      u32 b = e & 0x7fffffffu;
-      if (b) atomicAdd(&cur[(b - 1) >> pshift], 1u);
-    });
-  }
-  __syncthreads();
-  block_excl_scan2(cur, MAX_PARTS, tmp);
-  if (t < nparts) gdst[t] = pstart[job * nparts + t] + pc[jobs.pc_off[job] + (u64)t * jobs.nblk[job] + blk] - cur[t];
-  __syncthreads();
-  if (live) {
     const u32 t0 = jobs.tab_off[job] + (u32)i;
     msm::for_each_digit(s, W, win, [&](u32 w, u32 e) {
       u32 b = e & 0x7fffffffu;
