@@ -63,7 +63,7 @@ constexpr int MAX_C = 20;          // 2^19 buckets = 256 partitions x 2^11
 constexpr int PART_BITS = 11;      // buckets per virtual window = 2^11
 constexpr int MAX_PARTS = 256;
 inline u32 part_bits(u32 c) { return c - 1 < PART_BITS ? c - 1 : PART_BITS; }
-constexpr int TPB = 256;           // count kernel
+constexpr int TPB = 1024;          // count kernel: one scalar per thread
 constexpr int SORT_THREADS = 1024; // split / hist / scatter
 constexpr int SPLIT_ENTRIES = 13312;   // entries one split block stages in LDS (13 windows x 1024 scalars)
 constexpr int TILE_EPT = 16;           // scatter: entries per thread -> tiles of <= 16384 entries
