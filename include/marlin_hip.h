@@ -51,7 +51,12 @@ extern "C" {
 int mh_curve_info(int* curve_id, int* fr_limbs64, int* fq_limbs64, int* fr_two_adicity);
 
 /* ---- lifecycle ---------------------------------------------------------------- */
+/* One process drives ONE GPU (the multi-GPU layout is one process per GPU over RCCL, see mh_marlin_set_shard), so
+ * mh_init takes a single device id.  SURVEY.md 8b's sketch `mh_init(const int* device_ids, int n_devices)` is kept as
+ * mh_init_devices for binding compatibility: it accepts exactly one id (n_devices == 1) and fails with MH_EINVAL
+ * otherwise -- a deliberate deviation, documented in INTEGRATION.md section 2. */
 int mh_init(int device_id);               /* idempotent for the same device */
+int mh_init_devices(const int* device_ids, int n_devices);
 int mh_shutdown(void);
 const char* mh_last_error(void);
 int mh_set_stream(void* hip_stream);      /* NULL -> library-owned stream */
@@ -71,11 +76,22 @@ int mh_memset(void* dst_dev, int byte, size_t bytes);
  * also multiplies by n^-1.  log_n in [0, 32] (bounded by device memory). */
 int mh_ntt(int field, uint64_t* data_mont, uint32_t log_n, int inverse);
 int mh_ntt_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse);
+/* Coset transforms: ark_poly Radix2EvaluationDomain::{coset_fft_in_place, coset_ifft_in_place} [ark-poly 0.3]:
+ *   forward: data[i] *= g^i, then the NTT  (evaluations of the polynomial on the coset g H);
+ *   inverse: the inverse NTT (with n^-1), then data[i] *= g^-i,
+ * g = F::multiplicative_generator() (7 for BLS12-381 Fr, 5 for BN254 Fr).  The reference's prover calls no coset
+ * transform (seam B2); BASELINE.json's north_star names it, and the patched ark-poly of shim/ routes
+ * both here. */
+int mh_ntt_coset(int field, uint64_t* data_mont, uint32_t log_n, int inverse);
+int mh_ntt_coset_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse);
 
 /* ---- MSM over G1: replaces ark_ec VariableBaseMSM::multi_scalar_mul ------------------
  * Bases are uploaded once (the SRS: KZG10 powers_of_g / powers_of_gamma_g) and
  * addressed by handle + offset, because ark-poly-commit slices one SRS array
  * (powers[num_leading_zeros..], shifted_powers[..]).  Output: Jacobian X||Y||Z. */
+/* An affine point carries no infinity flag here, so the identity cannot be a base (arkworks' VariableBaseMSM accepts
+ * it): both upload calls check every point against the curve equation on the device and return MH_EINVAL for a point
+ * that is not on the curve -- which rejects (0, 0) / (0, 1) encodings of the identity instead of multiplying them. */
 int mh_bases_upload(int curve, const uint64_t* xy_mont, size_t n, uint64_t* handle_out);
 int mh_bases_from_dev(int curve, const void* d_xy_mont, size_t n, uint64_t* handle_out); /* adopts a copy */
 /* KZG10::setup's fixed-base powers for a known-tau (test/bench) SRS:
@@ -143,6 +159,16 @@ int mh_marlin_vk_bytes(uint64_t pk, uint8_t* out, size_t cap, size_t* len_out);
  * the flat ToBytes-layout proof (9 commitments, 4 evaluations, 2 opening proofs; 2143 bytes). */
 int mh_marlin_prove(uint64_t pk, const uint64_t* instance_mont, const uint64_t* witness_mont, const uint8_t* zk_seed32,
                     int zk_chacha_rounds, uint8_t* proof_out, size_t cap, size_t* len_out);
+
+/* Wire format (host only, no device needed): the flat ToBytes-layout proof of mh_marlin_prove <-> the bytes of
+ * ark-serialize's `CanonicalSerialize for Proof<Fr, PC>` (src/data_structures.rs:100-110; ProverMsg as Option<Vec<F>>,
+ * src/ahp/prover.rs:84-99): compressed G1 (x with the y-sign / infinity flags in the top two bits of the last byte), u64
+ * Vec lengths, one-byte Option tags.  pc = 0 MarlinKZG10 (855 bytes on BLS12-381), 1 SonicKZG10.  A stock arkworks
+ * verifier deserialises these bytes with `Proof::deserialize`.  mh_marlin_proof_deserialize validates like
+ * CanonicalDeserialize does (field range, on-curve, prime-order subgroup, flag consistency) and returns MH_EINVAL
+ * otherwise.  out == NULL queries the length. */
+int mh_marlin_proof_serialize(const uint8_t* flat_proof, size_t flat_len, int pc, uint8_t* out, size_t cap, size_t* len_out);
+int mh_marlin_proof_deserialize(const uint8_t* bytes, size_t len, int pc, uint8_t* flat_out, size_t cap, size_t* len_out);
 
 /* Multi-GPU (one process per GPU): shard every MSM of mh_marlin_prove by points over `world` ranks.  The
  * library is transport-agnostic: `allgather` must gather `bytes` bytes from every rank into recv

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, {"bls12_381": "libmarlin_hip.so", "bn254": "libma
 _u64p = C.POINTER(C.c_uint64)
 SYMBOLS = {
     "mh_init": (C.c_int, [C.c_int]),
+    "mh_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "mh_shutdown": (C.c_int, []),
     "mh_last_error": (C.c_char_p, []),
     "mh_set_stream": (C.c_int, [C.c_void_p]),
@@ -29,6 +30,8 @@ SYMBOLS = {
     "mh_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "mh_ntt": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_ntt_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
+    "mh_ntt_coset": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_int]),
+    "mh_ntt_coset_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_bases_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
     "mh_bases_from_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
     "mh_srs_powers": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, _u64p]),
@@ -51,6 +54,8 @@ SYMBOLS = {
     "mh_marlin_vk_bytes": (C.c_int, [C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mh_marlin_prove": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t,
                                   C.POINTER(C.c_size_t)]),
+    "mh_marlin_proof_serialize": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mh_marlin_proof_deserialize": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mh_marlin_set_shard": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mh_marlin_test_allgather": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mh_marlin_get_poly": (C.c_int, [C.c_uint64, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

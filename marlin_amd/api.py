@@ -108,6 +108,14 @@ def intt(evals):
     return ntt(evals, inverse=True)
 
 
+def coset_ntt(coeffs_or_evals, inverse=False):
+    """Radix2EvaluationDomain::coset_fft (inverse=False) / coset_ifft (inverse=True) of an (n,4) uint64 Montgomery array."""
+    a = _as_u64(coeffs_or_evals, 4).copy()
+    log_n = _log2_exact(a.shape[0])
+    _lib.check(_L().mh_ntt_coset(_curve_id(), a.ctypes.data, log_n, 1 if inverse else 0), "mh_ntt_coset")
+    return a
+
+
 def ntt_dev(d_in, d_out, log_n, inverse=False):
     """Device-resident NTT; d_in / d_out are DeviceBuffer or raw device pointers."""
     pi = d_in.ptr if isinstance(d_in, DeviceBuffer) else int(d_in)

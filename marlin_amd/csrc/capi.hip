@@ -133,6 +133,51 @@ int ntt_device_len(Context& c, const void* d_in, uint64_t in_len, void* d_out, u
   return MH_OK;
 }
 
+// Radix2EvaluationDomain::{coset_fft_in_place, coset_ifft_in_place} [ark-poly 0.3]: forward = distribute_powers(g) then
+// the transform; inverse = the inverse transform then distribute_powers(g^-1); g = F::multiplicative_generator().
+int ntt_coset_device(Context& c, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
+  const HFr g = HFr::from_u64(hostff::FR_MULT_GENERATOR);
+  const uint64_t n = 1ull << log_n;
+  const unsigned grid = (unsigned)((n + (uint64_t)256 * ntt::DP_CH - 1) / ((uint64_t)256 * ntt::DP_CH));
+  if (!inverse) {
+    { ProfScope ps(c, PF_GLUE);
+      hipLaunchKernelGGL(ntt::distribute_powers_kernel, dim3(grid), dim3(256), 0, c.stream, (Fr*)d_out, (const Fr*)d_in, to_dev_fr(g), (u64)n); }
+    MH_HIP(hipGetLastError());
+    return ntt_device(c, d_out, d_out, log_n, 0);
+  }
+  MH_TRY(ntt_device(c, d_in, d_out, log_n, 1));
+  { ProfScope ps(c, PF_GLUE);
+    hipLaunchKernelGGL(ntt::distribute_powers_kernel, dim3(grid), dim3(256), 0, c.stream, (Fr*)d_out, (const Fr*)d_out, to_dev_fr(g.inv()), (u64)n); }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// every uploaded base must satisfy the curve equation (an affine point has no infinity flag on this ABI, so an identity
+// encoded as (0, 0) or (0, 1) is rejected here instead of being multiplied as if it were a finite point)
+__global__ __launch_bounds__(256) void bases_check_kernel(const G1Affine* __restrict__ pts, u64 n, u32* __restrict__ bad) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const G1Affine p = g1_load_affine(pts + i);
+  const Fq rhs = ff_add(ff_mul(ff_sqr(p.x), p.x), G1_CURVE_B_MONT());
+  const Fq lhs = ff_sqr(p.y);
+  bool same = true;
+  for (int k = 0; k < Fq::N; k++) same = same && lhs.v[k] == rhs.v[k];
+  if (!same) atomicAdd(bad, 1u);
+}
+static int bases_validate(Context& c, const void* d_points, size_t n) {
+  if (n == 0) return MH_OK;
+  MH_TRY(c.tr_sums.ensure(64));
+  u32* d_bad = (u32*)c.tr_sums.ptr;
+  MH_HIP(hipMemsetAsync(d_bad, 0, 4, c.stream));
+  hipLaunchKernelGGL(bases_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, (const G1Affine*)d_points, (u64)n, d_bad);
+  MH_HIP(hipGetLastError());
+  u32 bad = 0;
+  MH_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  if (bad) return fail(MH_EINVAL, "bases: " + std::to_string(bad) + " point(s) are not on the curve (the identity cannot be a base: affine points carry no infinity flag)");
+  return MH_OK;
+}
+
 // --------------------------------------------------------------------------------
 // MSM driver
 // --------------------------------------------------------------------------------
@@ -699,6 +744,12 @@ int mh_init(int device_id) {
 }
 
 extern "C" int mh_marlin_release_all(void);
+int mh_init_devices(const int* device_ids, int n_devices) {
+  if (!device_ids || n_devices != 1)
+    return fail(MH_EINVAL, "mh_init_devices: one process drives exactly one GPU (launch one process per GPU; see mh_marlin_set_shard)");
+  return mh_init(device_ids[0]);
+}
+
 int mh_shutdown(void) {
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
@@ -826,6 +877,28 @@ int mh_ntt(int field, uint64_t* data, uint32_t log_n, int inverse) {
   return MH_OK;
 }
 
+int mh_ntt_coset_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
+  LOCKED_CTX();
+  if (field != hostff::CURVE_ID) return fail(MH_EINVAL, "mh_ntt_coset: unsupported field");
+  if (!d_in || !d_out) return fail(MH_EINVAL, "mh_ntt_coset_dev: null pointer");
+  if (log_n > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "log_n exceeds the two-adicity of Fr");
+  return ntt_coset_device(c, d_in, d_out, log_n, inverse);
+}
+
+int mh_ntt_coset(int field, uint64_t* data, uint32_t log_n, int inverse) {
+  LOCKED_CTX();
+  if (field != hostff::CURVE_ID) return fail(MH_EINVAL, "mh_ntt_coset: unsupported field");
+  if (!data) return fail(MH_EINVAL, "mh_ntt_coset: null pointer");
+  if (log_n > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "log_n exceeds the two-adicity of Fr");
+  size_t bytes = (size_t)32 << log_n;
+  MH_TRY(c.io.ensure(bytes));
+  MH_HIP(hipMemcpyAsync(c.io.ptr, data, bytes, hipMemcpyHostToDevice, c.stream));
+  MH_TRY(ntt_coset_device(c, c.io.ptr, c.io.ptr, log_n, inverse));
+  MH_HIP(hipMemcpyAsync(data, c.io.ptr, bytes, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+
 int mh_bases_upload(int curve, const uint64_t* xy, size_t n, uint64_t* handle_out) {
   LOCKED_CTX();
   if (curve != hostff::CURVE_ID) return fail(MH_EINVAL, "unsupported curve");
@@ -836,6 +909,8 @@ int mh_bases_upload(int curve, const uint64_t* xy, size_t n, uint64_t* handle_ou
     MH_HIP(hipMalloc(&b.d_points, n * PT_B));
     MH_HIP(hipMemcpyAsync(b.d_points, xy, n * PT_B, hipMemcpyHostToDevice, c.stream));
     MH_HIP(hipStreamSynchronize(c.stream));
+    int rc = bases_validate(c, b.d_points, n);
+    if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
   }
   uint64_t h = c.next_handle++;
   c.bases[h] = b;
@@ -853,6 +928,8 @@ int mh_bases_from_dev(int curve, const void* d_xy, size_t n, uint64_t* handle_ou
     MH_HIP(hipMalloc(&b.d_points, n * PT_B));
     MH_HIP(hipMemcpyAsync(b.d_points, d_xy, n * PT_B, hipMemcpyDeviceToDevice, c.stream));
     MH_HIP(hipStreamSynchronize(c.stream));
+    int rc = bases_validate(c, b.d_points, n);
+    if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
   }
   uint64_t h = c.next_handle++;
   c.bases[h] = b;

@@ -14,6 +14,16 @@ struct G1Affine {   // 96 bytes, no infinity flag (SRS points are never the iden
   Fq x, y;
 };
 
+// the curve constant b of y^2 = x^3 + b (4 on BLS12-381, 3 on BN254) in Montgomery form
+__device__ __forceinline__ Fq G1_CURVE_B_MONT() {
+  const Fq one = Fq::one(), two = ff_dbl(one);
+#ifdef MH_CURVE_BN254
+  return ff_add(two, one);
+#else
+  return ff_dbl(two);
+#endif
+}
+
 struct G1Xyzz {     // 192 bytes
   Fq x, y, zz, zzz;
   static __device__ __forceinline__ G1Xyzz identity() {

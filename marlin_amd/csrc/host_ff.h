@@ -22,6 +22,7 @@ struct HFp {
   uint64_t v[P::N];
 
   static HFp zero() { HFp r; memset(r.v, 0, sizeof(r.v)); return r; }
+  static uint64_t MOD_LIMB(int i) { return P::MOD[i]; }
   static HFp one() { HFp r; memcpy(r.v, P::ONE, sizeof(r.v)); return r; }
   bool is_zero() const { uint64_t o = 0; for (int i = 0; i < N; i++) o |= v[i]; return o == 0; }
   bool operator==(const HFp& b) const { return memcmp(v, b.v, sizeof(v)) == 0; }
@@ -129,6 +130,8 @@ typedef HFp<Bn254FqP> HFq;
 constexpr int CURVE_ID = 1;
 constexpr uint32_t FR_TWO_ADICITY_H = 28;
 constexpr uint64_t FR_SHAVE_MASK_TOP64 = 0x3fffffffffffffffull;
+constexpr uint64_t G1_B = 3;                 // y^2 = x^3 + 3
+constexpr uint64_t FR_MULT_GENERATOR = 5;    // F::multiplicative_generator()
 // 2^28-th root of unity of Fr (5^((r-1)/2^28)), Montgomery form
 static inline HFr fr_two_adic_root() {
   static const uint64_t c[4] = {0x9bd61b6e725b19f0ull, 0x402d111e41112ed4ull, 0x00e0a7eb8ef62abcull, 0x2a3c09f0a58a7e85ull};
@@ -141,6 +144,8 @@ typedef HFp<FqP> HFq;
 constexpr int CURVE_ID = 0;
 constexpr uint32_t FR_TWO_ADICITY_H = 32;
 constexpr uint64_t FR_SHAVE_MASK_TOP64 = 0x7fffffffffffffffull;
+constexpr uint64_t G1_B = 4;                 // y^2 = x^3 + 4
+constexpr uint64_t FR_MULT_GENERATOR = 7;    // F::multiplicative_generator()
 // 2^32-th root of unity of Fr (7^((r-1)/2^32)), Montgomery form
 static inline HFr fr_two_adic_root() {
   static const uint64_t c[4] = {0x3829971f439f0d2bull, 0xb63683508c2280b9ull, 0xd09b681922c813b4ull, 0x16a2a19edfe81f20ull};

@@ -133,6 +133,19 @@ __global__ __launch_bounds__(THREADS) void pass_kernel(const Fr* __restrict__ x,
   }
 }
 
+// ark_poly `distribute_powers(coeffs, g)`: out[i] = in[i] * g^i (coset_fft: before the transform; coset_ifft: after it,
+// with g^-1).  A thread owns DP_CH consecutive elements: g^(first) by square-and-multiply, then a running product.
+constexpr int DP_CH = 16;
+__global__ __launch_bounds__(256) void distribute_powers_kernel(Fr* __restrict__ out, const Fr* __restrict__ in, Fr g, u64 n) {
+  const u64 first = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * DP_CH;
+  if (first >= n) return;
+  Fr p = ff_pow(g, first);
+  for (int k = 0; k < DP_CH && first + k < n; k++) {
+    ff_store(out + first + k, ff_mul(ff_load(in + first + k), p));
+    p = ff_mul(p, g);
+  }
+}
+
 inline size_t pass_lds_bytes(u32 B, int logc) { return (size_t)(1u << B) * ((2u << logc) + 1) * 16; }
 
 }  // namespace ntt

@@ -19,6 +19,7 @@
 #include "host_ff.h"
 #include "poly.cuh"
 #include "rng.cuh"
+#include "wire_host.h"
 #include <chrono>
 #include <cstdlib>
 
@@ -476,10 +477,31 @@ int mh_marlin_release_all(void) {
 int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* user) {
   if (world < 1 || rank < 0 || rank >= world) return fail(MH_EINVAL, "mh_marlin_set_shard: bad rank/world");
   if (world > 1 && !allgather) return fail(MH_EINVAL, "mh_marlin_set_shard: all_gather callback required for world > 1");
-  g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  std::lock_guard<std::recursive_mutex> lk(c.mu);     // g_shard is read by a running mh_marlin_prove under this lock
+  g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
   return fb_set_world(c, (uint32_t)world);      // no-op without uploaded base sets (and without a device)
+}
+
+// ---- wire format (host only; wire_host.h) ------------------------------------------------------------------
+static int wire_copy_out(const std::vector<uint8_t>& v, uint8_t* out, size_t cap, size_t* len_out, const char* what) {
+  if (len_out) *len_out = v.size();
+  if (!out) return MH_OK;
+  if (cap < v.size()) return fail(MH_EINVAL, std::string(what) + ": buffer too small");
+  memcpy(out, v.data(), v.size());
+  return MH_OK;
+}
+int mh_marlin_proof_serialize(const uint8_t* flat, size_t flat_len, int pc, uint8_t* out, size_t cap, size_t* len_out) {
+  if (!flat || (pc != 0 && pc != 1)) return fail(MH_EINVAL, "mh_marlin_proof_serialize: bad argument");
+  std::vector<uint8_t> v;
+  if (!wire::serialize(flat, flat_len, pc, v)) return fail(MH_EINVAL, "mh_marlin_proof_serialize: not a flat proof of this scheme");
+  return wire_copy_out(v, out, cap, len_out, "mh_marlin_proof_serialize");
+}
+int mh_marlin_proof_deserialize(const uint8_t* bytes, size_t len, int pc, uint8_t* flat_out, size_t cap, size_t* len_out) {
+  if (!bytes || (pc != 0 && pc != 1)) return fail(MH_EINVAL, "mh_marlin_proof_deserialize: bad argument");
+  std::vector<uint8_t> v;
+  if (!wire::deserialize(bytes, len, pc, v)) return fail(MH_EINVAL, "mh_marlin_proof_deserialize: invalid encoding (SerializationError::InvalidData)");
+  return wire_copy_out(v, flat_out, cap, len_out, "mh_marlin_proof_deserialize");
 }
 // host-only hook: runs the registered all_gather once (used by the CPU gloo test of the callback plumbing)
 int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv) {
@@ -1105,15 +1127,17 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     std::vector<HFr> sr; host_axpy(sr, xi_pow(1), rd_g1.shifted.blind);
     {
       sw = sw.add(f_srw.get());
-      HFr srv = host_eval(sr, beta);
-      rv_beta = has_rv_beta ? rv_beta + srv : srv; has_rv_beta = true;
+      // marlin_pc `open`: `if let Some(s) = shifted_proof.random_v { random_v = random_v.map(|v| v + s) }` -- the shifted
+      // evaluation is added to a Some and never turns a None into a Some [ark-poly-commit 0.3, SURVEY B-4]
+      if (has_rv_beta) rv_beta = rv_beta + host_eval(sr, beta);
     }
     w_beta = wacc.add(sw).to_affine();
   }
   w_gamma = om[1].to_affine();
-  // at gamma nothing is hiding, but the degree-bounded g_2 goes through open_with_witness_polynomial with
-  // Some(empty witness): random_v = Some(0) [ark-poly-commit marlin_pc::open, SURVEY B-4]
-  has_rv_gamma = true;
+  // at gamma nothing is hiding: kzg10::open on the unshifted powers returns random_v = None, and the Some(0) of the
+  // shifted proof (open_with_witness_polynomial with Some(empty witness)) is dropped by `random_v.map(..)`
+  // [ark-poly-commit 0.3 marlin_pc::open, SURVEY B-4]
+  has_rv_gamma = false;
   }
 
   tr.mark("PC::open_combinations");

@@ -136,6 +136,24 @@ def prove(pk, instance_mont, witness_mont, zk_seed, zk_rounds=20):
     return bytes(out[:n.value])
 
 
+def proof_serialize(flat_proof, pc="marlin"):
+    """flat ToBytes proof (prove) -> ark-serialize `CanonicalSerialize for Proof` bytes (src/data_structures.rs:100-110)."""
+    out = (C.c_uint8 * 4096)()
+    n = C.c_size_t()
+    _lib.check(_lib.load().mh_marlin_proof_serialize(bytes(flat_proof), len(flat_proof), {"marlin": 0, "sonic": 1}[pc], out, 4096,
+                                                     C.byref(n)), "mh_marlin_proof_serialize")
+    return bytes(out[:n.value])
+
+
+def proof_deserialize(wire_bytes, pc="marlin"):
+    """`CanonicalDeserialize for Proof` (validating) -> flat ToBytes proof."""
+    out = (C.c_uint8 * 4096)()
+    n = C.c_size_t()
+    _lib.check(_lib.load().mh_marlin_proof_deserialize(bytes(wire_bytes), len(wire_bytes), {"marlin": 0, "sonic": 1}[pc], out, 4096,
+                                                       C.byref(n)), "mh_marlin_proof_deserialize")
+    return bytes(out[:n.value])
+
+
 # ---- the reference's benchmark / test circuits as padded square R1CS (host-side input preparation) ----
 def dummy_circuit(a, b, num_variables, num_constraints):
     """DummyCircuit of benches/bench.rs:26-66 after pad_input / make_matrices_square: returns

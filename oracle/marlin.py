@@ -174,7 +174,10 @@ def marlin_open(srs, enforced_bounds, polys, rands, point, xi):
         sw = EC.add(sw, EC.msm_naive(srs.powers_of_gamma_g, shifted_r_wit))
         srv = poly_eval(shifted_r, point)
         w = EC.add(w, sw)
-        random_v = (random_v + srv) % R if random_v is not None else srv
+        # marlin_pc `open`: `if let Some(s) = shifted_proof.random_v { random_v = random_v.map(|v| v + s) }` -- a None from
+        # the unshifted proof (non-hiding combined polynomial) STAYS None; the shifted value is only ever added to a Some.
+        # [ark-poly-commit 0.3 marlin_pc/mod.rs open_individual_opening_challenges, UPSTREAM-RECALLED; SURVEY.md B-4]
+        random_v = (random_v + srv) % R if random_v is not None else None
     return w, random_v
 
 
@@ -308,8 +311,12 @@ def proof_bytes(pr):
     return out
 
 
-def verify(pk, public_input, pr):
-    """src/lib.rs:315-433 with the pairing check replaced by the known-tau identity."""
+def verify(pk, public_input, pr, use_pairing=False):
+    """src/lib.rs:315-433.  PC::check_combinations' KZG10 equation e(C - [v]G - [rv]gamma_G, H) == e(W, beta_H - [z]H)
+    [ark-poly-commit 0.3 kzg10::check, UPSTREAM-RECALLED] is decided either with the real BLS12-381 pairing
+    (use_pairing=True: oracle/pairing.py, H = the G2 generator, beta_H = [tau]H -- what a verifier without tau does;
+    MarlinKZG10 only) or with the known-tau identity C - [v]G - [rv]gamma_G == [tau - z]W that the pairing equation
+    is equivalent to (default: O(1) group operations, any curve, both PC schemes)."""
     idx, srs = pk.index, pk.srs
     pub = list(public_input)
     full = [1] + pub
@@ -373,6 +380,118 @@ def verify(pk, public_input, pr):
         lhs = EC.add(combined, EC.neg(EC.scalar_mul(G, value)))
         if rv is not None:
             lhs = EC.add(lhs, EC.neg(EC.scalar_mul(srs.gamma_g, rv)))
-        rhs = EC.scalar_mul(w, (srs.tau - point) % R)
-        ok = ok and (lhs == rhs)
+        if use_pairing:
+            from . import pairing as PR
+            assert not sonic, "pairing verification is implemented for MarlinKZG10 (SonicKZG10's bound check needs G2 powers)"
+            h = PR.G2_GEN
+            beta_h = PR.g2_mul(h, srs.tau)                       # vk.beta_h of KZG10::setup
+            inner = PR.g2_add(beta_h, PR.g2_neg(PR.g2_mul(h, point)))
+            ok = ok and PR.pairing_product_is_one([(lhs, h), (EC.neg(w), inner)])
+        else:
+            rhs = EC.scalar_mul(w, (srs.tau - point) % R)
+            ok = ok and (lhs == rhs)
     return ok
+
+
+# ----------------------------------------------------------------------------------
+# Wire format: ark-serialize 0.3 `CanonicalSerialize` of `Proof` (src/data_structures.rs:100-110)
+# ----------------------------------------------------------------------------------
+# [UPSTREAM-RECALLED: ark-serialize / ark-ec / ark-ff 0.3, absent here]  derive(CanonicalSerialize) writes the fields in
+# declaration order; Vec<T> = u64 LE length + items; Option<T> = one bool byte (+ the value); bool = one byte;
+# Fp = ceil((MODULUS_BITS + flag bits) / 8) little-endian bytes of the canonical value with the flags in the top bits of the
+# last byte; a short-Weierstrass affine point = x with SWFlags (bit 7: y > -y "positive", bit 6: infinity; the identity
+# serialises x = 0); ProverMsg = Option<Vec<F>> (src/ahp/prover.rs:84-99); marlin_pc::Commitment = {comm, Option<shifted>};
+# kzg10::Proof = {w, Option<random_v>}; BatchLCProof = {Vec<kzg10::Proof>, evals: Option<Vec<F>>} (None from Marlin).
+def g1_compressed(pt):
+    if pt is None:
+        b = bytearray(FQ_BYTES); b[-1] |= 1 << 6
+        return bytes(b)
+    x, y = pt
+    b = bytearray(x.to_bytes(FQ_BYTES, "little"))
+    if y > (Q_MOD - y) % Q_MOD:
+        b[-1] |= 1 << 7
+    return bytes(b)
+
+
+def g1_decompress(b):
+    from .fields import G1_B as CURVE_B
+    b = bytearray(b)
+    flags = b[-1] & 0xC0
+    b[-1] &= 0x3F
+    x = int.from_bytes(b, "little")
+    if flags & 0x40:
+        assert x == 0 and not flags & 0x80, "invalid infinity encoding"
+        return None
+    assert x < Q_MOD
+    y2 = (x * x * x + CURVE_B) % Q_MOD
+    y = pow(y2, (Q_MOD + 1) // 4, Q_MOD)                 # p = 3 mod 4 for both curves
+    assert y * y % Q_MOD == y2, "x is not on the curve"
+    if (y > (Q_MOD - y) % Q_MOD) != bool(flags & 0x80):
+        y = (Q_MOD - y) % Q_MOD
+    return (x, y)
+
+
+def _u64(n):
+    return int(n).to_bytes(8, "little")
+
+
+def proof_serialize(pr):
+    """CanonicalSerialize bytes of `Proof<Fr, MarlinKZG10 | SonicKZG10>` (855 bytes for MarlinKZG10 on BLS12-381 with
+    random_v = Some at beta and None at gamma; the README's 880 counts 13 G1 + 8 Fr of an older layout)."""
+    out = _u64(len(pr.commitments))
+    for rnd in pr.commitments:
+        out += _u64(len(rnd))
+        for c in rnd:
+            if c[1] == "sonic":
+                out += g1_compressed(c[0])
+            else:
+                out += g1_compressed(c[0]) + (b"\x01" + g1_compressed(c[1][0]) if c[1] is not None else b"\x00")
+    out += _u64(len(pr.evaluations)) + b"".join(fr_bytes(e) for e in pr.evaluations)
+    out += _u64(3) + b"\x00" * 3                        # prover_messages: three EmptyMessage = Option::None each
+    out += _u64(len(pr.pc_proof))
+    for w, rv in pr.pc_proof:
+        out += g1_compressed(w) + (b"\x01" + fr_bytes(rv) if rv is not None else b"\x00")
+    out += b"\x00"                                      # BatchLCProof.evals = None
+    return out
+
+
+def proof_deserialize(b, pc="marlin"):
+    """inverse of proof_serialize (CanonicalDeserialize with point validation: on-curve + flag consistency)."""
+    pos = [0]
+
+    def take(n):
+        assert pos[0] + n <= len(b), "truncated proof"
+        v = b[pos[0]:pos[0] + n]; pos[0] += n
+        return v
+
+    def u64(): return int.from_bytes(take(8), "little")
+
+    def boolean():
+        v = take(1)[0]
+        assert v in (0, 1)
+        return bool(v)
+
+    def fr():
+        v = int.from_bytes(take(32), "little")
+        assert v < R
+        return v
+    pr = Proof()
+    pr.commitments = []
+    for _ in range(u64()):
+        rnd = []
+        for _ in range(u64()):
+            comm = g1_decompress(take(FQ_BYTES))
+            if pc == "sonic":
+                rnd.append((comm, "sonic"))
+            else:
+                rnd.append((comm, (g1_decompress(take(FQ_BYTES)),) if boolean() else None))
+        pr.commitments.append(rnd)
+    pr.evaluations = [fr() for _ in range(u64())]
+    for _ in range(u64()):
+        assert not boolean(), "Marlin's prover messages are all EmptyMessage"
+    pr.pc_proof = []
+    for _ in range(u64()):
+        w = g1_decompress(take(FQ_BYTES))
+        pr.pc_proof.append((w, fr() if boolean() else None))
+    assert not boolean() and pos[0] == len(b)
+    return pr

@@ -4,7 +4,11 @@
 No arkworks output can be produced in this environment (no Rust toolchain), so
 these are NOT arkworks-produced vectors: they freeze the oracle's restatement so that (a) oracle
 drift is detected by the CPU tests and (b) the HIP prover is compared byte-for-byte against them
-on the GPU box.  Run from the repo root:  python tests/golden/make_golden.py
+on the GPU box.  They are SELF-CONSISTENCY vectors (parity with arkworks bytes stays unpinned).
+Run from the repo root:
+    python tests/golden/make_golden.py            # the src/test.rs shapes (marlin_proofs.json, ~1 min)
+    python tests/golden/make_golden.py large      # DummyCircuit at 2^10 (BASELINE configs[0]), 2^12, 2^14
+                                                  # (marlin_proofs_large.json, ~15 min of pure-Python big-int work)
 """
 import hashlib
 import json
@@ -24,6 +28,7 @@ CASES = [
     ("test_circuit", 100, 25), ("test_circuit", 25, 100),
     ("dummy_circuit", 32, 10), ("dummy_circuit", 64, 10),
 ]
+LARGE_CASES = [("dummy_circuit", 1 << 10, 10), ("dummy_circuit", 1 << 12, 10), ("dummy_circuit", 1 << 14, 10)]
 
 
 def build(kind, nc, nv):
@@ -40,9 +45,11 @@ def build(kind, nc, nv):
 
 
 def main():
+    large = len(sys.argv) > 1 and sys.argv[1] == "large"
+    cases, fname = (LARGE_CASES, "marlin_proofs_large.json") if large else (CASES, "marlin_proofs.json")
     out = {"tau": hex(TAU), "gamma": hex(GAMMA), "zk_seed": ZK_SEED.hex(), "zk_rng": "ChaCha20 (rand_chacha ChaChaRng::from_seed)",
            "cases": []}
-    for kind, nc, nv in CASES:
+    for kind, nc, nv in cases:
         a, b, cs, pub = build(kind, nc, nv)
         nnz = 3 * max(nc, nv)
         srs = MR.universal_setup(max(nc, nv), max(nc, nv), nnz, TAU, GAMMA)
@@ -58,8 +65,11 @@ def main():
             "evaluations": [hex(e) for e in pr.evaluations],
             "proof_bytes": pb.hex(),
         })
-        print(kind, nc, nv, "H", pk.index.domain_h.size, "K", pk.index.domain_k.size, len(pb), "bytes")
-    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "marlin_proofs.json"), "w"), indent=1)
+        # blake2s of every prover polynomial's coefficient bytes: lets the GPU test say WHICH polynomial diverged
+        out["cases"][-1]["poly_blake2s"] = {l: hashlib.blake2s(b"".join(FS.fr_bytes(x) for x in pr.polys[l])).hexdigest()
+                                            for l in ("w", "z_a", "z_b", "mask_poly", "t", "g_1", "h_1", "g_2", "h_2")}
+        print(kind, nc, nv, "H", pk.index.domain_h.size, "K", pk.index.domain_k.size, len(pb), "bytes", flush=True)
+        json.dump(out, open(os.path.join(ROOT, "tests", "golden", fname), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -110,3 +110,27 @@ def test_fq30_constants_are_current_and_consistent(tmp_path):
         assert (x * r30 % p) * val32(arr(block, "FROM30")) * pow(r32, -1, p) % p == x * r32 % p
         # lazy-reduction head room: the product of two values below 20 p stays below 2 p
         assert (20 * p) * (20 * p) // r30 + p < 2 * p
+
+
+def test_zkstream_numpy_matches_sequential_oracle():
+    """tests/zkstream.py (vectorised ChaCha + rejection sampling, used by the full-size GPU parity tests) reproduces
+    oracle/fs.py's sequential ChaChaRng / fr_rand stream, across a 64-word buffer boundary and for both round counts."""
+    from tests import zkstream as ZS
+    seed = bytes(range(32))
+    for rounds in (20, 12):
+        r = FS.ChaChaRng(seed, rounds)
+        words = ZS.chacha_words(seed, rounds, 0, 12).reshape(-1)
+        assert [int(w) for w in words] == [r.next_u32() for _ in range(12 * 16)]
+        r = FS.ChaChaRng(seed, rounds)
+        want = [FS.fr_rand(r) for _ in range(700)]
+        assert [ZS.mont_to_canonical(row) for row in ZS.fr_draws(seed, 700, rounds)] == want
+    # the draws of one prove at |H| = 32 in Appendix-C order, incl. the mask polynomial's sum-over-H fix (prover.rs:373-380)
+    H = 32
+    r = FS.ChaChaRng(seed, 20)
+    d = ZS.prove_zk_draws(seed, H)
+    assert [d["r_w"], d["r_za"], d["r_zb"]] == [FS.fr_rand(r) for _ in range(3)]
+    mask = [FS.fr_rand(r) for _ in range(3 * H)]
+    mask[0] = (mask[0] - mask[0] - mask[H] - mask[2 * H]) % F.R_MOD
+    assert np_to_fr(d["mask"]) == mask
+    for name in ("blind_w", "blind_za", "blind_zb", "blind_g1", "blind_g1_shifted"):
+        assert d[name] == [FS.fr_rand(r) for _ in range(3)]
