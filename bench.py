@@ -14,10 +14,16 @@ MarlinKZG10).  One "step" = one pass of the prove hot path over one instance:
       (kernel-only view, --workload hotpath-inventory).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on
-rank 0.  N > 1 is launched by torch.distributed.run, one rank per GPU: every rank runs
-the whole prover but multiplies only its slice of each MSM; the 144-byte partial points
+rank 0.  N > 1 runs one rank per GPU: either the caller launches them (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: RANK / WORLD_SIZE are in the environment) or, when bench.py is started
+plainly with --gpus N > 1, it re-executes itself under torch.distributed.run with N ranks on 127.0.0.1.
+Every rank runs the whole prover but multiplies only its share of each MSM; the 144-byte partial points
 are exchanged with an RCCL all_gather and added on every rank, so all ranks derive the
-same transcript; the AHP rounds (NTTs + glue) are replicated (strong scaling).
+same transcript (strong scaling).
+
+The timed region is `Marlin::prove` from the padded R1CS instance + witness on: constraint synthesis
+(`generate_constraints` with construct_matrices, src/ahp/prover.rs:217-230 -- ark-relations host code, out of scope per
+SURVEY.md 2.2 E6) is NOT included; config.workload says so.
 """
 import argparse
 import json
@@ -113,16 +119,11 @@ class MarlinProve:
         return self.proof
 
 
-def cpu_baseline(log_n_sample=16):
-    """The C restatement (oracle/c/ref_hotpath.c, kind "port") timed on this host's cores on the
-    hot-path inventory of a 2^log_n_sample-constraint prove."""
-    from oracle import cref
-    from marlin_amd import workload as W
-    cref.build()
-    host_threads = os.cpu_count() or 1
-    H = 1 << log_n_sample
+def _cpu_inventory(cref, W, log_n, threads, rng):
+    """NTT + MSM inventory of one prove at 2^log_n constraints on the C restatement with `threads` host threads:
+    (seconds NTT, seconds MSM, busy threads of the MSM part)."""
+    H = 1 << log_n
     K = 4 * H
-    rng = np.random.default_rng(7)
     bases, _ = cref.bases_arith(K)
     ntts = W.ntt_inventory(H, K)
     msms, _ = W.msm_inventory(H, K)
@@ -131,22 +132,41 @@ def cpu_baseline(log_n_sample=16):
     scal = rand_fr_np(rng, K)
     t0 = time.time()
     for lg, inverse, _ in ntts:
-        cref.ntt(data[: 1 << lg], inverse=inverse)
+        cref.ntt(data[: 1 << lg], inverse=inverse, threads=threads)
     t_ntt = time.time() - t0
     t0 = time.time()
     for n, _ in msms:
-        cref.msm(bases[:n], scal[:n], montgomery=True, threads=host_threads)
+        cref.msm(bases[:n], scal[:n], montgomery=True, threads=threads)
     t_msm = time.time() - t0
-    total = t_ntt + t_msm
     # the restatement parallelises an MSM like arkworks does -- one task per c-bit window -- so at most
     # ceil(255 / c) threads are ever busy (c = ceil(log2 n) * 69 / 100 + 2), whatever the host offers
     lg = (K - 1).bit_length()
-    used = min(host_threads, -(-255 // (lg * 69 // 100 + 2)))
+    return t_ntt, t_msm, min(threads, -(-255 // (lg * 69 // 100 + 2)))
+
+
+def cpu_baseline(log_n_all=18, log_n_one=13):
+    """The C restatement (oracle/c/ref_hotpath.c, kind "port": arkworks' algorithm class -- radix-2 in-place NTT with the
+    butterflies of a stage split over threads like ark-poly's rayon chunks, Pippenger with ark-ec's window rule and one
+    task per window -- NOT arkworks itself) timed on this host: the NTT + MSM inventory of one prove (SURVEY.md Appendix A:
+    30 transforms, 15 MSMs) with all host threads at 2^log_n_all constraints (BASELINE configs[1]'s size; the headline
+    2^20 would take ~4x longer than the few minutes this run may use) and with ONE thread at 2^log_n_one."""
+    from oracle import cref
+    from marlin_amd import workload as W
+    cref.build()
+    host_threads = os.cpu_count() or 1
+    rng = np.random.default_rng(7)
+    t_ntt1, t_msm1, _ = _cpu_inventory(cref, W, log_n_one, 1, rng)
+    t_ntt, t_msm, busy = _cpu_inventory(cref, W, log_n_all, host_threads, rng)
     return {
-        "value": H / total, "unit": "constraints/s", "cores": used, "kind": "port",
+        "value": (1 << log_n_all) / (t_ntt + t_msm), "unit": "constraints/s", "cores": host_threads, "kind": "port",
+        "host_threads": host_threads, "msm_threads_busy": busy,
+        "single_thread": {"value": (1 << log_n_one) / (t_ntt1 + t_msm1), "unit": "constraints/s", "cores": 1,
+                          "sample": "same inventory at 2^%d constraints, 1 thread: NTT %.2fs, MSM %.2fs" % (log_n_one, t_ntt1, t_msm1)},
         "sample": "oracle/c/ref_hotpath.c (C restatement of arkworks' radix-2 NTT + Pippenger, NOT arkworks itself): "
-                  "NTT+MSM inventory of one prove at 2^%d constraints; NTT single-thread %.2fs, MSM one thread per window "
-                  "(%d busy of %d host threads) %.2fs" % (log_n_sample, t_ntt, used, host_threads, t_msm),
+                  "NTT+MSM inventory (30 transforms, 15 MSMs) of one prove at 2^%d constraints on %d host threads: NTT %.2fs "
+                  "(butterflies of each stage over all threads), MSM %.2fs (one task per window: %d threads busy); witness "
+                  "synthesis, AHP glue and Fiat-Shamir not included on either side of the comparison"
+                  % (log_n_all, host_threads, t_ntt, t_msm, busy),
     }
 
 
@@ -163,6 +183,17 @@ def main():
                          "the curve is chosen with MARLIN_AMD_CURVE=bls12_381|bn254")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started plainly with --gpus N: become N ranks (one per GPU) under torch.distributed.run on this node
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,11 +204,26 @@ def main():
         local_rank = 0
     import torch
     dist = None
+    dry = bool(os.environ.get("BENCH_DRY_RUN"))     # CPU test hook: rank plumbing only, no device, no number
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is what runs" % (args.gpus, world), file=sys.stderr)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        if not dry:
+            torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
+    if dry:
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "marlin_prove_constraints_per_sec", "value": None, "unit": "constraints/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_over_ranks": float(t.item())}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     import marlin_amd as M
     M.init(local_rank)
     torch.cuda.set_device(local_rank)
@@ -271,7 +317,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32-limb Montgomery integers (Fr 256-bit in 8 x 32; Fq 384-bit in 12 x 32 and 13 x 30 bits)",
         "data": "synthetic",
-        "config": {"workload": ("marlin-prove: full Marlin::prove (AHP rounds + KZG10 commit/open + Fiat-Shamir), "
+        "config": {"workload": ("marlin-prove: Marlin::prove from the padded R1CS instance + witness on (AHP rounds + KZG10 commit/open + "
+                                "Fiat-Shamir; witness synthesis src/ahp/prover.rs:217-230 excluded), "
                                 if workload == "marlin-prove" else
                                 "hotpath-inventory: 30 NTT + 15 MSM of one Marlin::prove on synthetic vectors, ")
                                + "DummyCircuit 2^%d constraints, BLS12-381, MarlinKZG10 (benches/bench.rs shape; SURVEY.md Appendix A)"

@@ -122,53 +122,70 @@ static void bitrev_permute(u64* a, uint32_t log_n) {
   }
 }
 
-int ref_ntt(u64* a, uint32_t log_n, int inverse) {
+/* threads <= 1: the serial loops; otherwise the butterflies of every stage (and the twiddle table, the bit reversal, the
+ * n^-1 scaling) are split over `threads` OpenMP threads -- ark-poly's `parallel` feature does the same with rayon chunks
+ * (SURVEY.md 2.3 [UPSTREAM-RECALLED]); results are identical. */
+int ref_ntt_mt(u64* a, uint32_t log_n, int inverse, int threads) {
   if (log_n > 32) return -1;
   u64 n = 1ull << log_n;
   if (n == 1) return 0;
+  if (threads < 1) threads = 1;
   u64 root32[4], w_n[4];
   fr_mul(root32, FR_ROOT32_CANON, FR_R2);                 /* to Montgomery */
   memcpy(w_n, root32, 32);
   for (uint32_t i = log_n; i < 32; i++) fr_mul(w_n, w_n, w_n);
   if (inverse) fr_inv(w_n, w_n);
-  /* twiddle table w_n^k, k < n/2 */
+  /* twiddle table w_n^k, k < n/2: chunks of 4096 started from w_n^(chunk start) */
   u64* tw = (u64*)malloc((size_t)(n / 2) * 32);
   if (!tw) return -2;
-  memcpy(tw, FR_ONE, 32);
-  for (u64 k = 1; k < n / 2; k++) fr_mul(tw + 4 * k, tw + 4 * (k - 1), w_n);
+  {
+    const u64 half = n / 2, CH = 4096;
+    const long nch = (long)((half + CH - 1) / CH);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long c = 0; c < nch; c++) {
+      u64 k0 = (u64)c * CH, k1 = k0 + CH < half ? k0 + CH : half;
+      fr_pow(tw + 4 * k0, w_n, k0);
+      for (u64 k = k0 + 1; k < k1; k++) fr_mul(tw + 4 * k, tw + 4 * (k - 1), w_n);
+    }
+  }
+  const long nb = (long)(n / 2);
   if (!inverse) {
-    /* DIF: gap n/2 .. 1 */
+    /* DIF: gap n/2 .. 1; butterfly b = (block s, offset k) */
     for (u64 gap = n / 2; gap >= 1; gap >>= 1) {
       u64 step = (n / 2) / gap;
-      for (u64 s = 0; s < n; s += 2 * gap)
-        for (u64 k = 0; k < gap; k++) {
-          u64 *x = a + 4 * (s + k), *y = a + 4 * (s + k + gap), t[4];
-          fr_sub(t, x, y);
-          fr_add(x, x, y);
-          fr_mul(y, t, tw + 4 * (k * step));
-        }
+#pragma omp parallel for num_threads(threads) schedule(static)
+      for (long b = 0; b < nb; b++) {
+        u64 k = (u64)b & (gap - 1), s = ((u64)b - k) << 1;
+        u64 *x = a + 4 * (s + k), *y = a + 4 * (s + k + gap), t[4];
+        fr_sub(t, x, y);
+        fr_add(x, x, y);
+        fr_mul(y, t, tw + 4 * (k * step));
+      }
     }
     bitrev_permute(a, log_n);
   } else {
     bitrev_permute(a, log_n);
     for (u64 gap = 1; gap < n; gap <<= 1) {
       u64 step = (n / 2) / gap;
-      for (u64 s = 0; s < n; s += 2 * gap)
-        for (u64 k = 0; k < gap; k++) {
-          u64 *x = a + 4 * (s + k), *y = a + 4 * (s + k + gap), t[4];
-          fr_mul(t, y, tw + 4 * (k * step));
-          fr_sub(y, x, t);
-          fr_add(x, x, t);
-        }
+#pragma omp parallel for num_threads(threads) schedule(static)
+      for (long b = 0; b < nb; b++) {
+        u64 k = (u64)b & (gap - 1), s = ((u64)b - k) << 1;
+        u64 *x = a + 4 * (s + k), *y = a + 4 * (s + k + gap), t[4];
+        fr_mul(t, y, tw + 4 * (k * step));
+        fr_sub(y, x, t);
+        fr_add(x, x, t);
+      }
     }
     u64 nn[4] = {n, 0, 0, 0}, ninv[4];
     fr_mul(nn, nn, FR_R2);
     fr_inv(ninv, nn);
-    for (u64 i = 0; i < n; i++) fr_mul(a + 4 * i, a + 4 * i, ninv);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long i = 0; i < (long)n; i++) fr_mul(a + 4 * i, a + 4 * i, ninv);
   }
   free(tw);
   return 0;
 }
+int ref_ntt(u64* a, uint32_t log_n, int inverse) { return ref_ntt_mt(a, log_n, inverse, 1); }
 
 /* Montgomery <-> canonical helpers for Fr vectors (arkworks into_repr / from_repr) */
 void ref_fr_from_mont(u64* a, size_t n) { static const u64 one[4] = {1, 0, 0, 0}; for (size_t i = 0; i < n; i++) fr_mul(a + 4 * i, a + 4 * i, one); }

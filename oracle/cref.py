@@ -24,6 +24,8 @@ def lib():
         L = C.CDLL(_SO)
         L.ref_ntt.restype = C.c_int
         L.ref_ntt.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.ref_ntt_mt.restype = C.c_int
+        L.ref_ntt_mt.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int]
         L.ref_msm.restype = C.c_int
         L.ref_msm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
         L.ref_g1_to_affine.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -41,13 +43,13 @@ def _limbs(x, n):
     return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
 
 
-def ntt(arr, inverse=False):
-    """(n,4) uint64 Montgomery Fr -> transformed copy."""
+def ntt(arr, inverse=False, threads=1):
+    """(n,4) uint64 Montgomery Fr -> transformed copy (threads > 1: the stages' butterflies split over OpenMP threads)."""
     a = np.ascontiguousarray(arr, dtype=np.uint64).copy()
     n = a.shape[0]
     log_n = n.bit_length() - 1
     assert 1 << log_n == n
-    rc = lib().ref_ntt(a.ctypes.data, log_n, 1 if inverse else 0)
+    rc = lib().ref_ntt_mt(a.ctypes.data, log_n, 1 if inverse else 0, int(threads))
     assert rc == 0
     return a
 

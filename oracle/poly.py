@@ -96,6 +96,19 @@ class Domain:
         assert len(evals) <= self.size
         return ntt(evals, self.log_size, inverse=True)
 
+    def coset_fft(self, coeffs):
+        """Radix2EvaluationDomain::coset_fft [ark-poly 0.3, UPSTREAM-RECALLED]: distribute_powers(coeffs, g) then fft --
+        the evaluations of the polynomial on the coset g H, g = F::multiplicative_generator()."""
+        from .fields import FR_GENERATOR as g
+        assert len(coeffs) <= self.size
+        return ntt([c * pow(g, i, R) % R for i, c in enumerate(coeffs)], self.log_size)
+
+    def coset_ifft(self, evals):
+        """Radix2EvaluationDomain::coset_ifft: ifft then distribute_powers(coeffs, g^-1)."""
+        from .fields import FR_GENERATOR as g
+        ginv = pow(g, -1, R)
+        return [c * pow(ginv, i, R) % R for i, c in enumerate(self.ifft(evals))]
+
     def evaluate_vanishing_polynomial(self, tau):
         return (pow(tau, self.size, R) - 1) % R
 

@@ -296,3 +296,17 @@ def test_sonic_full_size_verifies(gpu):
     vk = pk.vk_bytes()
     assert oracle_verify(vk, srs.max_degree, TAU, GAMMA, [a * b % F.R_MOD], proof, pc="sonic")
     assert not oracle_verify(vk, srs.max_degree, TAU, GAMMA, [a], proof, pc="sonic")
+
+
+def test_bench_gpus_2_runs_two_sharded_ranks(gpu):
+    """`python bench.py --gpus 2` launches two ranks that prove with sharded MSMs (both on this box's one GPU, gloo
+    exchange) and reports n_gpus = 2 with a real number."""
+    import json, subprocess, sys
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                          "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["constraints"] == 1 << 14

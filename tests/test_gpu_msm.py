@@ -114,6 +114,20 @@ def test_msm_empty_and_errors(gpu, bases4k):
         gpu.msm(B, fr_to_np([1] * 4), base_offset=6)
 
 
+def test_bases_upload_rejects_points_off_the_curve(gpu, bases4k):
+    """An affine point has no infinity flag on this ABI (ark's VariableBaseMSM accepts the identity as a base): a base set
+    containing an identity encoded as (0, 0) or (0, 1), or any other off-curve point, is refused at upload instead of
+    silently yielding a wrong MSM."""
+    pts, dl = bases4k
+    arr = points_to_np(pts[:16])
+    for bad_xy in ((0, 0), (0, 1), (pts[3][0], pts[4][1])):
+        a = arr.copy()
+        a[5] = points_to_np([bad_xy])[0]
+        with pytest.raises(gpu.MarlinHipError, match="not on the curve"):
+            gpu.Bases(a)
+    gpu.Bases(arr)                                         # the clean set uploads
+
+
 def test_msm_skewed_buckets_use_pair_tree(gpu, bases4k):
     """2^16 points, only 3 distinct scalars: a handful of buckets hold ~all points (the thread-per-bucket loop would
     serialise tens of thousands of additions; the driver switches to the pair-tree accumulation)."""

@@ -80,3 +80,39 @@ def test_ntt_dev_out_of_place(gpu):
     assert np.array_equal(dout.download(v.shape), gpu.ntt(v))
     gpu.ntt_dev(dout, dout, log_n, inverse=True)               # in place
     assert np.array_equal(dout.download(v.shape), v)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 4, 9, 12])
+def test_coset_ntt_matches_oracle(gpu, log_n):
+    """mh_ntt_coset = Radix2EvaluationDomain::{coset_fft, coset_ifft} (multiplicative generator 7 / 5): against the oracle,
+    against the definition p(g w^i) by Horner, and as a round trip."""
+    n = 1 << log_n
+    dom = OP.Domain(n)
+    v = rand_fr(n, 300 + log_n)
+    got = np_to_fr(gpu.coset_ntt(fr_to_np(v)))
+    assert got == dom.coset_fft(v)
+    g = F.FR_GENERATOR
+    for i in {0, n // 2, n - 1}:
+        assert got[i] == OP.poly_eval(v, g * dom.element(i) % F.R_MOD)
+    assert np_to_fr(gpu.coset_ntt(fr_to_np(v), inverse=True)) == dom.coset_ifft(v)
+    assert np_to_fr(gpu.coset_ntt(fr_to_np(got), inverse=True)) == v
+
+
+def test_coset_ntt_large_round_trip_and_spot(gpu):
+    log_n = 20
+    n = 1 << log_n
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    x[:, 3] &= np.uint64((1 << 61) - 1)
+    y = gpu.coset_ntt(x)
+    assert np.array_equal(gpu.coset_ntt(y, inverse=True), x)
+    # a sparse polynomial: evaluations on the coset by the definition
+    sp = np.zeros((n, 4), dtype=np.uint64)
+    idx = [0, 1, 12345, n - 1]
+    coeffs = [3, 5, 7, 11]
+    sp[idx] = fr_to_np(coeffs)
+    ev = np_to_fr(gpu.coset_ntt(sp)[[0, 1, 777, n - 1]])
+    w = F.root_of_unity(log_n)
+    for e, i in zip(ev, [0, 1, 777, n - 1]):
+        pt = F.FR_GENERATOR * pow(w, i, F.R_MOD) % F.R_MOD
+        assert e == sum(c * pow(pt, k, F.R_MOD) for c, k in zip(coeffs, idx)) % F.R_MOD

@@ -115,3 +115,23 @@ def test_every_commitment_pinned_by_cpu_msm(gpu, log_n):
         elif shifted is None or commit(label, D - bound, sblind) != shifted[0]:
             bad.append(label + " (shifted)")
     assert not bad, bad
+
+
+@BLS
+def test_gpu_proof_as_wire_bytes_verifies_under_the_pairing(gpu):
+    """prove on the device at 2^12 -> CanonicalSerialize bytes (what a stock arkworks verifier would read) -> the
+    oracle's Marlin::verify with the real pairing: accept / reject (src/test.rs:158-161)."""
+    from tests.verify_adapter import oracle_verify
+    rng = FS.test_rng()
+    a, b = FS.fr_rand(rng), FS.fr_rand(rng)
+    n = 1 << 12
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA)
+    ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
+    pk = GM.index(srs, ncp, ni, mats)
+    flat = GM.prove(pk, inst, wit, SEED)
+    wire = GM.proof_serialize(flat)
+    assert len(wire) == 855 and GM.proof_deserialize(wire) == flat
+    vk = pk.vk_bytes()
+    c = a * b % F.R_MOD
+    assert oracle_verify(vk, srs.max_degree, TAU, GAMMA, [c], wire, use_pairing=True, wire=True)
+    assert not oracle_verify(vk, srs.max_degree, TAU, GAMMA, [a], wire, use_pairing=True, wire=True)

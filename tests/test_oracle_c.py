@@ -12,6 +12,12 @@ def test_c_ntt_matches_python():
         assert np_to_fr(cref.ntt(fr_to_np(v), inverse=True)) == OP.ntt(v, log_n, inverse=True)
     v = rand_fr(32, 99)
     assert np_to_fr(cref.ntt(fr_to_np(v))) == OP.dft_naive(v, 5)
+    # the OpenMP-threaded stages (cpu_baseline's all-core figure) give the same transform, chunked twiddle table included
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 1 << 63, size=(1 << 14, 4), dtype=np.uint64)
+    x[:, 3] &= np.uint64((1 << 61) - 1)
+    for inv in (False, True):
+        assert np.array_equal(cref.ntt(x, inverse=inv, threads=4), cref.ntt(x, inverse=inv, threads=1))
 
 
 def test_c_bases_and_mul_gen():

@@ -62,7 +62,9 @@ def parse_proof(pb, pc="marlin"):
     return pr
 
 
-def oracle_verify(vk_bytes, srs_max_degree, tau, gamma, public_input, proof_bytes, pc="marlin"):
+def oracle_verify(vk_bytes, srs_max_degree, tau, gamma, public_input, proof_bytes, pc="marlin", use_pairing=False, wire=False):
+    """wire=True: proof_bytes are the CanonicalSerialize bytes (mh_marlin_proof_serialize); use_pairing=True: the KZG
+    equation is decided with the BLS12-381 pairing (oracle/pairing.py) instead of the known-tau identity."""
     nv, nc, nnz, comms = parse_vk(vk_bytes, pc)
     pk = MR.IndexKeys()
     pk.pc = pc
@@ -77,4 +79,5 @@ def oracle_verify(vk_bytes, srs_max_degree, tau, gamma, public_input, proof_byte
     srs.gamma_g = EC.scalar_mul(EC.G1_GEN, gamma)
     srs.powers_of_g = _LazyPowers(tau)
     pk.srs = srs
-    return MR.verify(pk, list(public_input), parse_proof(proof_bytes, pc))
+    pr = MR.proof_deserialize(proof_bytes, pc) if wire else parse_proof(proof_bytes, pc)
+    return MR.verify(pk, list(public_input), pr, use_pairing=use_pairing)

@@ -68,6 +68,72 @@ __global__ void k_madpair(u64* out, u32 a, u32 b) {   // mad + addc pairs as in 
   u64 s = 0; for (int i = 0; i < 4; i++) s += acc[i] + hi[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+
+// ---- controls: which VALU classes issue a wave64 instruction in 2 cycles (32 lanes / clock,
+// MI355X_MICROARCH.md "v_fma_f32 2 cyc") and which in 4 (16 lanes / clock)?  Same harness as above: 8 independent chains per
+// thread, 8 waves per SIMD, ITERS x 8 instructions per thread; every kernel also reports shader cycles per
+// wave-instruction from s_memtime, which is independent of the clock the chip happens to run at.
+__device__ __forceinline__ u64 memtime() { u64 t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t; }
+#define CTRL_KERNEL32(NAME, ASM, INIT)                                                                         \
+  __global__ void NAME(u64* out, u32 a, u32 b, unsigned long long* cyc) {                                    \
+    u32 acc[8]; for (int i = 0; i < 8; i++) acc[i] = INIT;                                                     \
+    const u64 t0 = memtime();                                                                                  \
+    for (int it = 0; it < ITERS; it++) {                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(ASM : "+v"(acc[i]) : "v"(b), "v"(a));         \
+    }                                                                                                          \
+    const u64 t1 = memtime();                                                                                  \
+    if ((threadIdx.x & 63) == 0) atomicAdd(cyc, (unsigned long long)(t1 - t0));                                \
+    u64 s = 0; for (int i = 0; i < 8; i++) s += acc[i];                                                        \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                            \
+  }
+CTRL_KERNEL32(k_c_fma_f32, "v_fma_f32 %0, %0, %1, %2", __int_as_float(0x3f800000 + threadIdx.x + i))
+CTRL_KERNEL32(k_c_add_u32, "v_add_u32 %0, %0, %1", threadIdx.x + i + a)
+CTRL_KERNEL32(k_c_and_b32, "v_and_b32 %0, %0, %1", threadIdx.x + i + a)
+CTRL_KERNEL32(k_c_lshrrev_b32, "v_lshrrev_b32 %0, 1, %0", threadIdx.x + i + a)
+CTRL_KERNEL32(k_c_and_or_b32, "v_and_or_b32 %0, %0, %1, %2", threadIdx.x + i + a)
+CTRL_KERNEL32(k_c_add3_u32, "v_add3_u32 %0, %0, %1, %2", threadIdx.x + i + a)
+CTRL_KERNEL32(k_c_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2", threadIdx.x + i + a)
+CTRL_KERNEL32(k_c_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1", threadIdx.x + i + a)
+CTRL_KERNEL32(k_c_addc_co_u32, "v_addc_co_u32 %0, vcc, %1, %0, vcc", threadIdx.x + i + a)
+CTRL_KERNEL32(k_c_add_co_u32, "v_add_co_u32 %0, vcc, %1, %0", threadIdx.x + i + a)
+#define CTRL_KERNEL64(NAME, ASM)                                                                               \
+  __global__ void NAME(u64* out, u32 a, u32 b, unsigned long long* cyc) {                                    \
+    u64 acc[8]; for (int i = 0; i < 8; i++) acc[i] = ((u64)(threadIdx.x + i) << 33) + a;                       \
+    const u32 x = a + threadIdx.x;                                                                             \
+    const u64 t0 = memtime();                                                                                  \
+    for (int it = 0; it < ITERS; it++) {                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(ASM : "+v"(acc[i]) : "v"(x), "v"(b) : "vcc"); \
+    }                                                                                                          \
+    const u64 t1 = memtime();                                                                                  \
+    if ((threadIdx.x & 63) == 0) atomicAdd(cyc, (unsigned long long)(t1 - t0));                                \
+    u64 s = 0; for (int i = 0; i < 8; i++) s += acc[i];                                                        \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                            \
+  }
+CTRL_KERNEL64(k_c_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
+CTRL_KERNEL64(k_c_lshrrev_b64, "v_lshrrev_b64 %0, 30, %0")
+CTRL_KERNEL64(k_c_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %0")
+CTRL_KERNEL64(k_c_pk_fma_f32, "v_pk_fma_f32 %0, %0, %0, %0")
+CTRL_KERNEL64(k_c_fma_f64, "v_fma_f64 %0, %0, %0, %0")
+// the accumulate loop's own mix: per product column 13 v_mad_u64_u32, then and / shift (the 30-bit carry)
+__global__ void k_c_column_mix(u64* out, u32 a, u32 b, unsigned long long* cyc) {
+  u64 acc[4]; u32 lo[4]; for (int i = 0; i < 4; i++) { acc[i] = threadIdx.x + i; lo[i] = 0; }
+  const u32 x = a + threadIdx.x;
+  const u64 t0 = memtime();
+  for (int it = 0; it < ITERS / 8; it++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int k = 0; k < 13; k++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(b) : "vcc");
+      asm volatile("v_and_b32 %0, %2, %1" : "=v"(lo[i]) : "v"((u32)acc[i]), "s"(0x3fffffffu));
+      asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo[i]) : "v"(x));
+      asm volatile("v_lshrrev_b64 %0, 30, %0" : "+v"(acc[i]));
+    }
+  }
+  const u64 t1 = memtime();
+  if ((threadIdx.x & 63) == 0) atomicAdd(cyc, (unsigned long long)(t1 - t0));
+  u64 s = 0; for (int i = 0; i < 4; i++) s += acc[i] + lo[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 template <class F>
 __global__ void k_ffmul(F* out, const F* in, int iters) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,6 +274,44 @@ int main() {
   printf("v_mad_u32_u24      : %8.3f ms  %8.2f Tops/s\n", ms, lanes_ops / ms / 1e9);
   ms = timeit(k_madpair, dim3(blocks), dim3(threads), 5, out, 3u, 5u);
   printf("mad+addc pair      : %8.3f ms  %8.2f Tpairs/s\n", ms, lanes_ops / ms / 1e9);
+
+
+  // ---- controls with in-kernel cycle counts ------------------------------------------------------------------
+  {
+    unsigned long long* dcyc; CK(hipMalloc(&dcyc, 8));
+    const double nwaves = (double)nthreads / 64, waves_per_simd = (double)blocks / p.multiProcessorCount * threads / 64 / 4;
+    printf("controls: %d blocks x %d threads = %.0f waves per SIMD; cyc = shader cycles per wave64 instruction per SIMD (s_memtime)\n",
+           blocks, threads, waves_per_simd);
+#define RUN_CTRL(K, LABEL, NINSTR)                                                                                          \
+    {                                                                                                                       \
+      CK(hipMemset(dcyc, 0, 8));                                                                                            \
+      hipLaunchKernelGGL(K, dim3(blocks), dim3(threads), 0, 0, out, 3u, 5u, dcyc); CK(hipDeviceSynchronize());             \
+      CK(hipMemset(dcyc, 0, 8));                                                                                            \
+      ms = timeit(K, dim3(blocks), dim3(threads), 5, out, 3u, 5u, dcyc);                                                    \
+      unsigned long long hc = 0; CK(hipMemcpy(&hc, dcyc, 8, hipMemcpyDeviceToHost));                                        \
+      const double instr = (double)(NINSTR);                                                                                \
+      printf("%-22s: %8.3f ms  %7.2f T lane-ops/s  %5.2f cyc/instr/SIMD  (eff. clock %.2f GHz)\n", LABEL, ms,               \
+             (double)nthreads * instr / ms / 1e9, (double)hc / 6.0 / nwaves / instr / waves_per_simd,                      \
+             ((double)hc / 6.0 / nwaves) / (ms * 1e6));                                                                     \
+    }
+    const double N8 = (double)ITERS * 8;
+    RUN_CTRL(k_c_fma_f32, "v_fma_f32", N8)
+    RUN_CTRL(k_c_pk_fma_f32, "v_pk_fma_f32", N8)
+    RUN_CTRL(k_c_fma_f64, "v_fma_f64", N8)
+    RUN_CTRL(k_c_add_u32, "v_add_u32", N8)
+    RUN_CTRL(k_c_and_b32, "v_and_b32", N8)
+    RUN_CTRL(k_c_lshrrev_b32, "v_lshrrev_b32", N8)
+    RUN_CTRL(k_c_and_or_b32, "v_and_or_b32", N8)
+    RUN_CTRL(k_c_add3_u32, "v_add3_u32", N8)
+    RUN_CTRL(k_c_add_co_u32, "v_add_co_u32", N8)
+    RUN_CTRL(k_c_addc_co_u32, "v_addc_co_u32", N8)
+    RUN_CTRL(k_c_mad_u32_u24, "v_mad_u32_u24", N8)
+    RUN_CTRL(k_c_mul_lo_u32, "v_mul_lo_u32", N8)
+    RUN_CTRL(k_c_mad_u64_u32, "v_mad_u64_u32", N8)
+    RUN_CTRL(k_c_lshrrev_b64, "v_lshrrev_b64", N8)
+    RUN_CTRL(k_c_lshl_add_u64, "v_lshl_add_u64", N8)
+    RUN_CTRL(k_c_column_mix, "13 mad + and + add + shr", (double)(ITERS / 8) * 4 * 16)
+  }
 
   // field ops
   std::vector<u32> h((nthreads + 8) * 12);
