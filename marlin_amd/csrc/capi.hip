@@ -403,9 +403,16 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     {
       ProfScope pa(c, PF_MSM_ACCUM);
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
-      hipLaunchKernelGGL(F::accum30_kernel, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
-                         (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
-                         (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB);
+      // resident waves per SIMD of the accumulate kernel (register budget 512 / waves): MH_ACC_WAVES = 3 | 4
+      static const int acc_waves = [] { const char* e = getenv("MH_ACC_WAVES"); int w = e ? atoi(e) : 3; return w == 4 ? 4 : 3; }();
+      if (acc_waves == 4)
+        hipLaunchKernelGGL(F::accum30_kernel<4>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
+                           (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
+                           (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB);
+      else
+        hipLaunchKernelGGL(F::accum30_kernel<3>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
+                           (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
+                           (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB);
     }
     hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw,
                        (const F::G1Aff30*)bs.d_table, (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr,

@@ -103,18 +103,40 @@ __device__ __forceinline__ Fq30 f30_sqr_cxx(const Fq30& a) {
 #else
 #define F30_GEN(fn) fn##_BLS12_381
 #endif
-__device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
+// separate product and reduction passes (the round-1 form; kept as the cross-check of the fused form below)
+__device__ __forceinline__ Fq30 f30_mul_sep(const Fq30& a, const Fq30& b) {
   u32 t[2 * Fq30::NL];
   Fq30 r;
   F30_GEN(f30_cols_mul)(t, a.v, b.v);
   F30_GEN(f30_redc)(r.v, t);
   return r;
 }
-__device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
+__device__ __forceinline__ Fq30 f30_sqr_sep(const Fq30& a) {
   u32 t[2 * Fq30::NL];
   Fq30 r;
   F30_GEN(f30_cols_sqr)(t, a.v);
   F30_GEN(f30_redc)(r.v, t);
+  return r;
+}
+// What the kernels use: product and reduction columns summed in ONE accumulator (finely integrated product scanning,
+// gen_fq30.py `fused`): a column costs one mask and one 64-bit shift instead of two masks, two 64-bit shifts and a 64-bit
+// add; 5 of the 26 columns of BLS12-381 move an early carry out to stay below 2^64.  Limb-for-limb equal to the separate
+// form and to the *_cxx versions (mh_selftest_fq30).
+__device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
+  Fq30 r;
+  F30_GEN(f30_mulredc)(r.v, a.v, b.v);
+  return r;
+}
+__device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
+  Fq30 r;
+  F30_GEN(f30_sqrredc)(r.v, a.v);
+  return r;
+}
+// (a b + c d) / R' with ONE Montgomery reduction: both products' columns go into the same accumulator.  For
+// a b + c d < 64 p^2 the result is below 1.2 p.
+__device__ __forceinline__ Fq30 f30_mul2(const Fq30& a, const Fq30& b, const Fq30& c, const Fq30& d) {
+  Fq30 r;
+  F30_GEN(f30_mul2redc)(r.v, a.v, b.v, c.v, d.v);
   return r;
 }
 

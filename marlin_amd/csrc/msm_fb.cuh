@@ -468,10 +468,11 @@ __global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__
 // ---- accumulate: thread per bucket, XYZZ += table point, all in 30-bit limbs -----------------------------------
 // Same structure as msm::accum_kernel (first entry seeds the accumulator, collisions are deferred to the fix-up), buckets
 // taken in the size order computed above, with the lazily reduced arithmetic of fq30.cuh.  Value bounds in units of
-// p (a product of u and v is below 1 + u v / 630): table x < 1, +-y <= 2, zz, zzz <= 1.1; X1 <= 6.2, Y1 <= 3.2 are
+// p (a product of u and v is below 1 + u v / 630): table x < 1, +-y <= 2, zz, zzz <= 1.1; X1 <= 6.2, Y1 <= 2 are
 // loop invariants: P = U2 - X1 + 8p <= 9.1, R = S2 - Y1 + 4p <= 5.1, PP, PPP, Q, R^2 <= 1.2,
-// X3 = (R^2 - PPP + 2p) - 2Q + 3p <= 6.2, Y3 = R (Q - X3 + 8p) - Y1 PPP + 2p <= 3.2.
-__global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
+// X3 = (R^2 - PPP + 2p) - 2Q + 3p <= 6.2, Y3 = (R (Q - X3 + 8p) + (4p - Y1) PPP) / R' <= 1 + (5.1 x 9.2 + 4 x 1.2) / 630 < 1.1.
+template <int WAVES>
+__global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                                u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                                const u32* __restrict__ tot, const u32* __restrict__ perm,
                                                                G1Xyzz30* __restrict__ buckets, u32* __restrict__ pend,
@@ -512,9 +513,9 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(3,
     const Fq30 Q = f30_mul(X1, PP);
     PP = f30_mul(P, PP);                 // PPP
     ZZZ = f30_mul(ZZZ, PP);
-    Y1 = f30_mul(Y1, PP);                // Y1 * PPP
+    const Fq30 nY1 = f30_sub<4>(zero, Y1);                      // 4p - Y1
     X1 = f30_sub2<3>(f30_sub<2>(f30_sqr(R), PP), Q);
-    Y1 = f30_sub<2>(f30_mul(R, f30_sub<8>(Q, X1)), Y1);
+    Y1 = f30_mul2(R, f30_sub<8>(Q, X1), nY1, PP);               // Y3 = R (Q - X3) - Y1 PPP: two products, ONE reduction
   }
   store30(buckets[gid].c[0], X1); store30(buckets[gid].c[1], Y1); store30(buckets[gid].c[2], ZZ); store30(buckets[gid].c[3], ZZZ);
   pend[gid] = np;
@@ -624,7 +625,15 @@ __global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ 
   same(f30_to_fq(c30), ff_mul(a, b));
   {
     const Fq30 cx = f30_mul_cxx(a30, b30), sx = f30_sqr_cxx(a30), sg = f30_sqr(a30);
-    for (int k = 0; k < Fq30::NL; k++) ok = ok && cx.v[k] == c30.v[k] && sx.v[k] == sg.v[k];
+    const Fq30 cs = f30_mul_sep(a30, b30), ss = f30_sqr_sep(a30);
+    for (int k = 0; k < Fq30::NL; k++) ok = ok && cx.v[k] == c30.v[k] && sx.v[k] == sg.v[k] && cs.v[k] == c30.v[k] && ss.v[k] == sg.v[k];
+    // lazily reduced operands (up to ~16 p: what the accumulate loop feeds the multiplier) through all three forms
+    const Fq30 wa = f30_add(f30_add(f30_dbl(f30_dbl(a30)), f30_dbl(f30_dbl(b30))), a30), wb = f30_sub<8>(f30_dbl(f30_dbl(b30)), a30);
+    const Fq30 w1 = f30_mul(wa, wb), w2 = f30_mul_sep(wa, wb), w3 = f30_mul_cxx(wa, wb);
+    const Fq30 q1 = f30_sqr(wa), q2 = f30_sqr_sep(wa), q3 = f30_sqr_cxx(wa);
+    for (int k = 0; k < Fq30::NL; k++) ok = ok && w1.v[k] == w2.v[k] && w1.v[k] == w3.v[k] && q1.v[k] == q2.v[k] && q1.v[k] == q3.v[k];
+    // two products under one reduction
+    same(f30_to_fq(f30_mul2(a30, b30, wa, wb)), ff_add(ff_mul(a, b), ff_mul(f30_to_fq(wa), f30_to_fq(wb))));
   }
   same(f30_to_fq(f30_sub<2>(f30_add(c30, a30), a30)), ff_mul(a, b));
   same(f30_to_fq(f30_mul(f30_sub<2>(a30, b30), f30_add(a30, b30))), f30_to_fq(f30_sub<2>(f30_sqr(a30), f30_sqr(b30))));

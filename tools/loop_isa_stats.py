@@ -16,6 +16,8 @@ with tempfile.TemporaryDirectory() as td:
     lines = open(out).read().split("\n")
 for kern in ("accum30_kernel", "accum_kernel"):
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN\d+msm(fb)?\d+%s\w*:" % kern, l)]
+    if len(starts) > 1:
+        print("%s: %d instantiations, the first is shown" % (kern, len(starts)))
     if not starts:
         continue
     start = starts[0]
