@@ -1,0 +1,22 @@
+//! Link-time check: the address of every binding of src/ffi.rs is taken, so a symbol missing from
+//! libmarlin_hip.so fails the build of this test.  UNCOMPILED (see Cargo.toml).
+use marlin_hip::ffi::*;
+
+#[test]
+fn every_header_symbol_links() {
+    let addrs: &[usize] = &[
+        mh_curve_info as usize, mh_init as usize, mh_init_devices as usize, mh_shutdown as usize, mh_last_error as usize,
+        mh_set_stream as usize, mh_synchronize as usize, mh_device_info as usize, mh_alloc as usize, mh_free as usize,
+        mh_memcpy_h2d as usize, mh_memcpy_d2h as usize, mh_memcpy_d2d as usize, mh_memset as usize, mh_ntt as usize,
+        mh_ntt_dev as usize, mh_ntt_coset as usize, mh_ntt_coset_dev as usize, mh_bases_upload as usize,
+        mh_bases_from_dev as usize, mh_srs_powers as usize, mh_bases_download as usize, mh_bases_free as usize,
+        mh_bases_len as usize, mh_bases_precompute as usize, mh_bases_table_info as usize, mh_msm_path_counts as usize,
+        mh_msm as usize, mh_msm_dev as usize, mh_msm_batch_dev as usize, mh_g1_to_affine as usize, mh_g1_sum as usize,
+        mh_marlin_index as usize, mh_marlin_index_pc as usize, mh_marlin_pk_free as usize, mh_marlin_pk_info as usize,
+        mh_marlin_vk_bytes as usize, mh_marlin_prove as usize, mh_marlin_proof_serialize as usize,
+        mh_marlin_proof_deserialize as usize, mh_marlin_set_shard as usize, mh_marlin_test_allgather as usize,
+        mh_marlin_get_poly as usize, mh_prof_enable as usize, mh_prof_reset as usize, mh_prof_get as usize,
+        mh_selftest_fq30 as usize,
+    ];
+    assert!(addrs.iter().all(|a| *a != 0));
+}
