@@ -163,3 +163,30 @@ pub fn kzg_open_with_witness(
     };
     Ok(kzg10::Proof { w: w.into_affine(), random_v })
 }
+
+/// Hook for the optional patched ark-ec (vendor/ark-ec-hip/msm_hip.patch): `Some(result)` when `G` is BLS12-381 G1
+/// and the MSM is large enough for the device, `None` to let ark-ec's own Pippenger run.  `scalars` are canonical
+/// `BigInteger256`s (what `VariableBaseMSM::multi_scalar_mul` receives), passed with `scalars_are_montgomery = 0`.
+/// The base slice is resolved to (handle, offset) through `srs_cache`: slices of one `powers_of_g` allocation share
+/// the upload made for the enclosing allocation's first sighting, later sub-slices are uploaded on demand.
+pub fn msm_hook<G: AffineCurve + 'static>(
+    bases: &[G],
+    scalars: &[<G::ScalarField as PrimeField>::BigInt],
+) -> Option<G::Projective> {
+    use std::any::{Any, TypeId};
+    let n = core::cmp::min(bases.len(), scalars.len());
+    if TypeId::of::<G>() != TypeId::of::<G1Affine>() || n < GPU_MSM_THRESHOLD {
+        return None;
+    }
+    // SAFETY: G == G1Affine was just checked
+    let bases: &[G1Affine] = unsafe { core::slice::from_raw_parts(bases.as_ptr() as *const G1Affine, n) };
+    let srs = srs_cache().get_or_upload(bases).ok()?;
+    let mut limbs = Vec::with_capacity(n * 4);
+    for s in &scalars[..n] {
+        limbs.extend_from_slice(s.as_ref());
+    }
+    let mut out = [0u64; 18];
+    check(unsafe { ffi::mh_msm(srs.handle, 0, limbs.as_ptr(), 0, n, out.as_mut_ptr()) }).ok()?;
+    let p: G1Projective = g1_from_jacobian_limbs(&out);
+    (Box::new(p) as Box<dyn Any>).downcast::<G::Projective>().ok().map(|b| *b)
+}
