@@ -40,3 +40,15 @@ def test_product_does_not_use_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".cpp", ".inc")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_rust_shim_binds_the_whole_header():
+    """shim/src/ffi.rs (uncompiled Rust side of the boundary) declares exactly the header's entry points, and
+    shim/tests/ffi_symbols.rs takes the address of each of them."""
+    names = _declared()
+    ffi = open(os.path.join(ROOT, "shim", "src", "ffi.rs")).read()
+    bound = sorted(set(re.findall(r"pub fn (mh_[a-z0-9_]+)\s*\(", ffi)))
+    assert bound == names, (set(names) - set(bound), set(bound) - set(names))
+    link = open(os.path.join(ROOT, "shim", "tests", "ffi_symbols.rs")).read()
+    for n in names:
+        assert "%s as usize" % n in link, n
