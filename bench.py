@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--log-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["marlin-prove", "hotpath-inventory"], default=None)
+    ap.add_argument("--simulate-rank", default=None, metavar="R/G",
+                    help="MEASUREMENT AID, one GPU: run what rank R of G would run (its bucket range of every MSM + the replicated "
+                         "AHP rounds) with the exchange replaced by a local copy; the proof is not valid and the JSON line says so")
     ap.add_argument("--pc", choices=["marlin", "sonic"], default="marlin",
                     help="polynomial commitment scheme (MarlinKZG10 = headline config; SonicKZG10 = configs[4]); "
                          "the curve is chosen with MARLIN_AMD_CURVE=bls12_381|bn254")
@@ -267,6 +270,10 @@ def main():
         if world > 1:
             from marlin_amd import dist as MD
             MD.enable_sharded_prove(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
+        elif args.simulate_rank:
+            from marlin_amd import dist as MD
+            sr, sg = (int(x) for x in args.simulate_rank.split("/"))
+            MD.enable_simulated_shard(sr, sg)
     else:
         wl = HotPathInventory(M, args.log_constraints, rank, world)
 
@@ -303,7 +310,8 @@ def main():
     # pairs the timed launches really process: the prover folds each opening's shifted witness into the witness MSM
     from marlin_amd import workload as W
     msms_run = W.msm_executed(wl.N, pc=args.pc) if workload == "marlin-prove" else wl.msms
-    msm_pairs_rank = sum((abs(n) * (rank + 1)) // world - (abs(n) * rank) // world for n, _ in msms_run)
+    # bucket-range sharding: every rank handles all pairs' digits that fall into its 1/world of the buckets
+    msm_pairs_rank = sum(abs(n) for n, _ in msms_run) / world
     # the MSMs of a commit round run as one batched launch: bytes per launch = all pairs of the step / launches of the step
     bytes_per_launch = 128.0 * msm_pairs_rank * args.steps / max(1, acc_launches)
     avg_launch_ms = acc_ms / max(1, acc_launches)
@@ -357,7 +365,7 @@ def main():
                                + "DummyCircuit 2^%d constraints, BLS12-381, MarlinKZG10 (benches/bench.rs shape; SURVEY.md Appendix A)"
                                % args.log_constraints,
                    "constraints": wl.N, "curve": "BLS12-381", "pc": "MarlinKZG10",
-                   "parallelism": "msm-point-sharded x%d (one all_gather of partial points per commit round), AHP rounds replicated" % world},
+                   "parallelism": "msm sharded by bucket range x%d (one all_gather of partial points per commit round), AHP rounds replicated" % world},
         "breakdown_ms_per_step": {"ntt": round(ntt_ms / args.steps, 3), "msm": round(msm_ms / args.steps, 3),
                                   "msm_accum": round(acc_ms / args.steps, 3), "glue": round(glue_ms / args.steps, 3),
                                   "host_and_other": round(ms_per_step - (ntt_ms + msm_ms + glue_ms) / args.steps, 3)},
@@ -372,6 +380,12 @@ def main():
     if _L.CURVE != "bls12_381" or args.pc != "marlin":
         out["dtype"] = "u32-limb Montgomery integers (Fr 256-bit, Fq %d-bit)" % (64 * _L.FQ_LIMBS)
         args.no_cpu_baseline = True          # the C restatement covers the headline configuration only
+    if args.simulate_rank:
+        out["simulated_rank"] = args.simulate_rank
+        out["value"] = None
+        out["note"] = ("simulation of one rank of a multi-GPU run on one GPU (exchange replaced by a local copy): ms_per_step is "
+                       "that rank's time without the all_gather; the proofs made are not valid; not a benchmark result")
+        args.no_cpu_baseline = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

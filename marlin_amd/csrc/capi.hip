@@ -291,8 +291,10 @@ static const BaseSet* find_table(Context& c, const void* b, size_t n, size_t& of
 
 // One group of <= MAX_JOBS jobs.  skewed = true (and nothing written) when a bucket is so overfull that the caller
 // should take the variable-base path with its pair-tree accumulation instead.
+// shard = {rank, world}: this rank accumulates and reduces only the buckets of the partitions v = rank (mod world) and `out`
+// is its PARTIAL sum (partial = true); when the table has fewer partitions than ranks the group is not sharded (partial = false).
 static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* offs, const void* const* d_scalars, const size_t* ns,
-                        int is_mont, HG1* out, bool& skewed) {
+                        int is_mont, HG1* out, bool& skewed, const int* shard, bool& partial) {
   namespace F = msmfb;
   hipStream_t s = c.stream;
   skewed = false;
@@ -304,6 +306,11 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   const u32 nparts = nbt / nb;
   const u32 WT = nparts * nj;
   const size_t WB = (size_t)nbt * nj;
+  F::Own own{0, 1};
+  partial = false;
+  if (shard && shard[1] > 1 && nparts >= (u32)shard[1]) { own.first = (u32)shard[0]; own.stride = (u32)shard[1]; partial = true; }
+  const u32 nown = (nparts - own.first + own.stride - 1) / own.stride;   // owned partitions of every job
+  const u32 nbown = nown * nb;                                           // owned buckets of every job
   const u32 S = F::split_scalars(W);                                     // scalars per count / split block
   F::FbJobs jobs;
   memset(&jobs, 0, sizeof(jobs));
@@ -331,8 +338,9 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   // 32.7 ms at 65536, per 3 proofs), at most SEG buckets each; MH_FB_SEG_THREADS overrides
   u32 seg = msm::SEG;
   static const u64 seg_threads = [] { const char* e = getenv("MH_FB_SEG_THREADS"); return e ? (u64)atoll(e) : 49152ull; }();
-  while (seg > 4 && (u64)nj * (nbt / seg) < seg_threads) seg >>= 1;
-  const u32 nseg = (nbt + seg - 1) / seg;
+  if (seg > nb) seg = nb;                                                // a segment stays inside one partition
+  while (seg > 4 && (u64)nj * (nbown / seg) < seg_threads) seg >>= 1;
+  const u32 nseg = nbown / seg;
   const u32 chunks = nseg >= 4096 ? nseg / 256 : 1;                      // reduce2 in two launches when nseg is large
   MH_TRY(c.msm_seg.ensure((size_t)nj * (nseg + chunks) * sizeof(F::G1Xyzz30)));
   MH_TRY(c.msm_win.ensure((size_t)nj * sizeof(G1Xyzz)));
@@ -345,11 +353,11 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     ProfScope ps(c, PF_MSM);
     u32* key = (u32*)c.msm_dig.ptr; u32* val = (u32*)c.fb_val.ptr;
     u32* d_ptot = (u32*)c.fb_ptot.ptr; u32* d_pstart = d_ptot + WT;
-    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)c.fb_pc.ptr, W, win, is_mont, nparts, pshift, S);
+    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)c.fb_pc.ptr, W, win, is_mont, nparts, pshift, S, own);
     hipLaunchKernelGGL(F::pscan_kernel, dim3(nparts, nj), dim3(1024), 0, s, jobs, (u32*)c.fb_pc.ptr, d_ptot, nparts);
     hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
     hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)c.fb_pc.ptr,
-                       (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S);
+                       (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S, own);
     MH_HIP(hipMemcpyAsync(ptot.data(), c.fb_ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count
@@ -392,7 +400,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     MH_HIP(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     const u64 avg = ent / WB + 1;
-    if (mx > 4096 && (u64)mx > 32 * avg) { skewed = true; return MH_OK; }
+    if (mx > 4096 && (u64)mx > 32 * avg) { skewed = true; partial = false; return MH_OK; }
     // buckets ordered by size, largest first
     u32* d_szh = (u32*)c.tr_sums.ptr + 16;
     MH_HIP(hipMemsetAsync(d_szh, 0, F::SIZE_BINS * 4, s));
@@ -408,11 +416,11 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
       if (acc_waves == 4)
         hipLaunchKernelGGL(F::accum30_kernel<4>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
-                           (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB);
+                           (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
       else
         hipLaunchKernelGGL(F::accum30_kernel<3>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
-                           (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB);
+                           (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
     }
     hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw,
                        (const F::G1Aff30*)bs.d_table, (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr,
@@ -420,7 +428,7 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
     F::G1Xyzz30* seg30 = (F::G1Xyzz30*)c.msm_seg.ptr;
     hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)c.msm_buckets.ptr,
-                       seg30, nbt, nseg, (u32)nj, seg);
+                       seg30, nbt, nseg, (u32)nj, seg, nb, own);
     const size_t r2lds = 256 * sizeof(F::G1Xyzz30);
     if (chunks > 1) {
       F::G1Xyzz30* mid = seg30 + (size_t)nj * nseg;
@@ -447,14 +455,12 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
 
 // Build the window table of a base set: level j = 2^{start_j} * P (c-bit windows tiling 256 bits), affine.
 // Automatic window width: lg(n) - 1, at most 20 (measured on the prover: 2^20-point SRS 51.0 / 42.4 / 40.7 / 44.4 ms per
-// proof at c = 16 / 18 / 19 / 20; 2^22-point SRS 115.8 / 113.2 ms at c = 19 / 20).  With point-sharding over `world` GPUs
-// every rank multiplies 1/world of each MSM, so the width follows n / world (the bucket reduction does not shrink with
-// the shard).
-static uint32_t g_fb_world = 1;
+// proof at c = 16 / 18 / 19 / 20; 2^22-point SRS 115.8 / 113.2 ms at c = 19 / 20).  Multi-GPU proving shards every MSM by
+// bucket range, which leaves the width alone.
 static uint32_t auto_window_bits(size_t n) {
   static const int env_c = [] { const char* e = getenv("MH_FB_C"); return e ? atoi(e) : 0; }();
   if (env_c) return (uint32_t)env_c;
-  size_t eff = n / g_fb_world;
+  size_t eff = n;
   u32 lg = 0;
   while ((1ull << lg) < eff) lg++;
   int cc = (int)lg - 1;
@@ -496,21 +502,14 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   return MH_OK;
 }
 
-// sharded proving changed the number of ranks: rebuild the automatically sized tables for the new shard length
-int fb_set_world(Context& c, uint32_t world) {
-  g_fb_world = world < 1 ? 1 : world;
-  for (auto& kv : c.bases) {
-    BaseSet& bs = kv.second;
-    if (bs.d_table && bs.tab_auto && auto_window_bits(bs.n) != bs.tab_c) MH_TRY(bases_precompute(c, bs, 0));
-  }
-  return MH_OK;
-}
-
-
 // A batch of independent MSMs through one launch sequence.  d_bases[j]: G1Affine[n_j]; d_scalars[j]: Fr[n_j];
 // out_xyz: njobs x 18 limbs (Jacobian).  Jobs with n_j == 0 yield the identity.
+// shard = {rank, world} (nullptr: one GPU): groups on the fixed-base path are sharded by bucket range and partial[j] = 1
+// marks a result that is this rank's share of the sum; every other job is computed in full on every rank (partial[j] = 0).
 int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const void* const* d_scalars, const size_t* ns,
-                     int is_mont, uint64_t* out_xyz) {
+                     int is_mont, uint64_t* out_xyz, const int* shard, uint8_t* partial_out) {
+  if (shard && shard[1] > 1 && !partial_out) return fail(MH_EINVAL, "msm_batch_device: sharded call without a partial-flag array");
+  if (partial_out) memset(partial_out, 0, (size_t)njobs_in);
   HG1 id = HG1::identity();
   for (int j = 0; j < njobs_in; j++) { memcpy(out_xyz + XYZ_L * j, id.X.v, FQ_B); memcpy(out_xyz + XYZ_L * j + FQ_L, id.Y.v, FQ_B); memcpy(out_xyz + XYZ_L * j + 2 * FQ_L, id.Z.v, FQ_B); }
   // process in groups of at most MAX_JOBS non-empty jobs
@@ -530,7 +529,8 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
         const size_t n = ns[live[g0 + nj]];
         size_t o = 0;
         const BaseSet* tb = forced == 0 ? find_table(c, d_bases[live[g0 + nj]], n, o) : nullptr;
-        const u64 e = (u64)(tb ? tb->tab_W : msm::make_plan(n).W) * n;
+        // a table group may still fall back to the variable-base plan (skew, underload, mixed base sets): size for the larger
+        const u64 e = (u64)std::max<u32>(tb ? tb->tab_W : 0, msm::make_plan(n).W) * n;
         if (nj && ent_est + e >= (1ull << 32) - (1ull << 26)) break;
         ent_est += e;
         nj++;
@@ -553,11 +553,12 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
       }
       if (ok && (u64)bs->tab_W * nsum >= 8ull * nj * (1ull << (bs->tab_c - 1))) {
         std::vector<HG1> res(nj);
-        bool skewed = false;
-        MH_TRY(msm_fb_group(c, *bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed));
+        bool skewed = false, part = false;
+        MH_TRY(msm_fb_group(c, *bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, shard, part));
         if (!skewed) {
           c.n_fb_groups++;
           for (int k = 0; k < nj; k++) {
+            if (partial_out) partial_out[live[g0 + k]] = part ? 1 : 0;
             uint64_t* o = out_xyz + XYZ_L * live[g0 + k];
             memcpy(o, res[k].X.v, FQ_B); memcpy(o + FQ_L, res[k].Y.v, FQ_B); memcpy(o + 2 * FQ_L, res[k].Z.v, FQ_B);
           }
@@ -657,7 +658,7 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
 
 int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mont, size_t n, uint64_t* out_xyz) {
   const void* b[1] = {d_bases}; const void* sc[1] = {d_scalars}; size_t ns[1] = {n};
-  return msm_batch_device(c, 1, b, sc, ns, is_mont, out_xyz);
+  return msm_batch_device(c, 1, b, sc, ns, is_mont, out_xyz, nullptr, nullptr);
 }
 
 // --------------------------------------------------------------------------------

@@ -132,8 +132,14 @@ __global__ __launch_bounds__(128) void table_level_kernel(const G1Affine* __rest
 }
 
 // ---- partition pass ------------------------------------------------------------------------------------
+// Own: the partitions (virtual windows of 2^PART_BITS buckets) this rank owns -- all of them on one GPU ({0, 1}); with the
+// MSM sharded by bucket range over G ranks rank g owns the partitions v = g (mod G): every rank recodes
+// every scalar but keeps only the digits that fall into its partitions.  Interleaved, not contiguous, because the
+// buckets are not equally loaded: the windows narrower than c bits (and the top window) only reach the low buckets.
+struct Own { u32 first, stride; };
+__device__ __forceinline__ bool owns(const Own& o, u32 v) { return v % o.stride == o.first; }
 __global__ __launch_bounds__(TPB) void count_kernel(FbJobs jobs, u32* __restrict__ pc, u32 W, Windows win, int is_mont, u32 nparts,
-                                                    u32 pshift, u32 S) {
+                                                    u32 pshift, u32 S, Own own) {
   __shared__ u32 cnt[MAX_PARTS];
   const u32 job = blockIdx.y, blk = blockIdx.x;
   if (blk >= jobs.nblk[job]) return;
@@ -148,7 +154,10 @@ __global__ __launch_bounds__(TPB) void count_kernel(FbJobs jobs, u32* __restrict
       if (is_mont) s = ff_from_mont(s);
       msm::for_each_digit(s, W, win, [&](u32, u32 e) {
         u32 b = e & 0x7fffffffu;
-        if (b) atomicAdd(&cnt[(b - 1) >> pshift], 1u);
+        if (b) {
+          const u32 v = (b - 1) >> pshift;
+          if (owns(own, v)) atomicAdd(&cnt[v], 1u);
+        }
       });
     }
   }
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(MAX_PARTS) void pstart_kernel(const u32* __restrict
 __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const u32* __restrict__ pc, const u32* __restrict__ ptot,
                                                              const u32* __restrict__ pstart, u32* __restrict__ key,
                                                              u32* __restrict__ val, u32 W, Windows win, int is_mont, u32 nparts,
-                                                             u32 pshift, u32 tab_n, u32 S) {
+                                                             u32 pshift, u32 tab_n, u32 S, Own own) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* cur = lds;                                  // [MAX_PARTS] counts -> local starts -> cursors
   u32* gdst = lds + MAX_PARTS;                     // [MAX_PARTS] global position of local entry 0 of each partition
@@ -239,6 +248,7 @@ __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const 
       if (b) {
         b -= 1;
         const u32 v = b >> pshift;
+        if (!owns(own, v)) return;                  // another rank's partition
         const u32 p = atomicAdd(&cur[v], 1u);
         skey[p] = ((b & ((1u << pshift) - 1)) + 1) | (e & 0x80000000u);
         sval[p] = w * tab_n + t0;
@@ -476,13 +486,17 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
                                                                u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                                const u32* __restrict__ tot, const u32* __restrict__ perm,
                                                                G1Xyzz30* __restrict__ buckets, u32* __restrict__ pend,
-                                                               u32* __restrict__ n_deferred, u32 nb, u64 WB) {
+                                                               u32* __restrict__ n_deferred, u32 nb, u64 WB, u32 nparts, Own own) {
   const u64 slot = (u64)blockIdx.x * msm::ACC_TPB + threadIdx.x;
   if (slot >= WB) return;
   const u64 gid = perm[slot];
   u32* lst = sorted_all + fbw[gid / nb].off + base[gid];
   const u32 cnt = tot[gid];
-  if (cnt == 0) { x30_store(buckets + gid, x30_identity()); pend[gid] = 0; return; }
+  if (cnt == 0) {
+    const u32 v = (u32)(gid / nb) % nparts;         // another rank's buckets are never read: nothing to store
+    if (owns(own, v)) { x30_store(buckets + gid, x30_identity()); pend[gid] = 0; }
+    return;
+  }
   Fq30 zero;
 #pragma unroll
   for (int i = 0; i < Fq30::NL; i++) zero.v[i] = 0;
@@ -548,13 +562,16 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
 // ---- reduce1: thread per (job, segment of `seg` buckets), on 30-bit limbs ------------------------------------------
 // sum_b (b + 1) B_b over the job's single bucket set: running sums inside the segment plus (first bucket index) x
 // (segment total) by double-and-add; the result goes to msm::reduce2_kernel in the standard representation.
+// nseg segments cover the buckets of the owned partitions (pbuckets = 2^pshift buckets each, seg divides pbuckets, so
+// a segment never straddles two partitions): local segment s lies in owned partition number (s * seg) / pbuckets
 __global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restrict__ buckets, G1Xyzz30* __restrict__ segsum, u32 nb,
-                                                        u32 nseg, u32 njobs, u32 seg) {
+                                                        u32 nseg, u32 njobs, u32 seg, u32 pbuckets, Own own) {
   u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= njobs * nseg) return;
   const u32 w = gid / nseg, s = gid % nseg;
-  const u32 lo = s * seg;
-  u32 hi = lo + seg; if (hi > nb) hi = nb;
+  const u32 l = s * seg;                                          // index among the owned buckets
+  const u32 lo = (own.first + (l / pbuckets) * own.stride) * pbuckets + l % pbuckets;
+  const u32 hi = lo + seg;
   X30 running = x30_identity(), acc = x30_identity();
   const G1Xyzz30* B = buckets + (u64)w * nb;
   for (u32 b = hi; b-- > lo;) {

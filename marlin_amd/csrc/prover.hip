@@ -223,34 +223,51 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
   return MH_OK;
 }
 
-// ---- multi-GPU: MSM point sharding ---------------------------------------------------
-// Every rank runs the whole prover (AHP rounds replicated) but multiplies only its slice of each
-// coefficient vector; the caller-supplied all_gather (torch.distributed over RCCL/xGMI) exchanges the
-// 144-byte partial points and every rank adds them, so all ranks see identical commitments.
+// ---- multi-GPU: MSM sharding by bucket range -------------------------------------------
+// Every rank runs the whole prover (AHP rounds replicated: all ranks hold every coefficient vector and the whole window
+// table anyway), recodes every scalar, but sorts, accumulates and reduces only the digits that fall into ITS range of
+// the 2^(c-1) buckets; its result is a partial sum.  The caller-supplied all_gather (torch.distributed over RCCL/xGMI)
+// exchanges the 144-byte partial points and every rank adds them, so all ranks see identical commitments.  Unlike a
+// split of the points, this shrinks the sort, the accumulation AND the bucket reduction by the number of ranks and keeps
+// the window width of the one-GPU table.
 struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; } g_shard;
 
 HG1 jac_from(const uint64_t* xyz);
 struct MsmJob { const char* bases; const Fr* scalars; uint64_t n; };
-// all jobs in one launch sequence (msm_batch_device); with sharding, every rank takes slice [lo, hi) of every job and
-// ONE all_gather moves all partial points
+// all jobs in one launch sequence (msm_batch_device) and ONE all_gather for all partial points.  Jobs the fixed-base
+// path did not serve (short vectors, skewed digits) are computed in full by every rank and counted once (rank 0's copy).
 int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<HG1>& out) {
   const int nj = (int)jobs.size();
   out.assign(nj, HG1::identity());
   if (nj == 0) return MH_OK;
   std::vector<const void*> b(nj), sc(nj); std::vector<size_t> ns(nj);
-  for (int j = 0; j < nj; j++) {
-    uint64_t lo = 0, hi = jobs[j].n;
-    if (g_shard.world > 1) { lo = (jobs[j].n * (uint64_t)g_shard.rank) / g_shard.world; hi = (jobs[j].n * (uint64_t)(g_shard.rank + 1)) / g_shard.world; }
-    b[j] = jobs[j].bases + lo * PT_B; sc[j] = jobs[j].scalars + lo; ns[j] = hi - lo;
-  }
+  for (int j = 0; j < nj; j++) { b[j] = jobs[j].bases; sc[j] = jobs[j].scalars; ns[j] = jobs[j].n; }
   std::vector<uint64_t> part((size_t)XYZ_L * nj);
-  MH_TRY(msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), 1, part.data()));
-  if (g_shard.world <= 1) { for (int j = 0; j < nj; j++) out[j] = jac_from(part.data() + XYZ_L * j); return MH_OK; }
+  const bool sharded = g_shard.world > 1;
+  const int sh[2] = {g_shard.rank, g_shard.world};
+  std::vector<uint8_t> partial(nj, 0);
+  int rc = msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), 1, part.data(), sharded ? sh : nullptr, sharded ? partial.data() : nullptr);
+  if (!sharded) { MH_TRY(rc); for (int j = 0; j < nj; j++) out[j] = jac_from(part.data() + XYZ_L * j); return MH_OK; }
   if (!g_shard.cb) return fail(MH_EINVAL, "sharded prove: no all_gather callback registered");
-  std::vector<uint64_t> all(part.size() * g_shard.world);
-  if (g_shard.cb(part.data(), part.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather callback failed");
+  // a rank whose launch failed still enters the collective (with an error marker in the spare word after the points) so
+  // that the other ranks do not block in it; every rank then fails together
+  std::vector<uint64_t> send(part.size() + 1, 0), all((part.size() + 1) * g_shard.world);
+  if (rc == MH_OK) {
+    HG1 id = HG1::identity();
+    for (int j = 0; j < nj; j++) {
+      uint64_t* o = send.data() + XYZ_L * j;
+      if (partial[j] || g_shard.rank == 0) memcpy(o, part.data() + XYZ_L * j, XYZ_L * 8);
+      else { memcpy(o, id.X.v, FQ_B); memcpy(o + FQ_L, id.Y.v, FQ_B); memcpy(o + 2 * FQ_L, id.Z.v, FQ_B); }
+    }
+  } else {
+    send[part.size()] = 1;
+  }
+  if (g_shard.cb(send.data(), send.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather callback failed");
+  MH_TRY(rc);
+  for (int g = 0; g < g_shard.world; g++)
+    if (all[(size_t)g * send.size() + part.size()] != 0) return fail(MH_EHIP, "sharded prove: the MSM of another rank failed");
   for (int j = 0; j < nj; j++)
-    for (int g = 0; g < g_shard.world; g++) out[j] = out[j].add(jac_from(all.data() + (size_t)g * part.size() + XYZ_L * j));
+    for (int g = 0; g < g_shard.world; g++) out[j] = out[j].add(jac_from(all.data() + (size_t)g * send.size() + XYZ_L * j));
   return MH_OK;
 }
 
@@ -480,7 +497,7 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);     // g_shard is read by a running mh_marlin_prove under this lock
   g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
-  return fb_set_world(c, (uint32_t)world);      // no-op without uploaded base sets (and without a device)
+  return MH_OK;                                 // the window table does not depend on the number of ranks (bucket-range sharding)
 }
 
 // ---- wire format (host only; wire_host.h) ------------------------------------------------------------------

@@ -1,10 +1,12 @@
 """Multi-GPU sharding of the MSM (one process per GPU, torch.distributed; backend "nccl" = RCCL over
 xGMI on the GPU box, "gloo" in the CPU tests).
 
-Rank g multiplies scalars/bases [lo_g, hi_g) of every MSM; the per-rank partial results (one Jacobian
-point, 144 bytes) are exchanged with ONE all_gather per batch of MSMs and summed on every rank, so all
-ranks derive the same commitments and the same Fiat-Shamir challenges.  Elliptic-curve addition is not
-an RCCL reduction operator, hence all_gather + local adds instead of all_reduce.
+Inside mh_marlin_prove rank g sorts, accumulates and reduces the buckets [g 2^(c-1) / G, (g+1) 2^(c-1) / G) of
+every MSM (bucket-range sharding; `msm_sharded` below is the plain point-sharded variant for
+callers that hold only a slice of the bases); the per-rank partial results (one Jacobian point, 144 bytes) are
+exchanged with ONE all_gather per batch of MSMs and summed on every rank, so all ranks derive the same
+commitments and the same Fiat-Shamir challenges.  Elliptic-curve addition is not an RCCL reduction operator,
+hence all_gather + local adds instead of all_reduce.
 """
 import ctypes as C
 import numpy as np
@@ -83,6 +85,22 @@ def enable_sharded_prove(dist, device=None):
             import sys
             print("all_gather callback failed:", e, file=sys.stderr)
             return -1
+    cb = _ALLGATHER_T(_cb)
+    _keepalive["cb"] = cb
+    _lib.check(_lib.load().mh_marlin_set_shard(rank, world, C.cast(cb, C.c_void_p), None), "mh_marlin_set_shard")
+
+
+def enable_simulated_shard(rank, world):
+    """MEASUREMENT ONLY: make this process behave like rank `rank` of `world` without any peers -- the exchange is
+    replaced by a local copy of this rank's own partial points into every slot, so the proof bytes are NOT valid, but
+    every kernel the rank would run (its bucket range of every MSM, the replicated AHP rounds) runs and can be timed
+    on a one-GPU box.  Used for the per-rank projection in DESIGN.md 8 (bench.py --simulate-rank)."""
+    def _cb(send, nbytes, recv, _user):
+        src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+        dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+        for g in range(world):
+            dst[g * nbytes:(g + 1) * nbytes] = src
+        return 0
     cb = _ALLGATHER_T(_cb)
     _keepalive["cb"] = cb
     _lib.check(_lib.load().mh_marlin_set_shard(rank, world, C.cast(cb, C.c_void_p), None), "mh_marlin_set_shard")

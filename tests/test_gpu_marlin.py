@@ -132,8 +132,9 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_sharded_prove_two_ranks_equals_single(gpu, tmp_path):
-    """MSM point-sharding across 2 ranks (gloo exchange, both ranks on the one GPU of this box) yields the
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_prove_ranks_equal_single(gpu, tmp_path, world):
+    """MSM sharding by bucket range across 2 and 3 ranks (gloo exchange, all ranks on the one GPU of this box) yields the
     very same proof bytes as the unsharded prover."""
     import subprocess, sys
     a, b = 0x1234567, 0x7654321
@@ -144,11 +145,11 @@ def test_sharded_prove_two_ranks_equals_single(gpu, tmp_path):
     want = GM.prove(pk, inst, wit, bytes(range(32)))
     script = tmp_path / "shard_worker.py"
     script.write_text(SHARD_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29613 + world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
-    for r in range(2):
+    for r in range(world):
         assert open(tmp_path / ("proof%d.bin" % r), "rb").read() == want
 
 
