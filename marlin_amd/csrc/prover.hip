@@ -973,6 +973,10 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   // coset g K, where v_K is the constant g^K - 1:  a = sum_M e_M val_M and b = alpha beta - alpha row - beta col + row_col
   // are combinations of index polynomials whose coset evaluations are part of the key, f needs one forward transform,
   // h_2 one inverse -- three transforms of size K instead of two of size K and three of size 2K.
+  // (The reference zips the coefficient vectors of val_a, val_b, val_c when it forms a, prover.rs:625-637, which truncates a
+  // to the shortest of them -- e.g. to nothing for an all-zero matrix.  That cannot change h_2: every variant of a has degree
+  // < |K|, so it only enters the REMAINDER of the division by v_K, which the reference discards (686-689); the quotient is
+  // that of -b f either way.  tests/test_gpu_marlin.py::test_all_zero_matrix_a_poly_zip_quirk pins it.)
   HFr alpha_beta = alpha * beta;
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::denom_kernel, K, S[1], (const Fr*)pk.ev_row.p, (const Fr*)pk.ev_col.p, arg(alpha), arg(beta), (u64)K);

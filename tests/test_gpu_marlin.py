@@ -214,6 +214,36 @@ def test_random_r1cs_with_coefficients_matches_oracle(gpu, nc, ni_raw, seed):
     assert proof == MR.proof_bytes(pr)
 
 
+def test_all_zero_matrix_a_poly_zip_quirk(gpu):
+    """src/ahp/prover.rs:625-637 builds a_poly by zipping the coefficient vectors of val_a, val_b, val_c: with an all-zero C
+    matrix val_c is the zero polynomial (an empty vector), the zip is empty and a_poly = 0.  The product instead evaluates
+    the full combination on the coset g K.  Both give the same h_2 -- any a of degree < |K| only enters the remainder of
+    the division by v_K, which the reference discards (686-689) -- so the proofs are byte-identical (the oracle mirrors
+    the zip) and verify."""
+    from tests.util import fr_to_np
+    import random
+    R = F.R_MOD
+    rng = random.Random(11)
+    nc, ni = 32, 2
+    inst = [1, rng.randrange(R)]
+    wit = [0] + [rng.randrange(1, R) for _ in range(nc - ni - 1)]          # variable ni is zero
+    A = [[(rng.randrange(1, R), rng.randrange(nc))] for _ in range(nc)]
+    B = [[(rng.randrange(1, R), ni)] for _ in range(nc)]                   # B z = 0 in every row
+    C = [[] for _ in range(nc)]                                            # all-zero matrix
+    cs_raw = AHP.R1CS(inst, wit, A, B, C)
+    cs = AHP.pad_and_square(cs_raw)
+    srs_o = MR.universal_setup(nc, nc, 3 * nc, TAU, GAMMA)
+    pk_o = MR.marlin_index(srs_o, cs)
+    assert len(pk_o.index.polys["c_val"]) == 0 and len(pk_o.index.polys["a_val"]) > 0     # the zip truncates to nothing
+    pr = MR.prove(pk_o, cs, FS.ChaChaRng(SEED, 20))
+    assert MR.verify(pk_o, cs_raw.instance[1:], pr)
+    srs = GM.universal_setup(nc, nc, 3 * nc, TAU, GAMMA)
+    pk = GM.index(srs, nc, ni, [_csr(cs.a), _csr(cs.b), _csr(cs.c)])
+    assert pk.vk_bytes() == MR.vk_bytes(pk_o)
+    proof = GM.prove(pk, fr_to_np(cs.instance), fr_to_np(cs.witness), SEED)
+    assert proof == MR.proof_bytes(pr)
+
+
 def test_index_and_prove_error_paths(gpu):
     import numpy as np
     srs = GM.universal_setup(64, 64, 192, TAU, GAMMA)
