@@ -8,6 +8,7 @@
 #include "msm_fb.cuh"
 #include <cstdlib>
 #include "ntt.cuh"
+#include "ntt30.cuh"
 #include "srs.cuh"
 #include "host_ff.h"
 
@@ -43,6 +44,11 @@ static int ensure_twiddles(Context& c, uint32_t log_n) {
   Fr root = to_dev_fr(hostff::fr_two_adic_root());
   hipLaunchKernelGGL(ntt::build_twiddles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, (Fr*)c.tw, want, root);
   MH_HIP(hipGetLastError());
+  // the same table as w R' mod r on 30-bit limbs (36 B per entry) for the butterflies of ntt30.cuh
+  if (c.tw30) { (void)hipFree(c.tw30); c.tw30 = nullptr; }
+  MH_HIP(hipMalloc(&c.tw30, (size_t)36 << want));
+  hipLaunchKernelGGL(ntt30::build_twiddles30, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, (u32*)c.tw30, (const Fr*)c.tw, (u64)n);
+  MH_HIP(hipGetLastError());
   c.tw_log = want;
   return MH_OK;
 }
@@ -57,10 +63,26 @@ static void plan_passes(uint32_t log_n, uint32_t* bits, int* npass) {
   *npass = np;
 }
 
+// MH_NTT=32 selects the 32-bit-limb radix-2 kernel of ntt.cuh (the cross-check of the 30-bit radix-8 kernel of ntt30.cuh)
+static bool ntt_use30() { static const bool v = [] { const char* e = getenv("MH_NTT"); return !(e && atoi(e) == 32); }(); return v; }
+
 static int launch_pass(Context& c, const Fr* x, Fr* y, uint32_t log_n, uint32_t B, uint32_t logP, uint32_t flags,
                        const Fr& ninv, uint64_t in_len) {
   uint32_t logc = log_n - B;
   if (logc > (uint32_t)ntt::MAX_LOGC) logc = ntt::MAX_LOGC;
+  if (ntt_use30()) {
+    const uint64_t blocks30 = (1ull << (log_n - B)) >> logc;
+    const u32* tw30 = (const u32*)c.tw30;
+    // stages per register round: 2 from 2^23 points on, 1 below (measured, see ntt30.cuh); MH_NTT_NS overrides
+    static const int env_ns = [] { const char* e = getenv("MH_NTT_NS"); return e ? atoi(e) : 0; }();
+    const int ns = env_ns ? env_ns : (log_n >= 23 ? 2 : 1);
+#define NTT30_LAUNCH(LC, NS) hipLaunchKernelGGL((ntt30::pass30_kernel<LC, NS, 256, 4, 0, false>), dim3((unsigned)blocks30), dim3(256), \
+    ntt30::pass_lds_bytes(B, (int)logc, logP == 0, 0, false), c.stream, x, y, tw30, log_n, B, logP, flags, ninv, (u64)in_len)
+    if (ns == 2) { switch (logc) { case 0: NTT30_LAUNCH(0, 2); break; case 1: NTT30_LAUNCH(1, 2); break; default: NTT30_LAUNCH(2, 2); break; } }
+    else { switch (logc) { case 0: NTT30_LAUNCH(0, 1); break; case 1: NTT30_LAUNCH(1, 1); break; default: NTT30_LAUNCH(2, 1); break; } }
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+  }
   uint64_t blocks = (1ull << (log_n - B)) >> logc;
   size_t lds = ntt::pass_lds_bytes(B, (int)logc);
   dim3 grid((unsigned)blocks), block(ntt::THREADS);
@@ -82,6 +104,12 @@ static int ntt_set_attrs() {
   MH_HIP(hipFuncSetAttribute((const void*)ntt::pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)ntt::pass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)ntt::pass_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const int lds30 = (int)ntt30::pass_lds_bytes(ntt30::MAX_B, ntt30::MAX_LOGC, true, 0, false);
+#define NTT30_ATTR(NS) \
+  MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<0, NS, 256, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30)); \
+  MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<1, NS, 256, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30)); \
+  MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<2, NS, 256, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30));
+  NTT30_ATTR(1) NTT30_ATTR(2)
   g_ntt_attr_done = true;
   return MH_OK;
 }
@@ -118,14 +146,16 @@ int ntt_device_len(Context& c, const void* d_in, uint64_t in_len, void* d_out, u
     Fr* dst;
     if (p == np - 1) dst = (Fr*)d_out;
     else dst = (Fr*)c.ntt_tmp[p & 1].ptr;
+    // flags: bit 0 = last pass of an inverse transform (n^-1, index negation), bit 1 = last pass (canonical residues out)
+    const uint32_t pass_flags = ((inverse && p == np - 1) ? 1u : 0u) | (p == np - 1 ? 2u : 0u);
     // last pass writes d_out; if d_out == src of this pass (only when np == 1 and in-place) bounce via scratch
     if (p == np - 1 && (const void*)dst == (const void*)src) {
       MH_TRY(c.ntt_tmp[0].ensure(bytes));
       dst = (Fr*)c.ntt_tmp[0].ptr;
-      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, (inverse && p == np - 1) ? 1u : 0u, ninv, p == 0 ? in_len : (1ull << log_n)));
+      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, pass_flags, ninv, p == 0 ? in_len : (1ull << log_n)));
       MH_HIP(hipMemcpyAsync(d_out, dst, bytes, hipMemcpyDeviceToDevice, c.stream));
     } else {
-      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, (inverse && p == np - 1) ? 1u : 0u, ninv, p == 0 ? in_len : (1ull << log_n)));
+      MH_TRY(launch_pass(c, src, dst, log_n, bits[p], logP, pass_flags, ninv, p == 0 ? in_len : (1ull << log_n)));
     }
     src = dst;
     logP += bits[p];
@@ -765,7 +795,8 @@ int mh_shutdown(void) {
   (void)hipStreamSynchronize(c.stream);
   (void)mh_marlin_release_all();
   if (c.tw) (void)hipFree(c.tw);
-  c.tw = nullptr; c.tw_log = 0;
+  if (c.tw30) (void)hipFree(c.tw30);
+  c.tw = nullptr; c.tw30 = nullptr; c.tw_log = 0;
   c.ntt_tmp[0].release(); c.ntt_tmp[1].release(); c.io.release();
   c.msm_dig.release(); c.msm_sorted.release(); c.msm_bh.release(); c.msm_tot.release(); c.msm_base.release();
   c.msm_buckets.release(); c.msm_seg.release(); c.msm_win.release(); c.msm_pend.release();

@@ -76,6 +76,7 @@ struct Context {
 
   // NTT
   void* tw = nullptr;        // Fr[2^tw_log]
+  void* tw30 = nullptr;      // the same table as 9 x 30-bit limbs of w R' mod r (ntt30.cuh), 36 B per entry
   uint32_t tw_log = 0;
   Scratch ntt_tmp[2];
   Scratch io;                // staging for host-pointer entry points

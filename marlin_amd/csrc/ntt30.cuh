@@ -1,0 +1,289 @@
+// NTT passes on 30-bit limbs (the kernel the prover's transforms run on).
+//
+// Same transform, same pass structure and Stockham indexing as ntt.cuh (which stays as the 32-bit cross-check,
+// MH_NTT=32): ceil(log n / 8) out-of-place passes over R x C tiles held in LDS.  What changes is the inside of a pass:
+//
+//  * Arithmetic.  An Fr multiplication on 8 x 32-bit limbs is 128 v_mad_u64_u32 + 128 v_addc_co_u32 (a 64-bit
+//    accumulator overflows after two products) plus conditional corrections in every addition and subtraction.  On
+//    9 x 30-bit limbs (R' = 2^270) it is 162 v_mad_u64_u32 with one mask + shift per column (gen_fq30.py, the same
+//    generator as the base field of the bucket accumulation), and because R' / r = 2^15 the butterflies never reduce:
+//    a' = a + w b, b' = a - w b + 2 r grow by at most 2 r per stage and are brought back below 2 r (r on the last pass)
+//    once per pass.  The transform is linear, so the DATA keeps its standard representation: an element a R (R = 2^256)
+//    is re-sliced into 30-bit limbs as the integer it is, multiplied by twiddles held as w R' mod r, and the Montgomery
+//    reduction by R' returns a w R.  Only the twiddle table exists in a second form (tw30, 36 B per entry).
+//  * Rounds.  A round takes 2^NS elements per work item into registers, runs NS stages on them and writes them back.
+//    Measured on MI355X (profiles/r02c_ntt_variants.txt): NS = 3 (8 elements, 188 VGPRs, 128-thread blocks) is SLOWER than
+//    NS = 1 (10.6 / 8.7 ms vs 5.9 ms per proof) -- two waves per SIMD cannot cover the LDS and twiddle latencies of a round
+//    -- NS = 2 wins from 2^23 points on (1.20 vs 1.23 ms), NS = 1 below (0.160 vs 0.184 ms at 2^20); LDS padding, four
+//    instead of three resident blocks and LDS-staged first-pass twiddles change nothing measurable: the kernel is bound
+//    by VALU issue (384 instructions per butterfly at NS = 1, 164 of them v_mad_u64_u32; 519 in ntt.cuh).  An ablation
+//    without barriers and without twiddle loads runs 10 % faster, which bounds what further latency hiding can give.
+//  * LDS holds the tile limb-major (9 arrays of words), optionally padded (PAD).
+//  * Twiddles are read from tw30 through L1/L2: the first pass needs 2^B - 1 per tile (shared by its columns), the second
+//    pass's 2.4 MB stay L2-resident, a third pass reads each of its twiddles once from HBM.
+//
+// Reference semantics: ark-poly 0.3 GeneralEvaluationDomain::{fft, ifft} (call sites /root/reference
+// src/ahp/prover.rs:326,350-351,359,365,427,488,532-535,545,655,681).
+#pragma once
+#include "ff.cuh"
+#include "fq30.cuh"
+
+namespace ntt30 {
+
+#ifdef MH_CURVE_BN254
+using RP = Fq30Params_BN254_FR;
+#define FR30_GEN(fn) fn##_BN254_FR
+#else
+using RP = Fq30Params_BLS12_381_FR;
+#define FR30_GEN(fn) fn##_BLS12_381_FR
+#endif
+
+constexpr int NL = 9;
+constexpr int MAX_B = 8;
+constexpr int MAX_LOGC = 2;
+static_assert(RP::NL == NL, "Fr on nine 30-bit limbs");
+
+struct Fr30 { u32 v[NL]; };
+
+// ---- representation changes (no arithmetic: the same integer on a different limb grid) ---------------------------
+__device__ __forceinline__ Fr30 slice30(const Fr& x) {
+  Fr30 r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const int bit = 30 * i, w = bit >> 5, s = bit & 31;
+    u32 lo = x.v[w] >> s;
+    if (s > 2 && w + 1 < Fr::N) lo |= x.v[w + 1] << (32 - s);
+    r.v[i] = lo & M30;
+  }
+  return r;
+}
+// value < 2^256, limbs normalised
+__device__ __forceinline__ Fr pack32(const Fr30& a) {
+  Fr r;
+#pragma unroll
+  for (int j = 0; j < Fr::N; j++) {
+    const int bit = 32 * j, i = bit / 30, s = bit % 30;
+    u32 w = a.v[i] >> s;
+    if (i + 1 < NL) w |= a.v[i + 1] << (30 - s);
+    if (s > 28 && i + 2 < NL) w |= a.v[i + 2] << (60 - s);
+    r.v[j] = w;
+  }
+  return r;
+}
+
+// ---- lazily reduced field operations ------------------------------------------------------------------------------
+__device__ __forceinline__ Fr30 add30(const Fr30& a, const Fr30& b) {
+  Fr30 r;
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    u32 s = a.v[i] + b.v[i] + c;
+    if (i < NL - 1) { r.v[i] = s & M30; c = s >> 30; } else r.v[i] = s;
+  }
+  return r;
+}
+// a - b + 2 r, for b <= 2 r
+__device__ __forceinline__ Fr30 sub30(const Fr30& a, const Fr30& b) {
+  Fr30 r;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    int s = (int)(a.v[i] - b.v[i]) + (int)RP::P2[i] + c;
+    if (i < NL - 1) { r.v[i] = (u32)s & M30; c = s >> 30; } else r.v[i] = (u32)s;
+  }
+  return r;
+}
+__device__ __forceinline__ Fr30 mul30(const Fr30& a, const u32* w) {
+  Fr30 r;
+  FR30_GEN(f30_mulredc)(r.v, a.v, w);
+  return r;
+}
+// a -= K r if a >= K r
+template <int K>
+__device__ __forceinline__ void cond_sub(Fr30& a) {
+  u32 t[NL];
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const u32 kp = K == 1 ? RP::P[i] : (K == 2 ? RP::P2[i] : (K == 4 ? RP::P4[i] : (K == 8 ? RP::P8[i] : RP::P16[i])));
+    int s = (int)(a.v[i] - kp) + c;
+    if (i < NL - 1) { t[i] = (u32)s & M30; c = s >> 30; } else { t[i] = (u32)s; c = s; }
+  }
+  if (c >= 0) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) a.v[i] = t[i];
+  }
+}
+// a < 32 r  ->  a < 2 r (full = false) or the canonical a < r (full = true)
+template <bool FULL>
+__device__ __forceinline__ void reduce_ladder(Fr30& a) {
+  cond_sub<16>(a); cond_sub<8>(a); cond_sub<4>(a); cond_sub<2>(a);
+  if (FULL) cond_sub<1>(a);
+}
+// (a, b) <- (a + w b, a - w b + 2 r): w b < 1.01 r whatever the (lazily reduced) b, so both grow by at most 2 r
+__device__ __forceinline__ void butterfly(Fr30& a, Fr30& b, const u32* w) {
+  const Fr30 t = mul30(b, w);
+  b = sub30(a, t);
+  a = add30(a, t);
+}
+
+// ---- tile in LDS: limb-major, 4 words of padding per 32 -------------------------------------------------------------
+// PAD: log2 of the words of padding inserted after every 32 words of a limb array (-1: none)
+template <int PAD>
+__device__ __host__ __forceinline__ u32 phys(u32 a) { return PAD < 0 ? a : a + ((a >> 5) << (PAD < 0 ? 0 : PAD)); }
+template <int PAD>
+__device__ __forceinline__ Fr30 tile_load(const u32* tile, u32 tw, u32 a) {
+  Fr30 r;
+  const u32 p = phys<PAD>(a);
+#pragma unroll
+  for (int l = 0; l < NL; l++) r.v[l] = tile[l * tw + p];
+  return r;
+}
+template <int PAD>
+__device__ __forceinline__ void tile_store(u32* tile, u32 tw, u32 a, const Fr30& x) {
+  const u32 p = phys<PAD>(a);
+#pragma unroll
+  for (int l = 0; l < NL; l++) tile[l * tw + p] = x.v[l];
+}
+
+// twiddle table in the 30-bit form: tw30[9 i + l] = limb l of (tw[i] R' / R mod r), same indexing as ntt.cuh's table
+__global__ __launch_bounds__(256) void build_twiddles30(u32* __restrict__ tw30, const Fr* __restrict__ tw, u64 n) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr c;
+#pragma unroll
+  for (int k = 0; k < Fr::N; k++) c.v[k] = RP::TO30[k];
+  const Fr30 w = slice30(ff_mul(ff_load(tw + i), c));      // w R * (R' mod r) / R = w R' mod r, canonical
+#pragma unroll
+  for (int l = 0; l < NL; l++) tw30[9 * i + l] = w.v[l];
+}
+
+// NS stages (t .. t + NS - 1) of the tile's B on 2^NS elements per work item.  Element j of an item is row
+// u0 + j m (m = 2^t) of column c; stage t + s pairs j with j + 2^s (bit s of j clear) under the twiddle of index
+// i + (j mod 2^s) m at that stage.  TWL: twiddles from the LDS copy of tw30[1 .. R) (first pass) or from global memory.
+template <int NS, int LOGC, bool TWL, int THREADS, int PAD>
+__device__ __forceinline__ void round_stages(u32* tile, u32 tw_words, const u32* __restrict__ twsrc, u32 B, u32 t, u32 logP,
+                                             u64 jbase) {
+  constexpr int C = 1 << LOGC;
+  constexpr int E = 1 << NS;
+  const u32 R = 1u << B, m = 1u << t;
+  const u32 items = (R >> NS) << LOGC;
+  const u64 P = 1ull << logP;
+  for (u32 idx = threadIdx.x; idx < items; idx += THREADS) {
+    const u32 c = idx & (C - 1), q = idx >> LOGC;
+    const u32 i = q & (m - 1), u0 = ((q >> t) << (t + NS)) + i;
+    const u64 k = (jbase + c) & (P - 1);
+    Fr30 e[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) e[j] = tile_load<PAD>(tile, tw_words, ((u0 + j * m) << LOGC) + c);
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+#pragma unroll
+      for (int g = 0; g < (1 << s); g++) {            // g = j mod 2^s: one twiddle for all pairs of this residue
+        const u64 ti = (P << (t + s)) + k + ((u64)(i + g * m) << logP);
+        u32 w[NL];
+        if (TWL) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) w[l] = twsrc[9 * (u32)ti + l];
+        } else {
+          const u32* p = twsrc + 9 * ti;
+#pragma unroll
+          for (int l = 0; l < NL; l++) w[l] = p[l];
+        }
+#pragma unroll
+        for (int j = g; j < E; j += (2 << s)) butterfly(e[j], e[j + (1 << s)], w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < E; j++) tile_store<PAD>(tile, tw_words, ((u0 + j * m) << LOGC) + c, e[j]);
+  }
+}
+
+// One Stockham pass (arguments as ntt::pass_kernel; tw30 instead of tw).
+template <int LOGC, int MAXNS, int THREADS, int WAVES, int PAD, bool TWLDS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pass30_kernel(const Fr* __restrict__ x, Fr* __restrict__ y, const u32* __restrict__ tw30,
+                                                         u32 log_n, u32 B, u32 logP, u32 flags, Fr ninv, u64 in_len) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds30[];
+  constexpr int C = 1 << LOGC;
+  const u32 R = 1u << B;
+  const u64 n = 1ull << log_n;
+  const u64 stride = n >> B;
+  const u64 jbase = (u64)blockIdx.x << LOGC;
+  const u32 tid = threadIdx.x;
+  const u32 tw_words = phys<PAD>(R << LOGC);
+  u32* tile = lds30;
+  u32* twl = lds30 + NL * tw_words;                  // first pass only: tw30[0 .. R)
+
+  // ---- load: row r (stride n / R), column c -> tile row bitrev_B(r); missing tail reads as zero
+  for (u32 idx = tid; idx < (R << LOGC); idx += THREADS) {
+    const u32 c = idx & (C - 1), r = idx >> LOGC;
+    const u64 gi = (jbase + c) + (u64)r * stride;
+    Fr30 v;
+    if (gi < in_len) v = slice30(ff_load(x + gi));
+    else {
+#pragma unroll
+      for (int l = 0; l < NL; l++) v.v[l] = 0;
+    }
+    const u32 rr = B ? (__brev(r) >> (32 - B)) : 0;
+    tile_store<PAD>(tile, tw_words, (rr << LOGC) + c, v);
+  }
+  if (logP == 0 && TWLDS)
+    for (u32 idx = tid; idx < R * NL; idx += THREADS) twl[idx] = tw30[idx];
+  __syncthreads();
+
+  // ---- B stages in rounds of 3 (then 2 or 1)
+  for (u32 t = 0; t < B;) {
+    const u32 ns = B - t >= (u32)MAXNS ? (u32)MAXNS : B - t;
+    if (logP == 0 && TWLDS) {
+      if (MAXNS >= 3 && ns == 3) round_stages<MAXNS >= 3 ? 3 : 1, LOGC, true, THREADS, PAD>(tile, tw_words, twl, B, t, 0, jbase);
+      else if (ns == 2) round_stages<2, LOGC, true, THREADS, PAD>(tile, tw_words, twl, B, t, 0, jbase);
+      else round_stages<1, LOGC, true, THREADS, PAD>(tile, tw_words, twl, B, t, 0, jbase);
+    } else {
+      if (MAXNS >= 3 && ns == 3) round_stages<MAXNS >= 3 ? 3 : 1, LOGC, false, THREADS, PAD>(tile, tw_words, tw30, B, t, logP, jbase);
+      else if (ns == 2) round_stages<2, LOGC, false, THREADS, PAD>(tile, tw_words, tw30, B, t, logP, jbase);
+      else round_stages<1, LOGC, false, THREADS, PAD>(tile, tw_words, tw30, B, t, logP, jbase);
+    }
+    __syncthreads();
+    t += ns;
+  }
+
+  // ---- store: values below (2 + 2 B) r come back below 2 r (more passes follow), to the canonical residue (last pass),
+  // or through the multiplication by n^-1 (last pass of an inverse transform; index negated)
+  const bool inv_last = flags & 1u;
+  const bool last = flags & 2u;
+  u32 ninv30[NL];
+  if (inv_last) {
+    Fr c;
+#pragma unroll
+    for (int k = 0; k < Fr::N; k++) c.v[k] = RP::TO30[k];
+    const Fr30 w = slice30(ff_mul(ninv, c));
+#pragma unroll
+    for (int l = 0; l < NL; l++) ninv30[l] = w.v[l];
+  }
+  const u64 P = 1ull << logP;
+  for (u32 idx = tid; idx < (R << LOGC); idx += THREADS) {
+    const u32 c = idx & (C - 1), r2 = idx >> LOGC;
+    Fr30 v = tile_load<PAD>(tile, tw_words, (r2 << LOGC) + c);
+    const u64 j = jbase + c;
+    const u64 k = j & (P - 1);
+    u64 o = ((j - k) << B) + k + ((u64)r2 << logP);        // logP = 0: (j << B) + r2
+    if (inv_last) {
+      o = (n - o) & (n - 1);
+      v = mul30(v, ninv30);
+      cond_sub<1>(v);
+    } else if (last) {
+      reduce_ladder<true>(v);
+    } else {
+      reduce_ladder<false>(v);
+    }
+    ff_store(y + o, pack32(v));
+  }
+}
+
+inline size_t pass_lds_bytes(u32 B, int logc, bool first, int pad, bool twlds) {
+  const u32 words = (1u << B) << logc;
+  const u32 tw_words = pad < 0 ? words : words + ((words >> 5) << pad);
+  return ((size_t)NL * tw_words + (first && twlds ? (size_t)NL << B : 0)) * 4;
+}
+
+}  // namespace ntt30
