@@ -37,11 +37,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_ISSUE_PEAK_TOPS = 39.3      # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one VALU lane-op per lane and clock
-# instructions of one bucket addition (XYZZ += affine, 8 M + 2 S on 13 x 30-bit limbs), counted in the ISA of the loop
-# body of msmfb::accum30_kernel (profiles/r01p_accum_loop_isa.txt, tools/loop_isa_stats.py); the variable-base kernel (32-bit limbs) has 7839
-ACCUM_VALU_PER_ADD = {"fixed-base": 5166, "variable-base": 7839}
-ACCUM_MAD_PER_ADD = {"fixed-base": 3224, "variable-base": 2880}
+# VALU issue rates measured on MI355X with tools/microbench (profiles/r02a_microbench_controls.txt), T lane-ops/s over the
+# whole chip: plain 32-bit ops (v_add_u32, v_and_b32, v_lshrrev_b32; v_fma_f32 is the same) issue at ~63, everything that
+# multiplies, carries or is 64 bits wide at about half of that -- v_mad_u64_u32 33.0, v_mul_lo_u32 / v_add3_u32 /
+# v_lshrrev_b64 / v_lshl_add_u64 / v_addc_co_u32 35-36.  (The guide's 2-cycle wave64 issue is the 63 T/s class.)
+VALU_CLASS_RATE_T = {"mad_u64": 33.0, "half_rate_other": 35.5, "full_rate": 63.1}
+# instruction mix of ONE bucket addition (XYZZ += affine table point: 8 M + 2 S, Y3 as two products under one reduction,
+# on 13 x 30-bit limbs) in the loop body of msmfb::accum30_kernel, counted in the ISA (tools/loop_isa_stats.py ->
+# profiles/r02b_accum_loop_isa.txt): 4214 VALU = 3055 v_mad_u64_u32 + 497 other half-rate (274 v_lshrrev_b64, 118
+# v_mul_lo_u32, 58 v_lshl_add_u64, 47 v_add3_u32) + 662 full-rate; the variable-base kernel (32-bit limbs): 7839 VALU
+# = 2880 mad + 2880 addc + 2079 others.
+ACCUM_MIX = {"fixed-base": {"mad_u64": 3055, "half_rate_other": 497, "full_rate": 662},
+             "variable-base": {"mad_u64": 2880, "half_rate_other": 2880 + 445 + 120, "full_rate": 1514}}
+
+
+def valu_bound_adds_per_s(path):
+    """bucket additions per second the chip could issue if nothing but this instruction mix ever stalled."""
+    return 1.0 / sum(cnt / (VALU_CLASS_RATE_T[k] * 1e12) for k, cnt in ACCUM_MIX[path].items())
 
 
 def rand_fr_np(rng, n):
@@ -337,19 +349,22 @@ def main():
     path = "fixed-base" if tab_w else "variable-base"
     W_windows = tab_w or 16
     madds_per_s = (msm_pairs_rank * W_windows * args.steps) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
-    valu_rate = madds_per_s * ACCUM_VALU_PER_ADD[path] / 1e12
+    bound_adds = valu_bound_adds_per_s(path)
+    mix = ACCUM_MIX[path]
     valu = {"bound": "valu-issue", "kernel": "msmfb::accum30_kernel" if tab_w else "msm::accum_kernel",
-            "achieved": round(valu_rate, 3), "peak": VALU_ISSUE_PEAK_TOPS, "unit": "T VALU lane-instr/s",
-            "frac": round(valu_rate / VALU_ISSUE_PEAK_TOPS, 4), "bucket_adds_per_s": round(madds_per_s / 1e9, 3),
-            "windows": W_windows, "window_bits": tab_c or 16, "valu_instr_per_add": ACCUM_VALU_PER_ADD[path],
-            "v_mad_u64_u32_per_add": ACCUM_MAD_PER_ADD[path],
-            "note": "achieved = bucket additions/s x VALU instructions of the loop body; every VALU instruction of this "
-                    "kernel issues at about one lane-op per lane and clock (profiles/r01_microbench.txt)"}
+            "achieved": round(madds_per_s / 1e9, 3), "peak": round(bound_adds / 1e9, 3), "unit": "G bucket additions/s",
+            "frac": round(madds_per_s / bound_adds, 4), "windows": W_windows, "window_bits": tab_c or 16,
+            "valu_instr_per_add": sum(mix.values()), "v_mad_u64_u32_per_add": mix["mad_u64"], "instr_mix_per_add": mix,
+            "class_rate_T_lane_ops_per_s": VALU_CLASS_RATE_T,
+            "note": "peak = 1 / sum(instructions of one bucket addition in a class / measured issue rate of the class): "
+                    "v_mad_u64_u32 and the other multiply / carry / 64-bit instructions issue at half the rate of plain "
+                    "32-bit VALU ops on gfx950 (profiles/r02a_microbench_controls.txt); mix counted in the ISA "
+                    "(profiles/r02b_accum_loop_isa.txt)"}
     roofline = {"bound": "hbm", "kernel": valu["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_launch_ms, 4),
                 "note": "algorithmic bytes = 128 B per (scalar, base) pair (SURVEY.md 8d); the MSM is VALU-issue bound "
-                        "(~5.2k VALU instr per bucket addition, %d additions per pair), see roofline_valu and DESIGN.md; "
+                        "(~4.2k VALU instr per bucket addition, %d additions per pair), see roofline_valu and DESIGN.md; "
                         "NTT family: %.1f GB/s over the %s" % (
                             W_windows, (ntt_bytes * args.steps) / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0, ntt_what)}
 

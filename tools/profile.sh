@@ -39,5 +39,18 @@ find $OUT/pmc_fetch -name "*counter_collection.csv" -exec cp {} $OUT/pmc_fetch.c
 find $OUT/pmc_write -name "*counter_collection.csv" -exec cp {} $OUT/pmc_write.csv \;
 cd $REPO
 python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
+python3 - "$OUT" "$TAG" <<'PY'
+import json, sys
+out, tag = sys.argv[1], sys.argv[2]
+d = json.load(open(out + "/pmc_summary.json"))
+po = d.get("prove_only:accum30_kernel")
+if po:
+    json.dump({"source": "profiles/%s_pmc_summary_marlin_prove_2p20.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, of "
+                         "`bench.py --steps 1 --warmup 0`; PROVE ONLY: the last 4 dispatches of msmfb::accum30_kernel = the 4 batched "
+                         "launches of the one timed prove; FETCH_SIZE x2 gfx950 correction)" % tag,
+               "msm_accum_bytes_per_launch": po["hbm_bytes_per_launch"],
+               "fetch_bytes_per_launch_x2corrected": po["fetch_bytes_per_launch_x2corrected"],
+               "write_bytes_per_launch": po["write_bytes_per_launch"]}, open(out + "/pmc_traffic.json", "w"), indent=1)
+PY
 find $OUT -name "*.csv" | head -20; rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT
