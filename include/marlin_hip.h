@@ -130,6 +130,21 @@ int mh_g1_to_affine(const uint64_t* xyz_mont, uint64_t* xy_mont_out, int* is_inf
  * the ranks all_gather their 144-byte partial results. */
 int mh_g1_sum(const uint64_t* xyz_points, size_t n, uint64_t* out_xyz);
 
+/* ---- G2 (the verifier side of the SRS): replaces ark_ec VariableBaseMSM over G2Affine and the G2 half of
+ * kzg10::setup (h, beta_h, SonicKZG10's neg_powers_of_h; reached from Marlin::universal_setup -> PC::setup,
+ * src/lib.rs:79-96).  Off the prover's hot path -- Marlin::prove multiplies G1 points only -- but named by
+ * BASELINE.json's north_star.  A G2 affine point is x.c0 || x.c1 || y.c0 || y.c1 (4 Fq, Montgomery, Fq2 = Fq[u]/(u^2+1)),
+ * no infinity flag: uploads are checked against the twist equation.  Results are AFFINE (the library normalises on the
+ * device) with an infinity flag. */
+int mh_g2_bases_upload(int curve, const uint64_t* xy_mont, size_t n, uint64_t* handle_out);
+/* bases[i] = [scale * tau^(first + i)] H for the caller's generator H (gen_xy, 4 Fq); scale_mont NULL = 1. */
+int mh_g2_srs_powers(int curve, const uint64_t* gen_xy_mont, const uint64_t* tau_mont, const uint64_t* scale_mont, size_t first,
+                     size_t n, uint64_t* handle_out);
+int mh_g2_bases_download(uint64_t handle, size_t offset, size_t n, uint64_t* xy_mont_out);
+int mh_g2_bases_free(uint64_t handle);
+int mh_g2_msm(uint64_t handle, size_t base_offset, const uint64_t* scalars, int scalars_are_montgomery, size_t n,
+              uint64_t* out_xy_mont, int* is_infinity_out);
+
 /* ---- Marlin index / prove with device-resident polynomials --------------------------------
  * Host-side mirror of Marlin::<Fr, MarlinKZG10<Bls12_381>, SimpleHashFiatShamirRng<Blake2s,
  * ChaChaRng>>::{index, prove} (src/lib.rs:100-148, 151-311).  The R1CS is given as the padded,

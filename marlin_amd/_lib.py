@@ -59,6 +59,11 @@ SYMBOLS = {
     "mh_marlin_set_shard": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mh_marlin_test_allgather": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mh_marlin_get_poly": (C.c_int, [C.c_uint64, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mh_g2_bases_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
+    "mh_g2_srs_powers": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, _u64p]),
+    "mh_g2_bases_download": (C.c_int, [C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "mh_g2_bases_free": (C.c_int, [C.c_uint64]),
+    "mh_g2_msm": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_int)]),
     "mh_prof_enable": (C.c_int, [C.c_int]),
     "mh_prof_reset": (C.c_int, []),
     "mh_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), _u64p]),

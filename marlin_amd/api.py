@@ -177,6 +177,57 @@ class Bases:
             pass
 
 
+class G2Bases:
+    """G2 points resident on the device (the verifier side of the SRS): mh_g2_bases_upload.  A point is
+    x.c0 || x.c1 || y.c0 || y.c1, Montgomery Fq limbs, (n, 4 * FQ_LIMBS) uint64."""
+
+    def __init__(self, xy_mont):
+        a = _as_u64(xy_mont, 4 * _fql())
+        h = C.c_uint64()
+        _lib.check(_L().mh_g2_bases_upload(_curve_id(), a.ctypes.data, a.shape[0], C.byref(h)), "mh_g2_bases_upload")
+        self.handle, self.n = h.value, a.shape[0]
+
+    @classmethod
+    def srs_powers(cls, gen_xy_mont, tau_mont, n, scale_mont=None, first=0):
+        """[scale * tau^(first+i)]H for i < n (KZG10::setup's powers_of_h / neg_powers_of_h for a known tau)."""
+        g = np.ascontiguousarray(gen_xy_mont, dtype=np.uint64).reshape(4 * _fql())
+        tau = np.ascontiguousarray(tau_mont, dtype=np.uint64).reshape(4)
+        sc = None if scale_mont is None else np.ascontiguousarray(scale_mont, dtype=np.uint64).reshape(4)
+        h = C.c_uint64()
+        _lib.check(_L().mh_g2_srs_powers(_curve_id(), g.ctypes.data, tau.ctypes.data, None if sc is None else sc.ctypes.data,
+                                         int(first), int(n), C.byref(h)), "mh_g2_srs_powers")
+        self = cls.__new__(cls)
+        self.handle, self.n = h.value, int(n)
+        return self
+
+    def download(self, offset=0, n=None):
+        n = self.n - offset if n is None else n
+        out = np.zeros((n, 4 * _fql()), dtype=np.uint64)
+        _lib.check(_L().mh_g2_bases_download(self.handle, int(offset), int(n), out.ctypes.data), "mh_g2_bases_download")
+        return out
+
+    def free(self):
+        if self.handle:
+            _lib.check(_L().mh_g2_bases_free(self.handle), "mh_g2_bases_free")
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def g2_msm(bases, scalars, base_offset=0, montgomery=True):
+    """VariableBaseMSM::multi_scalar_mul over G2: (affine x.c0||x.c1||y.c0||y.c1 as (4*FQ_LIMBS,) uint64, is_infinity)."""
+    s = _as_u64(scalars, 4)
+    out = np.zeros(4 * _fql(), dtype=np.uint64)
+    inf = C.c_int(0)
+    _lib.check(_L().mh_g2_msm(bases.handle, int(base_offset), s.ctypes.data, 1 if montgomery else 0, s.shape[0],
+                              out.ctypes.data, C.byref(inf)), "mh_g2_msm")
+    return out, bool(inf.value)
+
+
 def msm(bases, scalars, base_offset=0, montgomery=True):
     """VariableBaseMSM::multi_scalar_mul: returns Jacobian X||Y||Z as (18,) uint64 (Montgomery)."""
     s = _as_u64(scalars, 4)

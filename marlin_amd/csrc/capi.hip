@@ -6,6 +6,7 @@
 #include "msm.cuh"
 #include "msm_tree.cuh"
 #include "msm_fb.cuh"
+#include "msm_g2.cuh"
 #include <cstdlib>
 #include "ntt.cuh"
 #include "ntt30.cuh"
@@ -692,6 +693,69 @@ int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mo
 }
 
 // --------------------------------------------------------------------------------
+// G2: multi-scalar multiplication and fixed-base powers (msm_g2.cuh)
+// --------------------------------------------------------------------------------
+constexpr size_t G2PT_B = 4 * FQ_B;                 // affine x.c0 | x.c1 | y.c0 | y.c1
+// out_words: 4 * Fq::N Montgomery words of the affine result followed by the infinity flag
+static int msm_g2_device(Context& c, const G2Affine* d_bases, const Fr* d_scalars, int is_mont, size_t n, u32* out_words) {
+  const size_t OW = 4 * Fq::N + 1;
+  if (n == 0) { memset(out_words, 0, OW * 4); out_words[OW - 1] = 1; return MH_OK; }
+  if (n >= (1ull << 28)) return fail(MH_EINVAL, "mh_g2_msm: n must be < 2^28");
+  MH_TRY(msm_set_attrs());
+  hipStream_t s = c.stream;
+  msm::Plan p = msm::make_plan(n);
+  msm::Jobs jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  jobs.njobs = 1; jobs.bases[0] = nullptr; jobs.scalars[0] = d_scalars; jobs.n[0] = n;
+  jobs.ent_off[0] = 0; jobs.ntiles[0] = p.ntiles; jobs.bh_off[0] = 0;
+  const u64 WN = (u64)p.W * n;
+  const u32 WT = p.W;
+  const size_t WB = (size_t)WT * p.nb;
+  MH_TRY(c.msm_dig.ensure(WN * 4)); MH_TRY(c.msm_sorted.ensure(WN * 4)); MH_TRY(c.msm_bh.ensure((u64)p.W * p.ntiles * p.nb * 4));
+  MH_TRY(c.msm_tot.ensure(WB * 4)); MH_TRY(c.msm_base.ensure(WB * 4));
+  MH_TRY(c.msm_buckets.ensure(WB * sizeof(G2Xyzz)));
+  MH_TRY(c.msm_seg.ensure((size_t)WT * p.nseg * sizeof(G2Xyzz)));
+  MH_TRY(c.msm_win.ensure((size_t)WT * sizeof(G2Xyzz) + OW * 4));
+  MH_TRY(c.tr_sums.ensure(64));
+  ProfScope ps(c, PF_MSM);
+  hipLaunchKernelGGL(msm::digits_kernel, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, s, jobs, (u32*)c.msm_dig.ptr, p.W, p.win, is_mont);
+  const size_t lds = (size_t)p.nb * 4;
+  hipLaunchKernelGGL(msm::hist_kernel, dim3(msm::xcd_grid(p.ntiles, WT)), dim3(msm::HIST_THREADS), lds, s, jobs, (const u32*)c.msm_dig.ptr,
+                     (u32*)c.msm_bh.ptr, p.nb, p.tile, p.ntiles, p.W);
+  hipLaunchKernelGGL(msm::colscan_kernel, dim3((p.nb + 255) / 256, p.W, 1), dim3(256), 0, s, jobs, (u32*)c.msm_bh.ptr, (u32*)c.msm_tot.ptr, p.nb, p.W);
+  u32* d_max = (u32*)c.tr_sums.ptr;
+  MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
+  hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, p.nb, d_max);
+  hipLaunchKernelGGL(msm::scatter_kernel, dim3(msm::xcd_grid(p.ntiles, WT)), dim3(msm::HIST_THREADS), lds, s, jobs, (const u32*)c.msm_dig.ptr,
+                     (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr, p.nb, p.tile, p.W, p.ntiles);
+  hipLaunchKernelGGL(msmg2::accum_kernel, dim3((unsigned)((WB + 127) / 128)), dim3(128), 0, s, d_bases, (const u32*)c.msm_sorted.ptr, (u64)n,
+                     (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (G2Xyzz*)c.msm_buckets.ptr, p.nb, (u64)WB);
+  hipLaunchKernelGGL(msmg2::reduce1_kernel, dim3((WT * p.nseg + 63) / 64), dim3(64), 0, s, (const G2Xyzz*)c.msm_buckets.ptr, (G2Xyzz*)c.msm_seg.ptr,
+                     p.nb, p.nseg, WT, (u32)msm::SEG);
+  hipLaunchKernelGGL(msmg2::reduce2_kernel, dim3(WT), dim3(64), 0, s, (const G2Xyzz*)c.msm_seg.ptr, (G2Xyzz*)c.msm_win.ptr, p.nseg);
+  u32* d_out = (u32*)((char*)c.msm_win.ptr + (size_t)WT * sizeof(G2Xyzz));
+  hipLaunchKernelGGL(msmg2::combine_kernel, dim3(1), dim3(1), 0, s, (const G2Xyzz*)c.msm_win.ptr, p.W, p.win, d_out);
+  MH_HIP(hipGetLastError());
+  MH_HIP(hipMemcpyAsync(out_words, d_out, OW * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(hipStreamSynchronize(s));
+  return MH_OK;
+}
+
+static int g2_validate(Context& c, const void* d_points, size_t n) {
+  if (n == 0) return MH_OK;
+  MH_TRY(c.tr_sums.ensure(64));
+  u32* d_bad = (u32*)c.tr_sums.ptr;
+  MH_HIP(hipMemsetAsync(d_bad, 0, 4, c.stream));
+  hipLaunchKernelGGL(msmg2::check_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c.stream, (const G2Affine*)d_points, (u64)n, d_bad);
+  MH_HIP(hipGetLastError());
+  u32 bad = 0;
+  MH_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  if (bad) return fail(MH_EINVAL, "G2 bases: " + std::to_string(bad) + " point(s) are not on the twist (the identity cannot be a base)");
+  return MH_OK;
+}
+
+// --------------------------------------------------------------------------------
 // SRS generation (KZG10::setup's powers, known-tau test SRS)
 // --------------------------------------------------------------------------------
 static void* g_srs_table = nullptr;   // G1Affine[32][256]
@@ -804,6 +868,8 @@ int mh_shutdown(void) {
   c.tr_sums.release(); c.tr_ob.release(); c.tr_pre.release(); c.tr_prod.release(); c.tr_scr.release();
   for (auto& kv : c.bases) { if (kv.second.d_points) (void)hipFree(kv.second.d_points); if (kv.second.d_table) (void)hipFree(kv.second.d_table); }
   c.bases.clear();
+  for (auto& kv : c.g2_bases) if (kv.second.d_points) (void)hipFree(kv.second.d_points);
+  c.g2_bases.clear();
   c.fb_val.release(); c.fb_pc.release(); c.fb_ptot.release(); c.fb_desc.release(); c.fb_blk.release(); c.fb_perm.release();
   if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }
   for (auto& r : c.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1108,6 +1174,97 @@ int mh_g1_sum(const uint64_t* xyz_points, size_t n, uint64_t* out_xyz) {
     acc = acc.add(p);
   }
   memcpy(out_xyz, acc.X.v, FQ_B); memcpy(out_xyz + FQ_L, acc.Y.v, FQ_B); memcpy(out_xyz + 2 * FQ_L, acc.Z.v, FQ_B);
+  return MH_OK;
+}
+
+// ---- G2 ------------------------------------------------------------------------------------------------------
+int mh_g2_bases_upload(int curve, const uint64_t* xy, size_t n, uint64_t* handle_out) {
+  LOCKED_CTX();
+  if (curve != hostff::CURVE_ID) return fail(MH_EINVAL, "unsupported curve");
+  if (!handle_out || (!xy && n)) return fail(MH_EINVAL, "mh_g2_bases_upload: null pointer");
+  G2Set b;
+  b.n = n;
+  if (n) {
+    MH_HIP(hipMalloc(&b.d_points, n * G2PT_B));
+    MH_HIP(hipMemcpyAsync(b.d_points, xy, n * G2PT_B, hipMemcpyHostToDevice, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));
+    int rc = g2_validate(c, b.d_points, n);
+    if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
+  }
+  uint64_t h = c.next_handle++;
+  c.g2_bases[h] = b;
+  *handle_out = h;
+  return MH_OK;
+}
+int mh_g2_srs_powers(int curve, const uint64_t* gen_xy, const uint64_t* tau_mont, const uint64_t* scale_mont, size_t first, size_t n,
+                     uint64_t* handle_out) {
+  LOCKED_CTX();
+  if (curve != hostff::CURVE_ID) return fail(MH_EINVAL, "unsupported curve");
+  if (!handle_out || !gen_xy || !tau_mont) return fail(MH_EINVAL, "mh_g2_srs_powers: null pointer");
+  G2Affine H;
+  memcpy(&H, gen_xy, G2PT_B);
+  {
+    void* d_h = nullptr;
+    MH_HIP(hipMalloc(&d_h, G2PT_B));
+    MH_HIP(hipMemcpyAsync(d_h, gen_xy, G2PT_B, hipMemcpyHostToDevice, c.stream));
+    int rc = g2_validate(c, d_h, 1);
+    (void)hipFree(d_h);
+    if (rc != MH_OK) return rc;
+  }
+  Fr tau, scale;
+  memcpy(tau.v, tau_mont, 32);
+  if (scale_mont) memcpy(scale.v, scale_mont, 32); else { HFr one = HFr::one(); memcpy(scale.v, one.v, 32); }
+  G2Set b;
+  b.n = n;
+  if (n) {
+    MH_HIP(hipMalloc(&b.d_points, n * G2PT_B));
+    MH_TRY(c.tr_sums.ensure(64));
+    u32* d_zero = (u32*)c.tr_sums.ptr;
+    MH_HIP(hipMemsetAsync(d_zero, 0, 4, c.stream));
+    hipLaunchKernelGGL(msmg2::powers_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c.stream, (G2Affine*)b.d_points, H, tau, scale,
+                       (u64)first, (u64)n, d_zero);
+    hipError_t le = hipGetLastError();
+    u32 nz = 0;
+    hipError_t ce = hipMemcpyAsync(&nz, d_zero, 4, hipMemcpyDeviceToHost, c.stream);
+    hipError_t se = hipStreamSynchronize(c.stream);
+    if (le != hipSuccess || ce != hipSuccess || se != hipSuccess) { (void)hipFree(b.d_points); return fail(MH_EHIP, "mh_g2_srs_powers: kernel failed"); }
+    if (nz) { (void)hipFree(b.d_points); return fail(MH_EINVAL, "mh_g2_srs_powers: a power is the identity (tau or scale is zero)"); }
+  }
+  uint64_t h = c.next_handle++;
+  c.g2_bases[h] = b;
+  *handle_out = h;
+  return MH_OK;
+}
+int mh_g2_bases_download(uint64_t handle, size_t offset, size_t n, uint64_t* xy_out) {
+  LOCKED_CTX();
+  auto it = c.g2_bases.find(handle);
+  if (it == c.g2_bases.end()) return fail(MH_EINVAL, "unknown G2 bases handle");
+  if (offset + n > it->second.n) return fail(MH_EINVAL, "mh_g2_bases_download: range exceeds the base set");
+  if (n == 0) return MH_OK;
+  MH_HIP(hipMemcpyAsync(xy_out, (const char*)it->second.d_points + offset * G2PT_B, n * G2PT_B, hipMemcpyDeviceToHost, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
+}
+int mh_g2_bases_free(uint64_t handle) {
+  LOCKED_CTX();
+  auto it = c.g2_bases.find(handle);
+  if (it == c.g2_bases.end()) return fail(MH_EINVAL, "unknown G2 bases handle");
+  if (it->second.d_points) (void)hipFree(it->second.d_points);
+  c.g2_bases.erase(it);
+  return MH_OK;
+}
+int mh_g2_msm(uint64_t handle, size_t base_offset, const uint64_t* scalars, int is_mont, size_t n, uint64_t* out_xy_mont, int* is_infinity_out) {
+  LOCKED_CTX();
+  auto it = c.g2_bases.find(handle);
+  if (it == c.g2_bases.end()) return fail(MH_EINVAL, "unknown G2 bases handle");
+  if (base_offset + n > it->second.n) return fail(MH_EINVAL, "mh_g2_msm: range exceeds the base set");
+  if (!out_xy_mont || (!scalars && n)) return fail(MH_EINVAL, "mh_g2_msm: null pointer");
+  MH_TRY(c.io.ensure(n * 32 + 32));
+  if (n) MH_HIP(hipMemcpyAsync(c.io.ptr, scalars, n * 32, hipMemcpyHostToDevice, c.stream));
+  u32 words[4 * Fq::N + 1];
+  MH_TRY(msm_g2_device(c, (const G2Affine*)((const char*)it->second.d_points + base_offset * G2PT_B), (const Fr*)c.io.ptr, is_mont, n, words));
+  memcpy(out_xy_mont, words, G2PT_B);
+  if (is_infinity_out) *is_infinity_out = (int)words[4 * Fq::N];
   return MH_OK;
 }
 

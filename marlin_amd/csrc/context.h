@@ -63,6 +63,8 @@ struct BaseSet {
   bool tab_auto = false;     // width chosen by the library (re-chosen when the shard count changes)
 };
 
+struct G2Set { void* d_points = nullptr; size_t n = 0; };   // G2Affine[n] (x.c0 | x.c1 | y.c0 | y.c1, Montgomery)
+
 enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_COUNT = 4 };
 
 struct ProfRec { int family; hipEvent_t a, b; };
@@ -83,6 +85,7 @@ struct Context {
 
   // MSM
   std::map<uint64_t, BaseSet> bases;
+  std::map<uint64_t, G2Set> g2_bases;
   uint64_t next_handle = 1;
   Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win, msm_pend;
   Scratch fb_val, fb_pc, fb_ptot, fb_desc, fb_blk, fb_perm;   // fixed-base path (msm_fb.cuh)

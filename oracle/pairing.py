@@ -122,67 +122,9 @@ def f12_from_fq2(c0, c1):
     return f12([(c0 - c1) % P, 0, 0, 0, 0, 0, c1 % P])
 
 
-# ---- Fq2 (for G2 arithmetic on the twist) ---------------------------------------------------------------------------
-def f2_add(a, b): return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
-def f2_sub(a, b): return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
-def f2_neg(a): return ((-a[0]) % P, (-a[1]) % P)
-def f2_mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
-def f2_scale(a, k): return (a[0] * k % P, a[1] * k % P)
-
-
-def f2_inv(a):
-    n = pow(a[0] * a[0] + a[1] * a[1], -1, P)
-    return (a[0] * n % P, (-a[1]) * n % P)
-
-
-F2_ZERO, F2_ONE = (0, 0), (1, 0)
-G2_B = (4, 4)                                   # 4 (1 + u)
-
-# the standard generator of G2 (zkcrypto / IETF pairing-friendly-curves draft); validated by tests: on the twist, order r
-G2_GEN = (
-    (0x024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8,
-     0x13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e),
-    (0x0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801,
-     0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be),
-)
-
-
-def g2_is_on_curve(pt):
-    if pt is None:
-        return True
-    x, y = pt
-    return f2_mul(y, y) == f2_add(f2_mul(f2_mul(x, x), x), G2_B)
-
-
-def g2_add(p1, p2):
-    if p1 is None:
-        return p2
-    if p2 is None:
-        return p1
-    (x1, y1), (x2, y2) = p1, p2
-    if x1 == x2:
-        if y1 != y2 or y1 == F2_ZERO:
-            return None
-        m = f2_mul(f2_scale(f2_mul(x1, x1), 3), f2_inv(f2_scale(y1, 2)))
-    else:
-        m = f2_mul(f2_sub(y2, y1), f2_inv(f2_sub(x2, x1)))
-    x3 = f2_sub(f2_sub(f2_mul(m, m), x1), x2)
-    return (x3, f2_sub(f2_mul(m, f2_sub(x1, x3)), y1))
-
-
-def g2_neg(p):
-    return None if p is None else (p[0], f2_neg(p[1]))
-
-
-def g2_mul(p, k):
-    k %= R
-    out = None
-    while k:
-        if k & 1:
-            out = g2_add(out, p)
-        p = g2_add(p, p)
-        k >>= 1
-    return out
+# ---- Fq2 and G2 arithmetic on the twist: oracle/g2.py ---------------------------------------------------------------
+from .g2 import (f2_add, f2_sub, f2_neg, f2_mul, f2_scale, f2_inv, F2_ZERO, F2_ONE, G2_B, G2_GEN,    # noqa: E402,F401
+                 g2_is_on_curve, g2_add, g2_neg, g2_mul)
 
 
 # ---- the pairing ----------------------------------------------------------------------------------------------------

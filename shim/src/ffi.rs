@@ -76,6 +76,15 @@ extern "C" {
     pub fn mh_g1_to_affine(xyz_mont: *const u64, xy_mont_out: *mut u64, is_infinity_out: *mut c_int) -> c_int;
     pub fn mh_g1_sum(xyz_points: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
 
+    // ---- G2 (verifier side of the SRS)
+    pub fn mh_g2_bases_upload(curve: c_int, xy_mont: *const u64, n: usize, handle_out: *mut u64) -> c_int;
+    pub fn mh_g2_srs_powers(curve: c_int, gen_xy_mont: *const u64, tau_mont: *const u64, scale_mont: *const u64, first: usize, n: usize,
+                            handle_out: *mut u64) -> c_int;
+    pub fn mh_g2_bases_download(handle: u64, offset: usize, n: usize, xy_mont_out: *mut u64) -> c_int;
+    pub fn mh_g2_bases_free(handle: u64) -> c_int;
+    pub fn mh_g2_msm(handle: u64, base_offset: usize, scalars: *const u64, scalars_are_montgomery: c_int, n: usize,
+                     out_xy_mont: *mut u64, is_infinity_out: *mut c_int) -> c_int;
+
     // ---- Marlin index / prove with device-resident polynomials
     pub fn mh_marlin_index(m: *const mh_r1cs_matrices, srs_g: u64, srs_gamma_g: u64, pk_out: *mut u64) -> c_int;
     pub fn mh_marlin_index_pc(m: *const mh_r1cs_matrices, srs_g: u64, srs_gamma_g: u64, pc: c_int, pk_out: *mut u64) -> c_int;

@@ -16,7 +16,8 @@ fn every_header_symbol_links() {
         mh_marlin_vk_bytes as usize, mh_marlin_prove as usize, mh_marlin_proof_serialize as usize,
         mh_marlin_proof_deserialize as usize, mh_marlin_set_shard as usize, mh_marlin_test_allgather as usize,
         mh_marlin_get_poly as usize, mh_prof_enable as usize, mh_prof_reset as usize, mh_prof_get as usize,
-        mh_selftest_fq30 as usize,
+        mh_selftest_fq30 as usize, mh_g2_bases_upload as usize, mh_g2_srs_powers as usize, mh_g2_bases_download as usize,
+        mh_g2_bases_free as usize, mh_g2_msm as usize,
     ];
     assert!(addrs.iter().all(|a| *a != 0));
 }

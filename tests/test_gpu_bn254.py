@@ -20,7 +20,7 @@ def _run(files, extra=()):
 
 
 def test_bn254_ntt_msm_srs_parity():
-    out = _run(["tests/test_gpu_ntt.py", "tests/test_gpu_msm.py", "tests/test_gpu_srs.py"])
+    out = _run(["tests/test_gpu_ntt.py", "tests/test_gpu_msm.py", "tests/test_gpu_srs.py", "tests/test_gpu_g2.py"])
     assert " passed" in out
 
 
