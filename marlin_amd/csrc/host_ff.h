@@ -227,4 +227,23 @@ struct HG1 {
   }
 };
 
+// Affine normalisation of several points with ONE field inversion (Montgomery's trick): a commit round yields 3-5
+// commitments and the host's Fermat inversion is ~50 us, during which the GPU waits for the next Fiat-Shamir challenge.
+inline void batch_to_affine(const HG1* pts, size_t n, HG1Affine* out) {
+  HFq prefix[16];
+  HFq acc = HFq::one();
+  if (n > 16) { for (size_t i = 0; i < n; i++) out[i] = pts[i].to_affine(); return; }
+  for (size_t i = 0; i < n; i++) {
+    prefix[i] = acc;
+    if (!pts[i].is_identity()) acc = acc * pts[i].Z;
+  }
+  HFq inv = acc.inv();
+  for (size_t i = n; i-- > 0;) {
+    if (pts[i].is_identity()) { out[i].x = HFq::zero(); out[i].y = HFq::zero(); out[i].inf = true; continue; }
+    const HFq zi = inv * prefix[i], zi2 = zi.sqr();
+    inv = inv * pts[i].Z;
+    out[i].x = pts[i].X * zi2; out[i].y = pts[i].Y * zi2 * zi; out[i].inf = false;
+  }
+}
+
 }  // namespace hostff

@@ -415,12 +415,14 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
     std::vector<HG1> res;
     int rc_batch = sharded_msm_batch(c, jobs, res);
     if (rc_batch != MH_OK) { for (auto& f : hid) if (f.valid()) f.wait(); return rc_batch; }
+    std::vector<HG1> fin(reqs.size());
     for (size_t i = 0; i < reqs.size(); i++) {
-      HG1 cm = res[i];
-      if (reqs[i].hiding) cm = cm.add(hid[i].get());
-      comms[i].comm = cm.to_affine();
-      comms[i].has_shifted = false;
+      fin[i] = res[i];
+      if (reqs[i].hiding) fin[i] = fin[i].add(hid[i].get());
     }
+    std::vector<HG1Affine> aff(fin.size());
+    hostff::batch_to_affine(fin.data(), fin.size(), aff.data());        // one inversion for the round's commitments
+    for (size_t i = 0; i < reqs.size(); i++) { comms[i].comm = aff[i]; comms[i].has_shifted = false; }
     return MH_OK;
   }
   for (size_t i = 0; i < reqs.size(); i++) {
@@ -447,16 +449,24 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
   std::vector<HG1> res;
   int rc_batch = sharded_msm_batch(c, jobs, res);
   if (rc_batch != MH_OK) { for (auto& f : hid) if (f.valid()) f.wait(); for (auto& f : hid_sh) if (f.valid()) f.wait(); return rc_batch; }
+  std::vector<HG1> fin;
   size_t j = 0;
   for (size_t i = 0; i < reqs.size(); i++) {
     HG1 cm = res[j++];
     if (reqs[i].hiding) cm = cm.add(hid[i].get());
-    comms[i].comm = cm.to_affine();
+    fin.push_back(cm);
     if (reqs[i].has_bound) {
       HG1 sh = res[j++];
       if (reqs[i].hiding) sh = sh.add(hid_sh[i].get());
-      comms[i].shifted = sh.to_affine();
+      fin.push_back(sh);
     }
+  }
+  std::vector<HG1Affine> aff(fin.size());
+  hostff::batch_to_affine(fin.data(), fin.size(), aff.data());          // one inversion for the round's commitments
+  j = 0;
+  for (size_t i = 0; i < reqs.size(); i++) {
+    comms[i].comm = aff[j++];
+    if (reqs[i].has_bound) comms[i].shifted = aff[j++];
   }
   return MH_OK;
 }
@@ -1066,8 +1076,8 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
       wacc = wacc.add(small_msm(pk.gamma_g, host_div_linear(r, beta)));
       rv_beta = host_eval(r, beta); has_rv_beta = true;
     }
-    w_beta = wacc.to_affine();
-    w_gamma = om[1].to_affine();          // nothing hiding at gamma: random_v = None
+    { const HG1 two[2] = {wacc, om[1]}; HG1Affine a2[2]; hostff::batch_to_affine(two, 2, a2); w_beta = a2[0]; w_gamma = a2[1]; }
+    // nothing hiding at gamma: random_v = None
   } else {
   // The MSMs of the two opening proofs (witness + shifted witness at beta and at gamma, merged below) run as one batch.
   // --- at beta: labels g_1, outer_sumcheck, t, z_b  -> challenges xi^0 (g_1), xi^1 (g_1 shifted), xi^2, xi^3, xi^4
@@ -1136,6 +1146,7 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
     if (!merge_b) om[0] = om[0].add(res[nx++]);
     if (!merge_g) om[1] = om[1].add(res[nx++]);
   }
+  HG1 w_beta_jac;
   {
     HG1 wacc = om[0];
     if (r_nonzero) {
@@ -1152,9 +1163,9 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
       // evaluation is added to a Some and never turns a None into a Some [ark-poly-commit 0.3, SURVEY B-4]
       if (has_rv_beta) rv_beta = rv_beta + host_eval(sr, beta);
     }
-    w_beta = wacc.add(sw).to_affine();
+    w_beta_jac = wacc.add(sw);
   }
-  w_gamma = om[1].to_affine();
+  { const HG1 two[2] = {w_beta_jac, om[1]}; HG1Affine a2[2]; hostff::batch_to_affine(two, 2, a2); w_beta = a2[0]; w_gamma = a2[1]; }
   // at gamma nothing is hiding: kzg10::open on the unshifted powers returns random_v = None, and the Some(0) of the
   // shifted proof (open_with_witness_polynomial with Some(empty witness)) is dropped by `random_v.map(..)`
   // [ark-poly-commit 0.3 marlin_pc::open, SURVEY B-4]
