@@ -827,8 +827,20 @@ int mh_marlin_get_poly(uint64_t pk_handle, const char* label, uint64_t* out, siz
 // Marlin::prove (lib.rs:151-311).  instance: formatted public input (X elements, leading one included);
 // witness: nc - X elements (padding witnesses included).  zk_rng = ChaCha(zk_seed, rounds) drawn in the
 // order of SURVEY.md Appendix C.  proof_out: the flat ToBytes-layout proof.
+static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, bool inputs_on_device,
+                             const uint8_t* zk_seed, int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out);
 int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, const uint8_t* zk_seed,
                     int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out) {
+  return marlin_prove_impl(pk_handle, instance, witness, false, zk_seed, zk_rounds, proof_out, cap, len_out);
+}
+// the same with the assignment already in device memory (a witness generator that runs on the GPU, or a caller that
+// uploaded it ahead of time): no PCIe transfer inside the call
+int mh_marlin_prove_dev(uint64_t pk_handle, const void* d_instance, const void* d_witness, const uint8_t* zk_seed,
+                        int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out) {
+  return marlin_prove_impl(pk_handle, (const uint64_t*)d_instance, (const uint64_t*)d_witness, true, zk_seed, zk_rounds, proof_out, cap, len_out);
+}
+static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, bool inputs_on_device,
+                             const uint8_t* zk_seed, int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out) {
   LOCKED_CTX();
   auto pit = g_pks.find(pk_handle);
   if (pit == g_pks.end()) return fail(MH_EINVAL, "mh_marlin_prove: unknown prover key");
@@ -844,8 +856,8 @@ int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t
   const Fr* tw = (const Fr*)c.tw;
 
   // ---------------- prover_init (prover.rs:211-306): z = x || w, z_A = A z, z_B = B z --------------------
-  MH_TRY(h2d(c, pk.z.fr(), instance, X * 32));
-  MH_TRY(h2d(c, pk.z.fr() + X, witness, nw * 32));
+  if (inputs_on_device) { MH_TRY(d2d(c, pk.z.fr(), (const Fr*)instance, X)); MH_TRY(d2d(c, pk.z.fr() + X, (const Fr*)witness, nw)); }
+  else { MH_TRY(h2d(c, pk.z.fr(), instance, X * 32)); MH_TRY(h2d(c, pk.z.fr() + X, witness, nw * 32)); }
   {
     ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::spmv_kernel, nc, pk.za_ev.fr(), (const u64*)pk.A.row_ptr.p, (const u32*)pk.A.col.p,

@@ -136,6 +136,18 @@ def prove(pk, instance_mont, witness_mont, zk_seed, zk_rounds=20):
     return bytes(out[:n.value])
 
 
+def prove_dev(pk, d_instance, d_witness, zk_seed, zk_rounds=20):
+    """Marlin::prove with the formatted input and the witness already on the device (DeviceBuffer or device pointers):
+    mh_marlin_prove_dev.  Returns the flat ToBytes-layout proof."""
+    pi = d_instance.ptr if hasattr(d_instance, "ptr") else int(d_instance)
+    pw = d_witness.ptr if hasattr(d_witness, "ptr") else int(d_witness)
+    out = (C.c_uint8 * 4096)()
+    n = C.c_size_t()
+    _lib.check(_lib.load().mh_marlin_prove_dev(pk.handle, pi, pw, bytes(zk_seed), int(zk_rounds), out, 4096, C.byref(n)),
+               "mh_marlin_prove_dev")
+    return bytes(out[:n.value])
+
+
 def proof_serialize(flat_proof, pc="marlin"):
     """flat ToBytes proof (prove) -> ark-serialize `CanonicalSerialize for Proof` bytes (src/data_structures.rs:100-110)."""
     out = (C.c_uint8 * 4096)()

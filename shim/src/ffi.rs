@@ -93,6 +93,8 @@ extern "C" {
     pub fn mh_marlin_vk_bytes(pk: u64, out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_prove(pk: u64, instance_mont: *const u64, witness_mont: *const u64, zk_seed32: *const u8,
                            zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
+    pub fn mh_marlin_prove_dev(pk: u64, d_instance_mont: *const c_void, d_witness_mont: *const c_void, zk_seed32: *const u8,
+                               zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_proof_serialize(flat_proof: *const u8, flat_len: usize, pc: c_int, out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_proof_deserialize(bytes: *const u8, len: usize, pc: c_int, flat_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_set_shard(rank: c_int, world: c_int, allgather: mh_allgather_fn, user: *mut c_void) -> c_int;

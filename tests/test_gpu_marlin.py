@@ -244,6 +244,19 @@ def test_all_zero_matrix_a_poly_zip_quirk(gpu):
     assert proof == MR.proof_bytes(pr)
 
 
+def test_prove_dev_equals_prove(gpu):
+    """mh_marlin_prove_dev (assignment already in device memory -- what bench.py times) makes the same proof bytes as
+    mh_marlin_prove (host pointers)."""
+    n = 1 << 10
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA)
+    nc, ni, mats, inst, wit = GM.dummy_circuit(0x1234567, 0x7654321, 10, n)
+    pk = GM.index(srs, nc, ni, mats)
+    want = GM.prove(pk, inst, wit, SEED)
+    d_inst, d_wit = gpu.DeviceBuffer.from_numpy(inst), gpu.DeviceBuffer.from_numpy(wit)
+    assert GM.prove_dev(pk, d_inst, d_wit, SEED) == want
+    assert GM.prove_dev(pk, d_inst, d_wit, SEED) == want          # the inputs are not modified
+
+
 def test_index_and_prove_error_paths(gpu):
     import numpy as np
     srs = GM.universal_setup(64, 64, 192, TAU, GAMMA)
