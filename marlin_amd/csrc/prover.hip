@@ -125,21 +125,47 @@ int get_fr(Context& c, HFr* out, const Fr* src) {
 }
 
 // ark_ff::batch_inversion (+ optional scaling) of n elements in place; scratch: n + n / 16 + 64 elements
-int batch_inverse(Context& c, Fr* data, Fr* scratch, uint64_t n, const HFr& scale, int do_scale) {
-  ProfScope ps(c, PF_GLUE);
+// ark_ff::batch_inversion (prover.rs:663, mod.rs:314) of n device elements, zeros left untouched, every inverse optionally
+// multiplied by `scale`.  Montgomery's trick in levels: a level's threads multiply up 32 elements each (binv_fwd), the
+// per-thread products are inverted by the next level, and a backward sweep applies them (binv_bwd).  The ONE inversion
+// everything waits for is done on the host: a Fermat ladder on the device is ~380 dependent multiplications (0.3 ms
+// for a few thousand threads, whatever their number), the host does it in ~30 us behind a 2 KB copy.
+static int batch_inverse_level(Context& c, Fr* data, Fr* scratch, uint64_t n, const HFr& scale, int do_scale) {
   const uint64_t tile = (uint64_t)poly::TPB * poly::INV_CH;
-  if (n < 4 * tile) {
-    KLAUNCH(poly::batch_inverse_kernel, (n + poly::INV_CH - 1) / poly::INV_CH, data, scratch, (u64)n, arg(scale), do_scale);
+  if (n <= 512) {
+    // bottom: host
+    std::vector<uint64_t> h(4 * n);
+    MH_HIP(hipMemcpyAsync(h.data(), data, n * 32, hipMemcpyDeviceToHost, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));
+    std::vector<HFr> v(n), pre(n);
+    HFr acc = HFr::one();
+    for (uint64_t i = 0; i < n; i++) { memcpy(v[i].v, &h[4 * i], 32); pre[i] = acc; if (!v[i].is_zero()) acc = acc * v[i]; }
+    HFr inv = acc.inv();
+    if (do_scale) inv = inv * scale;             // the scale rides on the running inverse: r_i = scale / v_i
+    for (uint64_t i = n; i-- > 0;) {
+      if (v[i].is_zero()) continue;
+      HFr r = inv * pre[i];
+      inv = inv * v[i];
+      memcpy(&h[4 * i], r.v, 32);
+    }
+    MH_HIP(hipMemcpyAsync(data, h.data(), n * 32, hipMemcpyHostToDevice, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));       // h goes out of scope
     return MH_OK;
   }
   const uint64_t nblk = (n + tile - 1) / tile, nt = nblk * poly::TPB;
   Fr* totals = scratch + n;
   Fr* scratch2 = totals + nt;
   hipLaunchKernelGGL(poly::binv_fwd_kernel, dim3((unsigned)nblk), dim3(poly::TPB), 0, c.stream, (const Fr*)data, scratch, totals, (u64)n);
-  KLAUNCH(poly::batch_inverse_kernel, (nt + poly::INV_CH - 1) / poly::INV_CH, totals, scratch2, (u64)nt, arg(HFr::one()), 0);
+  MH_TRY(batch_inverse_level(c, totals, scratch2, nt, HFr::one(), 0));
   hipLaunchKernelGGL(poly::binv_bwd_kernel, dim3((unsigned)nblk), dim3(poly::TPB), 0, c.stream, data, (const Fr*)scratch, (const Fr*)totals,
                      (u64)n, arg(scale), do_scale);
+  MH_HIP(hipGetLastError());
   return MH_OK;
+}
+int batch_inverse(Context& c, Fr* data, Fr* scratch, uint64_t n, const HFr& scale, int do_scale) {
+  ProfScope ps(c, PF_GLUE);
+  if (n == 0) return MH_OK;
+  return batch_inverse_level(c, data, scratch, n, scale, do_scale);
 }
 
 struct Term { const Fr* p; uint64_t len; HFr coef; };
