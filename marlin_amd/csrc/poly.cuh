@@ -415,7 +415,7 @@ __global__ __launch_bounds__(TPB) void sum_kernel(Fr* __restrict__ out, const Fr
 // multiplier z.  Chunks of LIN_CH coefficients: (1) chunk Horner values V_c (carry-in 0),
 // (2) carry into chunk c = V_{c+1} + z^LIN_CH * carry_{c+1}: the same recurrence over chunks,
 // solved recursively (host drives levels), (3) chunk-local scan seeded with the carry.
-constexpr int LIN_CH = 64;
+constexpr int LIN_CH = 16;
 // level kernel 1: V[c] = sum_{i in chunk c} p[i] * z^(i - lo_c)   (Horner over the chunk)
 __global__ __launch_bounds__(TPB) void divlin_chunk_kernel(Fr* __restrict__ V, const Fr* __restrict__ p, u64 len,
                                                            FrArg z) {

@@ -214,11 +214,11 @@ int div_vanishing(Context& c, Fr* q, const Fr* p, uint64_t len, uint64_t n, Fr* 
   return MH_OK;
 }
 
-// q = (p - p(z)) / (X - z); q gets len - 1 coefficients.  scratch >= 2 * (len/64 + len/4096 + ...) elements
+// q = (p - p(z)) / (X - z); q gets len - 1 coefficients.  scratch >= 2 * (len/16 + len/256 + ...) elements
 int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* scratch) {
   if (len <= 1) return MH_OK;
   ProfScope ps(c, PF_GLUE);
-  // levels: A_0 = p; A_{j+1}[c] = Horner(A_j chunk c, m_j), m_0 = z, m_{j+1} = m_j^64
+  // levels: A_0 = p; A_{j+1}[c] = Horner(A_j chunk c, m_j), m_0 = z, m_{j+1} = m_j^LIN_CH
   std::vector<const Fr*> A; std::vector<uint64_t> L; std::vector<HFr> M;
   A.push_back(p); L.push_back(len); M.push_back(z);
   Fr* cur = scratch;
@@ -230,9 +230,9 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
     KLAUNCH(poly::divlin_chunk_kernel, nch, v, A.back(), (u64)n, arg(M.back()));
     V.push_back(v);
     HFr m = M.back();
-    for (int i = 0; i < 6; i++) m = m.sqr();     // ^64
+    for (int e = poly::LIN_CH; e > 1; e >>= 1) m = m.sqr();     // ^LIN_CH (a power of two)
     A.push_back(v); L.push_back(nch); M.push_back(m);
-    if (nch <= 64) break;
+    if (nch <= (uint64_t)poly::LIN_CH) break;
   }
   // top: carries into the chunks of the last A_j (j = A.size()-2) from A_{j+1} = V.back()
   int top = (int)V.size() - 1;
@@ -240,7 +240,7 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
   for (size_t j = 0; j < V.size(); j++) { C[j] = cur; cur += L[j + 1]; }
   hipLaunchKernelGGL(poly::divlin_top_kernel, dim3(1), dim3(1), 0, c.stream, C[top], (const Fr*)V[top], (u64)L[top + 1], arg(M[top + 1]));
   for (int j = top - 1; j >= 0; j--) {
-    // carries into chunks of A_j (count L[j+1]) from group carries C[j+1] (groups of 64 chunks), values V[j], multiplier M[j+1]
+    // carries into chunks of A_j (count L[j+1]) from group carries C[j+1] (groups of LIN_CH chunks), values V[j], multiplier M[j+1]
     uint64_t ngroups = L[j + 2];
     KLAUNCH(poly::divlin_expand_kernel, ngroups, C[j], (const Fr*)V[j], (const Fr*)C[j + 1], (u64)L[j + 1], arg(M[j + 1]));
   }
