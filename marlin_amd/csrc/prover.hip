@@ -183,19 +183,35 @@ int lincomb(Context& c, Fr* out, uint64_t n, const std::vector<Term>& terms) {
   return MH_OK;
 }
 
-// p(z) for a device polynomial
-int eval_poly(Context& c, ProverKey& pk, const Fr* p, uint64_t len, const HFr& z, HFr* out) {
-  if (len == 0) { *out = HFr::zero(); return MH_OK; }
-  uint64_t nthreads = (len + poly::EV_CH - 1) / poly::EV_CH;
-  unsigned blocks = poly::grid_for(nthreads);
-  Fr* partial = pk.small.fr();
+// p(z) for a device polynomial.  Long polynomials first collapse 16-coefficient chunks by Horner (one multiplication per
+// coefficient, no powers), then the chunk values are evaluated at z^16 by the block kernel (whose per-thread z^(start)
+// costs ~2 multiplications per coefficient it covers -- affordable on 1/16 of the data).
+// d_slot != nullptr: the value is left in device memory there (no host round trip; *out is not written)
+int eval_poly(Context& c, ProverKey& pk, const Fr* p, uint64_t len, const HFr& z, HFr* out, Fr* d_slot = nullptr) {
+  if (len == 0) {
+    if (d_slot) { MH_HIP(hipMemsetAsync(d_slot, 0, 32, c.stream)); return MH_OK; }
+    *out = HFr::zero(); return MH_OK;
+  }
+  Fr* base = pk.small.fr();
+  HFr zz = z;
   {
     ProfScope ps(c, PF_GLUE);
-    hipLaunchKernelGGL(poly::eval_partial_kernel, dim3(blocks), dim3(poly::TPB), 0, c.stream, partial, p, (u64)len, arg(z));
+    if (len >= (1u << 16)) {
+      const uint64_t nch = (len + poly::LIN_CH - 1) / poly::LIN_CH;
+      KLAUNCH(poly::divlin_chunk_kernel, nch, base, p, (u64)len, arg(z));
+      for (int e = poly::LIN_CH; e > 1; e >>= 1) zz = zz.sqr();
+      p = base; len = nch; base += nch;
+    }
+    uint64_t nthreads = (len + poly::EV_CH - 1) / poly::EV_CH;
+    unsigned blocks = poly::grid_for(nthreads);
+    Fr* partial = base;
+    hipLaunchKernelGGL(poly::eval_partial_kernel, dim3(blocks), dim3(poly::TPB), 0, c.stream, partial, p, (u64)len, arg(zz));
     hipLaunchKernelGGL(poly::sum_kernel, dim3(1), dim3(poly::TPB), 0, c.stream, partial + blocks, (const Fr*)partial, (u64)blocks);
+    base = partial + blocks;
   }
   MH_HIP(hipGetLastError());
-  return get_fr(c, out, partial + blocks);
+  if (d_slot) return d2d(c, d_slot, base, 1);
+  return get_fr(c, out, base);
 }
 
 // (q, -) = p / (X^n - 1); q gets len - n coefficients.  scratch: nchunks * n elements.
@@ -1061,10 +1077,18 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
 
   // ---------------- evaluations (lib.rs:272-287): g_1, g_2, t, z_b in label order ---------------------------
   HFr g1_beta, g2_gamma, t_beta, zb_beta;
-  MH_TRY(eval_poly(c, pk, pk.g1.fr(), g1_len, beta, &g1_beta));
-  MH_TRY(eval_poly(c, pk, pk.g2.fr(), g2_len, gamma, &g2_gamma));
-  MH_TRY(eval_poly(c, pk, pk.t.fr(), H, beta, &t_beta));
-  MH_TRY(eval_poly(c, pk, pk.zb.fr(), za_len, beta, &zb_beta));
+  {
+    // four evaluations, ONE copy back
+    Fr* slots = (Fr*)pk.scal.p;
+    MH_TRY(eval_poly(c, pk, pk.g1.fr(), g1_len, beta, nullptr, slots + 0));
+    MH_TRY(eval_poly(c, pk, pk.g2.fr(), g2_len, gamma, nullptr, slots + 1));
+    MH_TRY(eval_poly(c, pk, pk.t.fr(), H, beta, nullptr, slots + 2));
+    MH_TRY(eval_poly(c, pk, pk.zb.fr(), za_len, beta, nullptr, slots + 3));
+    uint64_t hv[16];
+    MH_HIP(hipMemcpyAsync(hv, slots, 4 * 32, hipMemcpyDeviceToHost, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));
+    memcpy(g1_beta.v, hv, 32); memcpy(g2_gamma.v, hv + 4, 32); memcpy(t_beta.v, hv + 8, 32); memcpy(zb_beta.v, hv + 12, 32);
+  }
   {
     std::vector<uint8_t> b;
     fsh::put_fr(b, g1_beta); fsh::put_fr(b, g2_gamma); fsh::put_fr(b, t_beta); fsh::put_fr(b, zb_beta);
