@@ -5,7 +5,9 @@ Metric (BASELINE.json): R1CS constraints / second for Marlin::prove on BLS12-381
 at 2^20 constraints (DummyCircuit of /root/reference benches/bench.rs:26-66,
 MarlinKZG10).  One "step" = one pass of the prove hot path over one instance:
 
-  workload "marlin-prove" (default): one full Marlin::prove (mh_marlin_prove: AHP rounds, Fiat-Shamir,
+  workload "marlin-prove" (default): one full Marlin::prove (mh_marlin_prove_dev -- formatted input and witness
+      already in HBM, as the measurement contract prescribes; BENCH_HOST_INPUTS=1 times the host-pointer entry point
+      mh_marlin_prove, the PCIe-inclusive figure --: AHP rounds, Fiat-Shamir,
       commitments, batch opening -- 16 NTTs and 13 large MSMs do the work of the reference's 30 and 15,
       DESIGN.md section 2) of DummyCircuit with its index and SRS resident in HBM; the proof it emits is
       byte-identical to the oracle's at the sizes the oracle reaches (tests/test_gpu_marlin.py) and
