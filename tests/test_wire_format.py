@@ -80,3 +80,18 @@ def test_verify_with_real_pairing_accepts_and_rejects():
     assert not MR.verify(pk, [a, a], pr, use_pairing=True)
     pr.evaluations[2] = (pr.evaluations[2] + 1) % F.R_MOD
     assert not MR.verify(pk, [c, d], pr, use_pairing=True)
+
+
+def test_serialized_size_follows_from_the_proof_structure():
+    """`Proof::serialized_size` (src/data_structures.rs:129-161 prints it) by the CanonicalSerialize rules of ark-serialize
+    0.3 [UPSTREAM-RECALLED]: u64 length prefix per Vec, 48-byte compressed G1, one tag byte per Option, 32-byte Fr.
+    MarlinKZG10: commitments 8 + 3 x 8 + 7 x (48 + 1) + 2 x (48 + 1 + 48) = 569; evaluations 8 + 4 x 32 = 136;
+    prover_messages 8 + 3 x 1 = 11; pc_proof 8 + (48 + 1 + 32) + (48 + 1) + 1 = 139  ->  855.
+    SonicKZG10: commitments 8 + 3 x 8 + 9 x 48 = 464  ->  750.
+    (README.md:87-88 quotes 880 / 784 bytes: those belong to an earlier proof structure of the paper's time, with more
+    evaluations; they do not describe `Proof` as src/data_structures.rs:100-110 defines it.)"""
+    marlin = (8 + 3 * 8 + 7 * (48 + 1) + 2 * (48 + 1 + 48)) + (8 + 4 * 32) + (8 + 3) + (8 + (48 + 1 + 32) + (48 + 1) + 1)
+    sonic = (8 + 3 * 8 + 9 * 48) + (8 + 4 * 32) + (8 + 3) + (8 + (48 + 1 + 32) + (48 + 1) + 1)
+    assert (marlin, sonic) == (855, 750)
+    # the flat ToBytes layout (uncompressed points with infinity bytes) of the same proofs
+    assert GM.proof_bytes_len("marlin") == 9 * 195 + 4 * 32 + 2 * (97 + 1 + 32) and GM.proof_bytes_len("sonic") == 9 * 97 + 4 * 32 + 2 * (97 + 1 + 32)
