@@ -121,10 +121,10 @@ from marlin_amd import marlin as GM, dist as MD
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 M.init(0)                                   # the GPU box has one GPU: both ranks share it
-n = 1 << 12
-srs = GM.universal_setup(n, n, 3 * n, %(tau)d, %(gamma)d)
+n = 1 << %(log_n)d
+srs = GM.universal_setup(n, n, 3 * n, %(tau)d, %(gamma)d, pc=%(pc)r)
 nc, ni, mats, inst, wit = GM.dummy_circuit(%(a)d, %(b)d, 10, n)
-pk = GM.index(srs, nc, ni, mats)
+pk = GM.index(srs, nc, ni, mats, pc=%(pc)r)
 MD.enable_sharded_prove(dist)
 proof = GM.prove(pk, inst, wit, bytes(range(32)))
 open(os.path.join(%(out)r, "proof%%d.bin" %% rank), "wb").write(proof)
@@ -132,20 +132,20 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_prove_ranks_equal_single(gpu, tmp_path, world):
-    """MSM sharding by bucket range across 2 and 3 ranks (gloo exchange, all ranks on the one GPU of this box) yields the
-    very same proof bytes as the unsharded prover."""
+@pytest.mark.parametrize("world,log_n,pc", [(2, 12, "marlin"), (3, 12, "marlin"), (2, 16, "sonic"), (4, 16, "marlin")])
+def test_sharded_prove_ranks_equal_single(gpu, tmp_path, world, log_n, pc):
+    """MSM sharding by bucket range across 2, 3 and 4 ranks (gloo exchange, all ranks on the one GPU of this box), both PC
+    schemes, yields the very same proof bytes as the unsharded prover."""
     import subprocess, sys
     a, b = 0x1234567, 0x7654321
-    n = 1 << 12
-    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA)
+    n = 1 << log_n
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc=pc)
     nc, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
-    pk = GM.index(srs, nc, ni, mats)
+    pk = GM.index(srs, nc, ni, mats, pc=pc)
     want = GM.prove(pk, inst, wit, bytes(range(32)))
     script = tmp_path / "shard_worker.py"
-    script.write_text(SHARD_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29613 + world), WORLD_SIZE=str(world))
+    script.write_text(SHARD_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "pc": pc})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29613 + world + log_n), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
