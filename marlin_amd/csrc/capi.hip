@@ -139,16 +139,20 @@ int ntt_device_len(Context& c, const void* d_in, uint64_t in_len, void* d_out, u
   Fr ninv = to_dev_fr(ninv_h);
   // buffer chain: in -> ... -> out, intermediates in scratch (never writes d_in unless d_in == d_out)
   const Fr* src = (const Fr*)d_in;
-  MH_TRY(c.ntt_tmp[0].ensure(np > 1 ? bytes : 0));
-  MH_TRY(c.ntt_tmp[1].ensure(np > 2 ? bytes : 0));
+  const size_t mid_bytes = ntt_use30() ? (size_t)36 << log_n : bytes;     // intermediate passes of the 30-bit kernel: 36 B per element
+  MH_TRY(c.ntt_tmp[0].ensure(np > 1 ? mid_bytes : 0));
+  MH_TRY(c.ntt_tmp[1].ensure(np > 2 ? mid_bytes : 0));
   uint32_t logP = 0;
   ProfScope ps(c, PF_NTT);
   for (int p = 0; p < np; p++) {
     Fr* dst;
     if (p == np - 1) dst = (Fr*)d_out;
     else dst = (Fr*)c.ntt_tmp[p & 1].ptr;
-    // flags: bit 0 = last pass of an inverse transform (n^-1, index negation), bit 1 = last pass (canonical residues out)
-    const uint32_t pass_flags = ((inverse && p == np - 1) ? 1u : 0u) | (p == np - 1 ? 2u : 0u);
+    // flags: bit 0 = last pass of an inverse transform (n^-1, index negation), bit 1 = last pass, bit 2 / bit 3 = the
+    // pass reads / writes the 36-byte lazy 9-limb elements that the 30-bit kernel keeps between passes
+    const bool lazy_mid = ntt_use30();
+    const uint32_t pass_flags = ((inverse && p == np - 1) ? 1u : 0u) | (p == np - 1 ? 2u : 0u) | ((lazy_mid && p > 0) ? 4u : 0u) |
+                                ((lazy_mid && p < np - 1) ? 8u : 0u);
     // last pass writes d_out; if d_out == src of this pass (only when np == 1 and in-place) bounce via scratch
     if (p == np - 1 && (const void*)dst == (const void*)src) {
       MH_TRY(c.ntt_tmp[0].ensure(bytes));

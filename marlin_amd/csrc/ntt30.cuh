@@ -7,8 +7,8 @@
 //    accumulator overflows after two products) plus conditional corrections in every addition and subtraction.  On
 //    9 x 30-bit limbs (R' = 2^270) it is 162 v_mad_u64_u32 with one mask + shift per column (gen_fq30.py, the same
 //    generator as the base field of the bucket accumulation), and because R' / r = 2^15 the butterflies never reduce:
-//    a' = a + w b, b' = a - w b + 2 r grow by at most 2 r per stage and are brought back below 2 r (r on the last pass)
-//    once per pass.  The transform is linear, so the DATA keeps its standard representation: an element a R (R = 2^256)
+//    a' = a + w b, b' = a - w b + 2 r grow by at most 2 r per stage; the passes in between store the lazy 9-limb values as
+//    they are (36 B per element in the scratch buffers) and only the last pass reduces to the canonical residue.  The transform is linear, so the DATA keeps its standard representation: an element a R (R = 2^256)
 //    is re-sliced into 30-bit limbs as the integer it is, multiplied by twiddles held as w R' mod r, and the Montgomery
 //    reduction by R' returns a w R.  Only the twiddle table exists in a second form (tw30, 36 B per entry).
 //  * Rounds.  A round takes 2^NS elements per work item into registers, runs NS stages on them and writes them back.
@@ -105,7 +105,7 @@ __device__ __forceinline__ void cond_sub(Fr30& a) {
   int c = 0;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
-    const u32 kp = K == 1 ? RP::P[i] : (K == 2 ? RP::P2[i] : (K == 4 ? RP::P4[i] : (K == 8 ? RP::P8[i] : RP::P16[i])));
+    const u32 kp = K == 1 ? RP::P[i] : (K == 2 ? RP::P2[i] : (K == 4 ? RP::P4[i] : (K == 8 ? RP::P8[i] : (K == 16 ? RP::P16[i] : (K == 32 ? RP::P32[i] : RP::P64[i])))));
     int s = (int)(a.v[i] - kp) + c;
     if (i < NL - 1) { t[i] = (u32)s & M30; c = s >> 30; } else { t[i] = (u32)s; c = s; }
   }
@@ -114,11 +114,22 @@ __device__ __forceinline__ void cond_sub(Fr30& a) {
     for (int i = 0; i < NL; i++) a.v[i] = t[i];
   }
 }
-// a < 32 r  ->  a < 2 r (full = false) or the canonical a < r (full = true)
-template <bool FULL>
-__device__ __forceinline__ void reduce_ladder(Fr30& a) {
-  cond_sub<16>(a); cond_sub<8>(a); cond_sub<4>(a); cond_sub<2>(a);
-  if (FULL) cond_sub<1>(a);
+// a < 128 r  ->  the canonical a < r.  A transform of 2^k points leaves values below (1 + 2 k) r <= 65 r at the end of its
+// last pass (every stage adds at most 2 r, and the passes in between store the lazy values as they are).  The quotient
+// is estimated from the top limb (bits 240 and up) against r's top 15 bits, rounded so that it never overshoots and
+// undershoots by at most 2: one multiple of r is subtracted, two conditional subtractions finish (a ladder of seven
+// conditional subtractions costs 2.4 x as many instructions).
+__device__ __forceinline__ void reduce_full(Fr30& a) {
+  constexpr u32 R_TOP = RP::P[NL - 1];                                   // r >> 240
+  constexpr u32 MAGIC = (u32)(0xffffffffull / (R_TOP + 1));              // <= 2^32 / (r_top + 1)
+  const u32 q = (u32)(((u64)a.v[NL - 1] * MAGIC) >> 32);                 // <= floor(a / r), >= floor(a / r) - 2
+  long long c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const long long s = (long long)a.v[i] - (long long)((u64)q * RP::P[i]) + c;
+    if (i < NL - 1) { a.v[i] = (u32)s & M30; c = s >> 30; } else a.v[i] = (u32)s;
+  }
+  cond_sub<2>(a); cond_sub<1>(a);
 }
 // (a, b) <- (a + w b, a - w b + 2 r): w b < 1.01 r whatever the (lazily reduced) b, so both grow by at most 2 r
 __device__ __forceinline__ void butterfly(Fr30& a, Fr30& b, const u32* w) {
@@ -201,7 +212,7 @@ __device__ __forceinline__ void round_stages(u32* tile, u32 tw_words, const u32*
 
 // One Stockham pass (arguments as ntt::pass_kernel; tw30 instead of tw).
 template <int LOGC, int MAXNS, int THREADS, int WAVES, int PAD, bool TWLDS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pass30_kernel(const Fr* __restrict__ x, Fr* __restrict__ y, const u32* __restrict__ tw30,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pass30_kernel(const void* __restrict__ x, void* __restrict__ y, const u32* __restrict__ tw30,
                                                          u32 log_n, u32 B, u32 logP, u32 flags, Fr ninv, u64 in_len) {
   extern __shared__ __attribute__((aligned(16))) u32 lds30[];
   constexpr int C = 1 << LOGC;
@@ -219,7 +230,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
     const u32 c = idx & (C - 1), r = idx >> LOGC;
     const u64 gi = (jbase + c) + (u64)r * stride;
     Fr30 v;
-    if (gi < in_len) v = slice30(ff_load(x + gi));
+    if (flags & 4u) {                                  // a pass in between: 9 lazy limbs per element, as the previous pass left them
+      const u32* p = (const u32*)x + 9 * gi;
+#pragma unroll
+      for (int l = 0; l < NL; l++) v.v[l] = p[l];
+    } else if (gi < in_len) v = slice30(ff_load((const Fr*)x + gi));
     else {
 #pragma unroll
       for (int l = 0; l < NL; l++) v.v[l] = 0;
@@ -247,10 +262,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
     t += ns;
   }
 
-  // ---- store: values below (2 + 2 B) r come back below 2 r (more passes follow), to the canonical residue (last pass),
-  // or through the multiplication by n^-1 (last pass of an inverse transform; index negated)
+  // ---- store.  More passes follow (flags bit 3): the 9 lazy limbs go out as they are, 36 B per element -- no reduction,
+  // no repacking; the NTT is bound by VALU issue, not by HBM, so 12 % more bytes on the intermediate buffers are cheaper
+  // than ~250 instructions per element.  Last pass: the canonical residue in the standard 8 x 32-bit form, through the
+  // multiplication by n^-1 for an inverse transform (index negated).
   const bool inv_last = flags & 1u;
-  const bool last = flags & 2u;
   u32 ninv30[NL];
   if (inv_last) {
     Fr c;
@@ -267,16 +283,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
     const u64 j = jbase + c;
     const u64 k = j & (P - 1);
     u64 o = ((j - k) << B) + k + ((u64)r2 << logP);        // logP = 0: (j << B) + r2
+    if (flags & 8u) {
+      u32* q = (u32*)y + 9 * o;
+#pragma unroll
+      for (int l = 0; l < NL; l++) q[l] = v.v[l];
+      continue;
+    }
     if (inv_last) {
       o = (n - o) & (n - 1);
       v = mul30(v, ninv30);
       cond_sub<1>(v);
-    } else if (last) {
-      reduce_ladder<true>(v);
     } else {
-      reduce_ladder<false>(v);
+      reduce_full(v);
     }
-    ff_store(y + o, pack32(v));
+    ff_store((Fr*)y + o, pack32(v));
   }
 }
 
