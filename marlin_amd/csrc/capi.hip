@@ -395,15 +395,19 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
                        (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S, own);
     MH_HIP(hipMemcpyAsync(ptot.data(), c.fb_ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
-    // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count
+    // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count.  The XCD of
+    // a window is its rank among the windows that HAVE entries, mod 8: with the MSM sharded over G ranks a rank owns the
+    // partitions v = g (mod G), and numbering by gw would put all of them on one XCD for G = 8
     u64 bho = 0, xcd_tiles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<u32> live;                 // windows with entries, in gw order
     for (int k = 0; k < nj; k++) {
       u64 off = jobs.ent_off[k];
       for (u32 v = 0; v < nparts; v++) {
         const u32 gw = k * nparts + v;
         msmfb::FbWin& d = desc[gw];
         d.off = off; d.cnt = ptot[gw]; d.ntiles = (u32)((d.cnt + tile - 1) / tile); d.bh_off = bho;
-        off += d.cnt; bho += (u64)d.ntiles * nb; xcd_tiles[gw & 7] += d.ntiles;
+        off += d.cnt; bho += (u64)d.ntiles * nb;
+        if (d.ntiles) { xcd_tiles[live.size() & 7] += d.ntiles; live.push_back(gw); }
       }
     }
     u64 grid_tiles = 0;
@@ -411,8 +415,8 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     blk.assign(grid_tiles * 8, F::FbBlk{0xffffffffu, 0});
     for (u32 x = 0; x < 8; x++) {
       u64 k = 0;
-      for (u32 gw = x; gw < WT; gw += 8)
-        for (u32 t = 0; t < desc[gw].ntiles; t++) blk[(k++ << 3) | x] = F::FbBlk{gw, t};
+      for (size_t li = x; li < live.size(); li += 8)
+        for (u32 t = 0; t < desc[live[li]].ntiles; t++) blk[(k++ << 3) | x] = F::FbBlk{live[li], t};
     }
     MH_HIP(hipMemcpyAsync(c.fb_desc.ptr, desc.data(), (size_t)WT * sizeof(msmfb::FbWin), hipMemcpyHostToDevice, s));
     if (grid_tiles) MH_HIP(hipMemcpyAsync(c.fb_blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
