@@ -381,7 +381,7 @@ def main():
     out = {
         "metric": "marlin_prove_constraints_per_sec", "value": round(value, 1), "unit": "constraints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32-limb Montgomery integers (Fr 256-bit in 8 x 32; Fq 384-bit in 12 x 32 and 13 x 30 bits)",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32-limb Montgomery integers (Fr 256-bit in 8 x 32 and 9 x 30 bits; Fq 384-bit in 12 x 32 and 13 x 30 bits)",
         "data": "synthetic",
         "config": {"workload": ("marlin-prove: Marlin::prove from the padded R1CS instance + witness on (AHP rounds + KZG10 commit/open + "
                                 "Fiat-Shamir; witness synthesis src/ahp/prover.rs:217-230 excluded), "
