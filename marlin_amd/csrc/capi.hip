@@ -350,10 +350,21 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
   F::FbJobs jobs;
   memset(&jobs, 0, sizeof(jobs));
   jobs.njobs = nj;
+  // A job whose scalars ARE another job's (same device vector, same length) with bases further into the same set --
+  // MarlinKZG10 commits a degree-bounded polynomial against powers and against shifted_powers(d) -- has the same digits,
+  // hence the same sorted bucket lists: it skips the sort stages and reads the other job's lists with its table indices
+  // shifted by the distance of the base ranges (FbWin::delta).  Accumulation and reduction stay per job.
+  std::vector<int> alias(nj, -1);
+  static const bool alias_on = [] { const char* e = getenv("MH_FB_ALIAS"); return !(e && atoi(e) == 0); }();
+  for (int k = 1; k < nj && alias_on; k++)
+    for (int j = 0; j < k; j++)
+      if (alias[j] < 0 && d_scalars[j] == d_scalars[k] && ns[j] == ns[k] && offs[k] >= offs[j]) { alias[k] = j; break; }
   u64 ent = 0, pco = 0; u32 max_blk = 0;
   for (int k = 0; k < nj; k++) {
     jobs.scalars[k] = (const Fr*)d_scalars[k]; jobs.n[k] = ns[k]; jobs.tab_off[k] = (u32)offs[k];
-    jobs.ent_off[k] = ent; ent += (u64)W * ns[k];
+    jobs.ent_off[k] = ent;
+    if (alias[k] >= 0) { jobs.nblk[k] = 0; jobs.pc_off[k] = pco; continue; }       // no blocks: count / split skip the job
+    ent += (u64)W * ns[k];
     jobs.nblk[k] = (u32)((ns[k] + S - 1) / S);
     jobs.pc_off[k] = pco; pco += (u64)nparts * jobs.nblk[k];
     max_blk = std::max(max_blk, jobs.nblk[k]);
@@ -405,6 +416,13 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
       for (u32 v = 0; v < nparts; v++) {
         const u32 gw = k * nparts + v;
         msmfb::FbWin& d = desc[gw];
+        d.delta = 0; d.pad = 0;
+        if (alias[k] >= 0) {
+          // shares the lists of the job it aliases: no tiles of its own (hist / scatter never see it)
+          const msmfb::FbWin& src = desc[alias[k] * nparts + v];
+          d.off = src.off; d.cnt = src.cnt; d.ntiles = 0; d.bh_off = bho; d.delta = (u32)(offs[k] - offs[alias[k]]);
+          continue;
+        }
         d.off = off; d.cnt = ptot[gw]; d.ntiles = (u32)((d.cnt + tile - 1) / tile); d.bh_off = bho;
         off += d.cnt; bho += (u64)d.ntiles * nb;
         if (d.ntiles) { xcd_tiles[live.size() & 7] += d.ntiles; live.push_back(gw); }
@@ -431,6 +449,11 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
     u32* d_max = (u32*)c.tr_sums.ptr;                  // [0] largest bucket, [1] buckets with deferred entries
     MH_HIP(hipMemsetAsync(d_max, 0, 8, s));
     hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, nb, d_max);
+    for (int k = 0; k < nj; k++)
+      if (alias[k] >= 0) {          // an aliasing job has the bucket sizes and list positions of the job whose lists it reads
+        MH_HIP(hipMemcpyAsync((u32*)c.msm_tot.ptr + (size_t)k * nbt, (const u32*)c.msm_tot.ptr + (size_t)alias[k] * nbt, (size_t)nbt * 4, hipMemcpyDeviceToDevice, s));
+        MH_HIP(hipMemcpyAsync((u32*)c.msm_base.ptr + (size_t)k * nbt, (const u32*)c.msm_base.ptr + (size_t)alias[k] * nbt, (size_t)nbt * 4, hipMemcpyDeviceToDevice, s));
+      }
     if (grid_tiles) {
       hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::scatter_lds_bytes(nb), s, fbw, dblk, (const u32*)key,
                          (const u32*)val, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr, nb, (u32)tile);
@@ -462,8 +485,8 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
                            (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
     }
     hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw,
-                       (const F::G1Aff30*)bs.d_table, (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_pend.ptr,
-                       (const u32*)(d_max + 1), (F::G1Xyzz30*)c.msm_buckets.ptr, nb, (u64)WB);
+                       (const F::G1Aff30*)bs.d_table, (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr,
+                       (const u32*)c.msm_pend.ptr, (const u32*)(d_max + 1), (F::G1Xyzz30*)c.msm_buckets.ptr, nb, (u64)WB);
     // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
     F::G1Xyzz30* seg30 = (F::G1Xyzz30*)c.msm_seg.ptr;
     hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)c.msm_buckets.ptr,

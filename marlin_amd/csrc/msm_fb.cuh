@@ -30,7 +30,10 @@ namespace msmfb {
 using msm::Windows;
 
 // Virtual window: a variable-length run of the entry arrays holding the entries of 2^PART_BITS consecutive buckets
-struct FbWin { u64 off; u64 bh_off; u32 cnt; u32 ntiles; };
+// delta: added to every table index of the window's entries -- 0 except for a job that SHARES the sorted lists of another
+// job with the same scalars and a base range `delta` points further into the same base set (MarlinKZG10 commits a
+// degree-bounded polynomial twice: against powers and against shifted_powers(d) = powers[max_degree - d ..])
+struct FbWin { u64 off; u64 bh_off; u32 cnt; u32 ntiles; u32 delta; u32 pad; };
 
 // Table point: affine, coordinates as 30-bit-limb Montgomery residues (fq30.cuh), each coordinate padded to a
 // multiple of four words (BLS12-381: 2 x 64 B, one cache line per coordinate)
@@ -483,14 +486,16 @@ __global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__
 // X3 = (R^2 - PPP + 2p) - 2Q + 3p <= 6.2, Y3 = (R (Q - X3 + 8p) + (4p - Y1) PPP) / R' <= 1 + (5.1 x 9.2 + 4 x 1.2) / 630 < 1.1.
 template <int WAVES>
 __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
-                                                               u32* __restrict__ sorted_all, const u32* __restrict__ base,
+                                                               const u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                                const u32* __restrict__ tot, const u32* __restrict__ perm,
                                                                G1Xyzz30* __restrict__ buckets, u32* __restrict__ pend,
                                                                u32* __restrict__ n_deferred, u32 nb, u64 WB, u32 nparts, Own own) {
   const u64 slot = (u64)blockIdx.x * msm::ACC_TPB + threadIdx.x;
   if (slot >= WB) return;
   const u64 gid = perm[slot];
-  u32* lst = sorted_all + fbw[gid / nb].off + base[gid];
+  const FbWin d = fbw[gid / nb];
+  const u32* lst = sorted_all + d.off + base[gid];
+  const G1Aff30* tab = table + d.delta;
   const u32 cnt = tot[gid];
   if (cnt == 0) {
     const u32 v = (u32)(gid / nb) % nparts;         // another rank's buckets are never read: nothing to store
@@ -503,24 +508,25 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
   Fq30 X1, Y1, ZZ, ZZZ;
   {
     const u32 e = lst[0];
-    const G1Aff30* q = table + (e & 0x7fffffffu);
+    const G1Aff30* q = tab + (e & 0x7fffffffu);
     X1 = load30(q->x);
     Y1 = load30(q->y);
     if (e & 0x80000000u) Y1 = f30_sub<2>(zero, Y1);
 #pragma unroll
     for (int i = 0; i < Fq30::NL; i++) { ZZ.v[i] = Fq30Params::ONE[i]; ZZZ.v[i] = Fq30Params::ONE[i]; }
   }
-  u32 np = 0;
   u32 e_next = cnt > 1 ? lst[1] : 0;
   for (u32 k = 1; k < cnt; k++) {
     const u32 e = e_next;
     if (k + 1 < cnt) e_next = lst[k + 1];           // one iteration ahead: takes the list load off the critical path
-    const G1Aff30* q = table + (e & 0x7fffffffu);
+    const G1Aff30* q = tab + (e & 0x7fffffffu);
     const Fq30 x2 = load30(q->x);
     Fq30 y2 = load30(q->y);
     if (e & 0x80000000u) y2 = f30_sub<2>(zero, y2);
     const Fq30 P = f30_sub<8>(f30_mul(x2, ZZ), X1);
-    if (__builtin_expect(f30_is_zero(P), 0)) { lst[np++] = e; continue; }   // np <= k: never overtakes the read cursor
+    // equal x (the same point twice, or P and -P): leave the whole bucket to the fix-up pass, which recomputes it with the
+    // complete addition law.  The lists are read-only here because two jobs may share them (FbWin::delta).
+    if (__builtin_expect(f30_is_zero(P), 0)) { pend[gid] = 1; atomicAdd(n_deferred, 1u); return; }
     const Fq30 R = f30_sub<4>(f30_mul(y2, ZZZ), Y1);
     Fq30 PP = f30_sqr(P);
     ZZ = f30_mul(ZZ, PP);
@@ -532,25 +538,27 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
     Y1 = f30_mul2(R, f30_sub<8>(Q, X1), nY1, PP);               // Y3 = R (Q - X3) - Y1 PPP: two products, ONE reduction
   }
   store30(buckets[gid].c[0], X1); store30(buckets[gid].c[1], Y1); store30(buckets[gid].c[2], ZZ); store30(buckets[gid].c[3], ZZZ);
-  pend[gid] = np;
-  if (np) atomicAdd(n_deferred, 1u);
+  pend[gid] = 0;
 }
 
-// deferred entries: complete group law in the standard representation, one thread per bucket that has any (a small
-// grid-stride launch that returns at once in the usual case of no deferred entry at all)
+// buckets that met an equal-x pair (pend != 0): recomputed from their whole list with the complete group law in the
+// standard representation, one thread per such bucket (a small grid-stride launch that returns at once in the usual case
+// of no deferred bucket at all)
 __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                      const u32* __restrict__ sorted_all, const u32* __restrict__ base,
-                                                     const u32* __restrict__ pend, const u32* __restrict__ n_deferred,
-                                                     G1Xyzz30* __restrict__ buckets, u32 nb, u64 WB) {
+                                                     const u32* __restrict__ tot, const u32* __restrict__ pend,
+                                                     const u32* __restrict__ n_deferred, G1Xyzz30* __restrict__ buckets, u32 nb, u64 WB) {
   if (*n_deferred == 0) return;
   for (u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x; gid < WB; gid += (u64)gridDim.x * blockDim.x) {
-  const u32 np = pend[gid];
-  if (np == 0) continue;
-  const u32* lst = sorted_all + fbw[gid / nb].off + base[gid];
-  G1Xyzz acc = x30_to_std(x30_load(buckets + gid));
-  for (u32 k = 0; k < np; k++) {
+  if (pend[gid] == 0) continue;
+  const FbWin d = fbw[gid / nb];
+  const u32* lst = sorted_all + d.off + base[gid];
+  const G1Aff30* tab = table + d.delta;
+  const u32 cnt = tot[gid];
+  G1Xyzz acc = G1Xyzz::identity();
+  for (u32 k = 0; k < cnt; k++) {
     const u32 e = lst[k];
-    const G1Aff30* q = table + (e & 0x7fffffffu);
+    const G1Aff30* q = tab + (e & 0x7fffffffu);
     Fq x = f30_to_fq(load30(q->x)), y = f30_to_fq(load30(q->y));
     if (e & 0x80000000u) y = ff_neg(y);
     g1_madd(acc, x, y);
