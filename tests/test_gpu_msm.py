@@ -263,6 +263,39 @@ def test_fixed_base_table_info_and_shard_resize(gpu, bases4k):
     assert B.table_info()[0] == 14
 
 
+def test_msm_fixed_base_jobs_sharing_scalars(gpu, bases4k):
+    """Jobs of one batch that multiply the SAME scalar vector against ranges of the same tabled base set (what
+    MarlinKZG10::commit does for a degree-bounded polynomial: powers and shifted_powers(d)) share one sort: results equal
+    the known-dlog answers, including with repeated (base, scalar) pairs (the equal-x buckets are recomputed by the
+    fix-up pass, whose lists are shared) and with the offsets in either order."""
+    pts, dl = bases4k
+    n = 1 << 15
+    big = np.tile(points_to_np(pts), (n // 4096, 1))
+    dlb = [dl[i % 4096] for i in range(n)]
+    B = gpu.Bases(big).precompute(12)
+    r = F.R_MOD
+
+    def want(sc, off):
+        return EC.scalar_mul(EC.G1_GEN, sum(s * a for s, a in zip(sc, dlb[off:off + len(sc)])) % r)
+
+    m = 20000
+    sc = rand_fr(m, 99)
+    buf = gpu.DeviceBuffer.from_numpy(fr_to_np(sc))
+    other = rand_fr(9000, 100)
+    obuf = gpu.DeviceBuffer.from_numpy(fr_to_np(other))
+    fb0, _ = gpu.msm_path_counts()
+    out = gpu.msm_batch_dev([(B, 0, buf, m), (B, 4096 + 7, buf, m), (B, 11, obuf, 9000), (B, 3, buf, m)])
+    assert gpu.msm_path_counts()[0] > fb0
+    assert [jac_np_to_affine(o) for o in out] == [want(sc, 0), want(sc, 4103), want(other, 11), want(sc, 3)]
+    out = gpu.msm_batch_dev([(B, 500, buf, m), (B, 2, buf, m)])                      # the later job starts EARLIER: no sharing
+    assert [jac_np_to_affine(o) for o in out] == [want(sc, 500), want(sc, 2)]
+    # repeated pairs: base i and base i + 4096 are the same point, equal scalars put them into the same buckets
+    rep = ([5, 5, r - 5, 77] * (m // 4))[:m]
+    rbuf = gpu.DeviceBuffer.from_numpy(fr_to_np(rep))
+    out = gpu.msm_batch_dev([(B, 0, rbuf, m), (B, 4096, rbuf, m), (B, 1, rbuf, m)])
+    assert [jac_np_to_affine(o) for o in out] == [want(rep, 0), want(rep, 4096), want(rep, 1)]
+
+
 def test_fq30_device_selftest(gpu):
     """the 30-bit-limb field / group arithmetic of the fixed-base path agrees with the 32-bit Montgomery arithmetic on
     2^18 pseudo-random operand pairs plus structured ones (mh_selftest_fq30)."""
