@@ -550,11 +550,19 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   hipStream_t s = c.stream;
   const unsigned grid = (unsigned)((bs.n + 127) / 128);
   const G1Affine* prev = (const G1Affine*)bs.d_points;
+  // level 0 = [R^-1 mod r] P (see table_level_kernel): R^-1 as a canonical integer is the value whose Montgomery words are 1
+  Fr kinv;
+  {
+    HFr one_raw = HFr::zero(); one_raw.v[0] = 1;
+    uint64_t k64[4];
+    one_raw.to_canonical(k64);
+    memcpy(kinv.v, k64, 32);
+  }
   for (u32 j = 0; j < W; j++) {
     G1Affine* next_std = (G1Affine*)((char*)tmp + (size_t)(j & 1) * bs.n * PT_B);
     hipLaunchKernelGGL(msmfb::table_level_kernel, dim3(grid), dim3(128), 0, s, prev, next_std,
-                       (msmfb::G1Aff30*)((char*)tab + (size_t)j * bs.n * pt30), (u64)bs.n, j ? (u32)win.bits[j - 1] : 0u);
-    if (j) prev = next_std;
+                       (msmfb::G1Aff30*)((char*)tab + (size_t)j * bs.n * pt30), (u64)bs.n, j ? (u32)win.bits[j - 1] : 0u, kinv);
+    prev = next_std;
   }
   hipError_t le = hipGetLastError();
   hipError_t se = hipStreamSynchronize(s);

@@ -110,15 +110,31 @@ struct FbJobs {
 };
 
 // ---- table -----------------------------------------------------------------------------------------------
-// level j from level j-1 by `bits` doublings (bits = 0: level 0, the points themselves); the standard-form
-// result feeds the next level, the 30-bit-limb form is what the accumulation reads
+// level j from level j-1 by `bits` doublings; the standard-form result feeds the next level, the 30-bit-limb form is what
+// the accumulation reads.  Level 0 (bits = 0) is NOT the point itself but [R^-1 mod r] P (R = 2^256, kinv = that
+// integer): the prover's scalars arrive in Montgomery form -- the integer s R mod r -- and sum (s_i R) ([R^-1] P_i) =
+// sum s_i P_i, so the partition kernels recode the words they load and never run a Montgomery reduction per scalar and
+// window pass (canonical scalars are multiplied by R instead, at the cost the reduction had).
 __global__ __launch_bounds__(128) void table_level_kernel(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next_std,
-                                                          G1Aff30* __restrict__ next30, u64 n, u32 bits) {
+                                                          G1Aff30* __restrict__ next30, u64 n, u32 bits, Fr kinv) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1Affine p = g1_load_affine(prev + i);
   G1Affine r = p;
-  if (bits) {
+  if (bits == 0) {
+    G1Xyzz a = G1Xyzz::identity();
+    for (int limb = Fr::N - 1; limb >= 0; limb--)
+      for (int b = 31; b >= 0; b--) {
+        g1_dbl(a);
+        if ((kinv.v[limb] >> b) & 1u) g1_madd(a, p.x, p.y);
+      }
+    Fq iz = ff_inv(a.zzz);                     // [k] P of a point of prime order r with 0 < k < r is never the identity
+    Fq izz = ff_mul(ff_sqr(a.zz), ff_sqr(iz));
+    r.x = ff_mul(a.x, izz);
+    r.y = ff_mul(a.y, iz);
+    ff_store(&next_std[i].x, r.x);
+    ff_store(&next_std[i].y, r.y);
+  } else {
     G1Xyzz a;
     g1_dbl_affine(a, p.x, p.y);
     for (u32 k = 1; k < bits; k++) g1_dbl(a);
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(TPB) void count_kernel(FbJobs jobs, u32* __restrict
     u64 i = (u64)blk * S + k;
     if (i < n) {
       Fr s = ff_load(jobs.scalars[job] + i);
-      if (is_mont) s = ff_from_mont(s);
+      if (!is_mont) s = ff_to_mont(s);            // the table holds [R^-1] P: the digits of s R are what multiplies it
       msm::for_each_digit(s, W, win, [&](u32, u32 e) {
         u32 b = e & 0x7fffffffu;
         if (b) {
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const 
   const bool live = t < S && i < n;
   if (live) {
     Fr s = ff_load(jobs.scalars[job] + i);
-    if (is_mont) s = ff_from_mont(s);
+    if (!is_mont) s = ff_to_mont(s);
     const u32 t0 = jobs.tab_off[job] + (u32)i;
     msm::for_each_digit(s, W, win, [&](u32 w, u32 e) {
       u32 b = e & 0x7fffffffu;
