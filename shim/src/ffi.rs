@@ -29,6 +29,17 @@ pub struct mh_r1cs_matrices {
     pub val: [*const u64; 3],
 }
 
+/// `mh_verifier_key` (marlin_hip.h): the group elements of kzg10::VerifierKey / marlin_pc::VerifierKey.
+#[repr(C)]
+pub struct mh_verifier_key {
+    pub g_xy: *const u64,
+    pub gamma_g_xy: *const u64,
+    pub h_xy: *const u64,
+    pub beta_h_xy: *const u64,
+    pub shift_power_h_xy: *const u64,
+    pub shift_power_k_xy: *const u64,
+}
+
 /// `mh_allgather_fn`: gather `bytes` bytes from every rank into `recv` (rank-major).
 pub type mh_allgather_fn =
     Option<unsafe extern "C" fn(send: *const c_void, bytes: usize, recv: *mut c_void, user: *mut c_void) -> c_int>;
@@ -95,6 +106,9 @@ extern "C" {
                            zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_prove_dev(pk: u64, d_instance_mont: *const c_void, d_witness_mont: *const c_void, zk_seed32: *const u8,
                                zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
+    pub fn mh_marlin_verify(vk_bytes: *const u8, vk_len: usize, vk: *const mh_verifier_key, public_input_mont: *const u64, n_public: usize,
+                            flat_proof: *const u8, proof_len: usize, ok_out: *mut c_int) -> c_int;
+    pub fn mh_pairing_product_is_one(g1_xy_mont: *const u64, g2_xy_mont: *const u64, n: usize, is_one_out: *mut c_int) -> c_int;
     pub fn mh_marlin_proof_serialize(flat_proof: *const u8, flat_len: usize, pc: c_int, out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_proof_deserialize(bytes: *const u8, len: usize, pc: c_int, flat_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_set_shard(rank: c_int, world: c_int, allgather: mh_allgather_fn, user: *mut c_void) -> c_int;
