@@ -250,7 +250,9 @@ def main():
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -258,6 +260,7 @@ def main():
     # test hooks: BENCH_BACKEND=gloo and BENCH_SINGLE_DEVICE=1 let the N > 1 code path run with every rank on GPU 0
     # (the GPU box of this project has one GPU; RCCL refuses two ranks on one device)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("BENCH_SINGLE_DEVICE"):
         local_rank = 0
     import torch
@@ -270,7 +273,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dry:
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl" and not dry:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if dry:
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         if world > 1:

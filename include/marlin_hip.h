@@ -190,22 +190,25 @@ int mh_marlin_prove_dev(uint64_t pk, const void* d_instance_mont, const void* d_
 int mh_marlin_proof_serialize(const uint8_t* flat_proof, size_t flat_len, int pc, uint8_t* out, size_t cap, size_t* len_out);
 int mh_marlin_proof_deserialize(const uint8_t* bytes, size_t len, int pc, uint8_t* flat_out, size_t cap, size_t* len_out);
 
-/* Marlin::verify (src/lib.rs:315-433) for MarlinKZG10 on BLS12-381, on the host (no device needed): transcript replay,
- * linear combinations, PC::check_combinations with a real pairing.  vk_bytes = mh_marlin_vk_bytes (index_info || 6 index
- * commitments); the group elements of kzg10::VerifierKey / marlin_pc::VerifierKey are passed separately, affine
- * Montgomery limbs (G1: x||y, 12 limbs; G2: x.c0||x.c1||y.c0||y.c1, 24 limbs): g, gamma_g, h, beta_h and the shift powers
- * powers_of_g[max_degree - (|H| - 2)], powers_of_g[max_degree - (|K| - 2)] of the two enforced degree bounds.
- * public_input: the UNformatted input (no leading one), Montgomery Fr.  *ok_out = 1 accept / 0 reject; a malformed
- * proof or key is MH_EINVAL.  The BN254 library returns MH_EINVAL (no pairing built for it). */
+/* Marlin::verify (src/lib.rs:315-433) on the host (no device needed): transcript replay, linear combinations,
+ * PC::check_combinations with a real pairing on the library's curve.  pc: 0 = MarlinKZG10, 1 = SonicKZG10.
+ * vk_bytes = mh_marlin_vk_bytes (index_info || 6 index commitments); the group elements of kzg10::VerifierKey and
+ * marlin_pc:: / sonic_pc::VerifierKey are passed separately as affine Montgomery limbs (G1: x||y, 2 * fq_limbs64;
+ * G2: x.c0||x.c1||y.c0||y.c1, 4 * fq_limbs64): g, gamma_g, h, beta_h and, for the two enforced degree bounds |H| - 2 and
+ * |K| - 2, the shift powers -- pc 0: G1 points powers_of_g[max_degree - bound]; pc 1: G2 points
+ * [beta^-(max_degree - bound)] h (sonic_pc's degree_bounds_and_neg_powers_of_h).  G2 elements must lie in the order-r
+ * subgroup.  public_input: the UNformatted input (no leading one), Montgomery Fr.  *ok_out = 1 accept / 0 reject; a
+ * malformed proof or key is MH_EINVAL. */
 typedef struct {
   const uint64_t* g_xy; const uint64_t* gamma_g_xy;
   const uint64_t* h_xy; const uint64_t* beta_h_xy;
   const uint64_t* shift_power_h_xy; const uint64_t* shift_power_k_xy;
 } mh_verifier_key;
-int mh_marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, const uint64_t* public_input_mont,
+int mh_marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, int pc, const uint64_t* public_input_mont,
                      size_t n_public, const uint8_t* flat_proof, size_t proof_len, int* ok_out);
 /* prod_i e(P_i, Q_i) == 1 (ark_ec PairingEngine::product_of_pairings followed by the comparison), host only;
- * n affine G1 points (12 limbs each) and n affine G2 points (24 limbs each), none of them the identity. */
+ * n affine G1 points (2 * fq_limbs64 limbs each) and n affine G2 points (4 * fq_limbs64 limbs each), none of them the
+ * identity; G2 points are taken to be in the order-r subgroup. */
 int mh_pairing_product_is_one(const uint64_t* g1_xy_mont, const uint64_t* g2_xy_mont, size_t n, int* is_one_out);
 
 /* Multi-GPU (one process per GPU): shard every MSM of mh_marlin_prove by points over `world` ranks.  The

@@ -56,7 +56,7 @@ SYMBOLS = {
                                   C.POINTER(C.c_size_t)]),
     "mh_marlin_prove_dev": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_size_t)]),
-    "mh_marlin_verify": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "mh_marlin_verify": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "mh_pairing_product_is_one": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "mh_marlin_proof_serialize": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mh_marlin_proof_deserialize": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

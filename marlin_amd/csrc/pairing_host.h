@@ -1,23 +1,35 @@
-// BLS12-381 pairing on the host, for the product's verifier (verify_host.h): what ark-ec's `Bls12::product_of_pairings`
-// decides inside `kzg10::check` under `Marlin::verify` -> `PC::check_combinations` (/root/reference src/lib.rs:413-423)
-// [ark-ec / ark-poly-commit 0.3, third-party, UPSTREAM-RECALLED].  Not on the prover's hot path and written for clarity,
-// not speed (a verification is two products of two pairings: ~0.2 s here, milliseconds in arkworks):
+// Pairing on the host for the product's verifier (verify_host.h): what ark-ec's `E::product_of_pairings` decides inside
+// `kzg10::check` / sonic_pc's `check_elems` under `Marlin::verify` -> `PC::check_combinations` (/root/reference
+// src/lib.rs:413-423) [ark-ec / ark-poly-commit 0.3, third-party, UPSTREAM-RECALLED].  Not on the prover's hot path and
+// written for clarity, not speed (a verification is two products of two or three pairings: ~0.2 s here, milliseconds in
+// arkworks).  One tower shape serves both build-time curves: with xi = A + u the sextic non-residue of Fq2 = Fq[u]/(u^2+1),
 //
-//   Fq12 = Fq[w] / (w^12 - 2 w^6 + 2)          (u = w^6 - 1 satisfies u^2 = -1; Fq2 = Fq[u] embeds as a + b u)
-//   G2   = E'(Fq2): y^2 = x^3 + 4 (1 + u)     (M-type twist), untwisted by (x, y) -> (x / w^2, y / w^3)
-//   e(P, Q) = f_{|x|, Q}(P) ^ ((p^12 - 1) / r)  with affine lines; T stays on the twist, so every slope is an Fq2
-//   division and a line evaluated at P is  -y_P + (m x_P) w^-1 + (y_T - m x_T) w^-3
+//   Fq12 = Fq[w] / (w^12 - 2A w^6 + A^2 + 1)    (w^6 = xi, so u = w^6 - A; Fq2 embeds as a + b u)
 //
-// The same bilinear map, in the same representation, as oracle/pairing.py (whose Miller loop carries T in E(Fq12)): the
-// tests compare the two coefficient by coefficient.  Any non-degenerate bilinear map decides the KZG equation alike.
+//   BLS12-381: A = 1; G2 = E'(Fq2): y^2 = x^3 + 4 xi (M-type twist), untwisted by (x, y) -> (x / w^2, y / w^3);
+//              e(P, Q) = f_{|x|, Q}(P) ^ ((p^12 - 1) / r); a line with slope m through T, evaluated at P, is
+//              -y_P + (m x_P) w^-1 + (y_T - m x_T) w^-3
+//   BN254:     A = 9; G2 = E'(Fq2): y^2 = x^3 + 3 / xi (D-type twist), untwisted by (x, y) -> (x w^2, y w^3);
+//              e(P, Q) = f_{t-1, Q}(P) ^ ((p^12 - 1) / r) with t - 1 = 6 x^2 -- the plain ate pairing (ark-ec's `Bn` runs
+//              the shorter optimal-ate loop 6x + 2 plus two Frobenius steps); the line is y_P - (m x_P) w + (m x_T - y_T) w^3
+//
+// T stays on the twist, so every slope is one Fq2 division.  Any non-degenerate bilinear map G1 x G2 -> mu_r decides the
+// KZG equation alike; the tests pin bilinearity, non-degeneracy and the decisions of oracle/pairing.py, which evaluates
+// the same maps with T carried in E(Fq12).
 #pragma once
 #include "host_ff.h"
 
-#ifndef MH_CURVE_BN254
 namespace hostpair {
 using hostff::HFq;
 using hostff::HG1Affine;
 #include "pairing_consts.inc"
+#ifdef MH_CURVE_BN254
+constexpr uint64_t XI_A = 9;
+constexpr bool TWIST_M = false;
+#else
+constexpr uint64_t XI_A = 1;
+constexpr bool TWIST_M = true;
+#endif
 
 struct F2 { HFq a, b; };       // a + b u
 inline F2 f2_add(const F2& x, const F2& y) { return {x.a + y.a, x.b + y.b}; }
@@ -33,11 +45,17 @@ inline F2 f2_inv(const F2& x) {
 }
 
 struct G2Aff { F2 x, y; bool inf; };
+inline const F2& g2_curve_b() {                       // b xi (M-type) or b / xi (D-type)
+  static const F2 v = [] {
+    const F2 xi{HFq::from_u64(XI_A), HFq::one()};
+    const F2 b{HFq::from_u64(hostff::G1_B), HFq::zero()};
+    return TWIST_M ? f2_mul(b, xi) : f2_mul(b, f2_inv(xi));
+  }();
+  return v;
+}
 inline bool g2_on_curve(const G2Aff& p) {
   if (p.inf) return true;
-  const HFq four = HFq::from_u64(4);
-  const F2 rhs = f2_add(f2_mul(f2_mul(p.x, p.x), p.x), F2{four, four});
-  return f2_eq(f2_mul(p.y, p.y), rhs);
+  return f2_eq(f2_mul(p.y, p.y), f2_add(f2_mul(f2_mul(p.x, p.x), p.x), g2_curve_b()));
 }
 // p + q on the twist; *slope receives the slope of the chord / tangent (undefined when the sum is the identity)
 inline G2Aff g2_add(const G2Aff& p, const G2Aff& q, F2* slope = nullptr) {
@@ -77,24 +95,32 @@ inline F12 f12_mul(const F12& a, const F12& b) {
     if (a.c[i].is_zero()) continue;
     for (int j = 0; j < 12; j++) t[i + j] = t[i + j] + a.c[i] * b.c[j];
   }
-  for (int k = 22; k >= 12; k--) {                 // w^12 = 2 w^6 - 2
-    const HFq v2 = t[k].dbl();
-    t[k - 6] = t[k - 6] + v2;
-    t[k - 12] = t[k - 12] - v2;
+  static const HFq red6 = HFq::from_u64(2 * XI_A), red0 = HFq::from_u64(XI_A * XI_A + 1);
+  for (int k = 22; k >= 12; k--) {                 // w^12 = 2A w^6 - (A^2 + 1)
+    if (t[k].is_zero()) continue;
+    t[k - 6] = t[k - 6] + red6 * t[k];
+    t[k - 12] = t[k - 12] - red0 * t[k];
   }
   F12 r;
   for (int i = 0; i < 12; i++) r.c[i] = t[i];
   return r;
 }
-inline F12 f12_from_f2(const F2& x) {                // a + b u with u = w^6 - 1
+inline F12 f12_from_f2(const F2& x, int shift = 0) {   // (a + b u) w^shift with u = w^6 - A, shift < 6
+  static const HFq A = HFq::from_u64(XI_A);
   F12 r = f12_zero();
-  r.c[0] = x.a - x.b;
-  r.c[6] = x.b;
+  r.c[shift] = x.a - A * x.b;
+  r.c[6 + shift] = x.b;
   return r;
 }
-// w^-1 = (2 w^5 - w^11) / 2  (from w (w^11 - 2 w^5) = -2)
+// w^-1 = (2A w^5 - w^11) / (A^2 + 1)  (from w (w^11 - 2A w^5) = -(A^2 + 1))
 inline const F12& f12_winv() {
-  static const F12 v = [] { F12 r = f12_zero(); r.c[5] = HFq::one(); r.c[11] = HFq::from_u64(2).inv().neg(); return r; }();
+  static const F12 v = [] {
+    const HFq d = HFq::from_u64(XI_A * XI_A + 1).inv();
+    F12 r = f12_zero();
+    r.c[5] = HFq::from_u64(2 * XI_A) * d;
+    r.c[11] = d.neg();
+    return r;
+  }();
   return v;
 }
 inline const F12& f12_w3inv() {
@@ -103,25 +129,33 @@ inline const F12& f12_w3inv() {
 }
 // the line with slope m through T (both on the twist), evaluated at P in E(Fq)
 inline F12 line_at(const F2& m, const G2Aff& T, const HG1Affine& P) {
+  if (!TWIST_M) {                                  // y_P - (m x_P) w + (m x_T - y_T) w^3
+    F12 r = f12_from_f2(f2_neg(f2_scale(m, P.x)), 1);
+    const F12 c3 = f12_from_f2(f2_sub(f2_mul(m, T.x), T.y), 3);
+    for (int i = 0; i < 12; i++) r.c[i] = r.c[i] + c3.c[i];
+    r.c[0] = r.c[0] + P.y;
+    return r;
+  }
   F12 r = f12_mul(f12_from_f2(f2_scale(m, P.x)), f12_winv());
   const F12 c3 = f12_mul(f12_from_f2(f2_sub(T.y, f2_mul(m, T.x))), f12_w3inv());
   for (int i = 0; i < 12; i++) r.c[i] = r.c[i] + c3.c[i];
   r.c[0] = r.c[0] - P.y;
   return r;
 }
-// f_{|x|, Q}(P); 1 when either argument is the identity
+// f_{loop, Q}(P); 1 when either argument is the identity
 inline F12 miller_loop(const HG1Affine& P, const G2Aff& Q) {
   if (P.inf || Q.inf) return f12_one();
   G2Aff T = Q;
   F12 f = f12_one();
-  int top = 63;
-  while (!((BLS12_381_ATE_LOOP >> top) & 1)) top--;
+  auto bit = [](int i) { return (PAIRING_ATE_LOOP[i / 64] >> (i % 64)) & 1; };
+  int top = 64 * PAIRING_ATE_LOOP_LIMBS - 1;
+  while (!bit(top)) top--;
   for (int i = top - 1; i >= 0; i--) {
     F2 m;
     const G2Aff T2 = g2_add(T, T, &m);
     f = f12_mul(f12_mul(f, f), line_at(m, T, P));
     T = T2;
-    if ((BLS12_381_ATE_LOOP >> i) & 1) {
+    if (bit(i)) {
       const G2Aff T3 = g2_add(T, Q, &m);
       f = f12_mul(f, line_at(m, T, P));
       T = T3;
@@ -132,13 +166,14 @@ inline F12 miller_loop(const HG1Affine& P, const G2Aff& Q) {
 inline F12 final_exponentiation(const F12& f) {
   F12 acc = f12_one();
   bool started = false;
-  for (int i = BLS12_381_FINAL_EXP_LIMBS - 1; i >= 0; i--)
+  for (int i = PAIRING_FINAL_EXP_LIMBS - 1; i >= 0; i--)
     for (int b = 63; b >= 0; b--) {
       if (started) acc = f12_mul(acc, acc);
-      if ((BLS12_381_FINAL_EXP[i] >> b) & 1) { acc = started ? f12_mul(acc, f) : f; started = true; }
+      if ((PAIRING_FINAL_EXP[i] >> b) & 1) { acc = started ? f12_mul(acc, f) : f; started = true; }
     }
   return acc;
 }
+inline bool g2_in_subgroup(const G2Aff& p) { return g2_on_curve(p) && g2_mul(p, PAIRING_GROUP_ORDER, PAIRING_GROUP_ORDER_LIMBS).inf; }
 inline F12 pairing(const HG1Affine& P, const G2Aff& Q) { return final_exponentiation(miller_loop(P, Q)); }
 // prod_i e(P_i, Q_i) == 1 with one shared final exponentiation (ark-ec product_of_pairings)
 inline bool pairing_product_is_one(const HG1Affine* Ps, const G2Aff* Qs, size_t n) {
@@ -148,4 +183,3 @@ inline bool pairing_product_is_one(const HG1Affine* Ps, const G2Aff* Qs, size_t 
 }
 
 }  // namespace hostpair
-#endif

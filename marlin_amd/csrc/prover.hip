@@ -554,7 +554,6 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
 }
 
 // ---- verifier (host only; verify_host.h, pairing_host.h) -----------------------------------------------------
-#ifndef MH_CURVE_BN254
 static bool load_g1(const uint64_t* p, hostff::HG1Affine* out) {
   memcpy(out->x.v, p, FQ_B); memcpy(out->y.v, p + FQ_L, FQ_B); out->inf = false;
   return !HFq::geq_mod(out->x.v) && !HFq::geq_mod(out->y.v) && hostverify::g1_on_curve(*out);
@@ -562,20 +561,25 @@ static bool load_g1(const uint64_t* p, hostff::HG1Affine* out) {
 static bool load_g2(const uint64_t* p, hostpair::G2Aff* out) {
   memcpy(out->x.a.v, p, FQ_B); memcpy(out->x.b.v, p + FQ_L, FQ_B); memcpy(out->y.a.v, p + 2 * FQ_L, FQ_B); memcpy(out->y.b.v, p + 3 * FQ_L, FQ_B);
   out->inf = false;
+  for (const HFq* f : {&out->x.a, &out->x.b, &out->y.a, &out->y.b}) if (HFq::geq_mod(f->v)) return false;
   return hostpair::g2_on_curve(*out);
 }
-#endif
-int mh_marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, const uint64_t* public_input, size_t n_public,
+int mh_marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, int pc, const uint64_t* public_input, size_t n_public,
                      const uint8_t* flat_proof, size_t proof_len, int* ok_out) {
-#ifdef MH_CURVE_BN254
-  (void)vk_bytes; (void)vk_len; (void)vk; (void)public_input; (void)n_public; (void)flat_proof; (void)proof_len; (void)ok_out;
-  return fail(MH_EINVAL, "mh_marlin_verify: the pairing is built for BLS12-381 only");
-#else
   if (!vk_bytes || !vk || !flat_proof || !ok_out || (!public_input && n_public)) return fail(MH_EINVAL, "mh_marlin_verify: null pointer");
+  if (pc != 0 && pc != 1) return fail(MH_EINVAL, "mh_marlin_verify: pc must be 0 (MarlinKZG10) or 1 (SonicKZG10)");
+  if (!vk->g_xy || !vk->gamma_g_xy || !vk->h_xy || !vk->beta_h_xy || !vk->shift_power_h_xy || !vk->shift_power_k_xy)
+    return fail(MH_EINVAL, "mh_marlin_verify: null verifier-key element");
   hostverify::VerifierKey k;
-  if (!load_g1(vk->g_xy, &k.g) || !load_g1(vk->gamma_g_xy, &k.gamma_g) || !load_g1(vk->shift_power_h_xy, &k.shift_h) ||
-      !load_g1(vk->shift_power_k_xy, &k.shift_k) || !load_g2(vk->h_xy, &k.h) || !load_g2(vk->beta_h_xy, &k.beta_h))
-    return fail(MH_EINVAL, "mh_marlin_verify: a verifier-key element is not on its curve");
+  k.pc = pc;
+  bool ok_key = load_g1(vk->g_xy, &k.g) && load_g1(vk->gamma_g_xy, &k.gamma_g) && load_g2(vk->h_xy, &k.h) && load_g2(vk->beta_h_xy, &k.beta_h);
+  if (pc == 0) ok_key = ok_key && load_g1(vk->shift_power_h_xy, &k.shift_h) && load_g1(vk->shift_power_k_xy, &k.shift_k);
+  else ok_key = ok_key && load_g2(vk->shift_power_h_xy, &k.neg_h) && load_g2(vk->shift_power_k_xy, &k.neg_k);
+  if (!ok_key) return fail(MH_EINVAL, "mh_marlin_verify: a verifier-key element is not on its curve");
+  // G2 has a cofactor on both curves: the pairing is only defined on the order-r subgroup (ark-serialize checks this when a key is read)
+  if (!hostpair::g2_in_subgroup(k.h) || !hostpair::g2_in_subgroup(k.beta_h) ||
+      (pc == 1 && (!hostpair::g2_in_subgroup(k.neg_h) || !hostpair::g2_in_subgroup(k.neg_k))))
+    return fail(MH_EINVAL, "mh_marlin_verify: a G2 element of the verifier key is outside the order-r subgroup");
   std::vector<HFr> pub(n_public);
   for (size_t i = 0; i < n_public; i++) {
     memcpy(pub[i].v, public_input + 4 * i, 32);
@@ -586,13 +590,8 @@ int mh_marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_k
   if (hostverify::marlin_verify(vk_bytes, vk_len, k, pub, flat_proof, proof_len, &ok, &err) != 0) return fail(MH_EINVAL, "mh_marlin_verify: " + err);
   *ok_out = ok ? 1 : 0;
   return MH_OK;
-#endif
 }
 int mh_pairing_product_is_one(const uint64_t* g1_xy, const uint64_t* g2_xy, size_t n, int* is_one_out) {
-#ifdef MH_CURVE_BN254
-  (void)g1_xy; (void)g2_xy; (void)n; (void)is_one_out;
-  return fail(MH_EINVAL, "mh_pairing_product_is_one: the pairing is built for BLS12-381 only");
-#else
   if ((!g1_xy || !g2_xy) && n) return fail(MH_EINVAL, "mh_pairing_product_is_one: null pointer");
   if (!is_one_out) return fail(MH_EINVAL, "mh_pairing_product_is_one: null pointer");
   std::vector<hostff::HG1Affine> ps(n);
@@ -601,7 +600,6 @@ int mh_pairing_product_is_one(const uint64_t* g1_xy, const uint64_t* g2_xy, size
     if (!load_g1(g1_xy + AFF_L * i, &ps[i]) || !load_g2(g2_xy + 4 * FQ_L * i, &qs[i])) return fail(MH_EINVAL, "mh_pairing_product_is_one: point not on its curve");
   *is_one_out = hostpair::pairing_product_is_one(ps.data(), qs.data(), n) ? 1 : 0;
   return MH_OK;
-#endif
 }
 
 // ---- wire format (host only; wire_host.h) ------------------------------------------------------------------

@@ -1,20 +1,23 @@
 // Marlin::verify on the host (no GPU involved): /root/reference src/lib.rs:315-433 for
-// Marlin<Fr, MarlinKZG10<Bls12_381>, SimpleHashFiatShamirRng<Blake2s, ChaChaRng>>.
+// Marlin<Fr, PC, SimpleHashFiatShamirRng<Blake2s, ChaChaRng>> with PC = MarlinKZG10<E> or SonicKZG10<E>, E the build-time
+// curve (BLS12-381 or BN254).
 //
 // Replays the Fiat-Shamir transcript (lib.rs:335-383), builds the query set and the linear combinations
 // (src/ahp/verifier.rs:103-188, src/ahp/mod.rs:110-221), and decides `PC::check_combinations` (lib.rs:413-423) the way
-// ark-poly-commit 0.3's marlin_pc does [third-party, UPSTREAM-RECALLED; SURVEY.md Appendix B-4]: per query point the LC
-// commitments are combined with the opening-challenge powers -- one power per LC and one more per degree-bounded LC,
-// whose shifted commitment enters as shifted_comm - [value] shift_power -- and the KZG10 equation
-//     e(C - [v] G - [random_v] gamma_G,  H)  ==  e(W,  beta_H - [z] H)
-// is checked with the pairing of pairing_host.h.  Same steps as oracle/marlin.py `verify(use_pairing=True)`; the verifier
-// key material (g, gamma_g, h, beta_h and the two shift powers) is what kzg10::VerifierKey / marlin_pc::VerifierKey hold.
+// ark-poly-commit 0.3 does [third-party, UPSTREAM-RECALLED; SURVEY.md Appendix B-4, B-5]:
+//   marlin_pc: per query point the LC commitments are combined with the opening-challenge powers -- one power per LC and
+//     one more per degree-bounded LC, whose shifted commitment enters as shifted_comm - [value] shift_power -- and
+//         e(C - [v] G - [random_v] gamma_G,  H)  ==  e(W,  beta_H - [z] H)
+//   sonic_pc: one power per LC; a degree-bounded commitment is a commitment against the powers shifted by D - d, so the
+//     combination is kept per degree bound and each bounded part is paired with [beta^-(D - d)] H (`check_elems`):
+//         e(C_unbounded - [v] G - [random_v] gamma_G, H) * prod_d e(C_d, [beta^-(D-d)] H)  ==  e(W,  beta_H - [z] H)
+// with the pairing of pairing_host.h.  Same steps as oracle/marlin.py `verify(use_pairing=True)`; the verifier key material
+// is what kzg10::VerifierKey / marlin_pc::VerifierKey / sonic_pc::VerifierKey hold.
 #pragma once
 #include <vector>
 #include "fs_host.h"
 #include "pairing_host.h"
 
-#ifndef MH_CURVE_BN254
 namespace hostverify {
 using hostff::HFq; using hostff::HFr; using hostff::HG1; using hostff::HG1Affine;
 using hostpair::G2Aff; using hostpair::F2;
@@ -22,7 +25,9 @@ using hostpair::G2Aff; using hostpair::F2;
 struct VerifierKey {
   HG1Affine g, gamma_g;
   G2Aff h, beta_h;
-  HG1Affine shift_h, shift_k;        // powers_of_g[max_degree - (|H| - 2)], powers_of_g[max_degree - (|K| - 2)]
+  int pc = 0;                        // 0 MarlinKZG10, 1 SonicKZG10
+  HG1Affine shift_h, shift_k;        // marlin_pc: powers_of_g[max_degree - (|H| - 2)], powers_of_g[max_degree - (|K| - 2)]
+  G2Aff neg_h, neg_k;                // sonic_pc: [beta^-(max_degree - (|H| - 2))] H, [beta^-(max_degree - (|K| - 2))] H
 };
 
 inline bool read_fq(const uint8_t* p, HFq* out) {
@@ -49,8 +54,7 @@ inline bool read_g1(const uint8_t* p, HG1Affine* out) {
   if (out->inf) { out->x = HFq::zero(); out->y = HFq::zero(); return true; }
   return read_fq(p, &out->x) && read_fq(p + hostff::FQ_B, &out->y) && g1_on_curve(*out);
 }
-constexpr size_t G1_TB = 2 * hostff::FQ_B + 1;       // 97
-constexpr size_t COMM_TB = 2 * G1_TB + 1;            // marlin_pc::Commitment: comm || has_shifted || shifted = 195
+constexpr size_t G1_TB = 2 * hostff::FQ_B + 1;       // 97 (BLS12-381) / 65 (BN254)
 
 inline HFr pow_u64(HFr b, uint64_t e) { return b.pow_u64(e); }
 inline uint64_t next_pow2(uint64_t n) { uint64_t p = 1; while (p < n) p <<= 1; return p; }
@@ -74,8 +78,11 @@ inline G2Aff g2_mul_fr(const G2Aff& a, const HFr& k) {
 inline int marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const VerifierKey& vk, const std::vector<HFr>& public_input,
                          const uint8_t* proof, size_t proof_len, bool* ok, std::string* err) {
   *ok = false;
-  if (vk_len != 24 + 6 * COMM_TB) { *err = "verifier key bytes: expected index_info + 6 MarlinKZG10 commitments"; return -1; }
-  if (proof_len != 9 * COMM_TB + 4 * 32 + 2 * (G1_TB + 1 + 32)) { *err = "proof: not a flat MarlinKZG10 proof"; return -1; }
+  const bool sonic = vk.pc == 1;
+  // marlin_pc::Commitment: comm || has_shifted || shifted (195 / 131 bytes); sonic_pc: a bare kzg10::Commitment
+  const size_t COMM_TB = sonic ? G1_TB : 2 * G1_TB + 1;
+  if (vk_len != 24 + 6 * COMM_TB) { *err = "verifier key bytes: expected index_info + 6 commitments of this scheme"; return -1; }
+  if (proof_len != 9 * COMM_TB + 4 * 32 + 2 * (G1_TB + 1 + 32)) { *err = "proof: not a flat proof of this scheme"; return -1; }
   uint64_t info[3];
   memcpy(info, vk_bytes, 24);
   const uint64_t num_constraints = info[1], num_non_zero = info[2];
@@ -84,6 +91,8 @@ inline int marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const VerifierK
   struct Comm { HG1Affine comm; bool has_shifted; HG1Affine shifted; };
   auto read_comm = [&](const uint8_t* p, Comm* c) {
     if (!read_g1(p, &c->comm)) return false;
+    c->has_shifted = false;
+    if (sonic) return true;
     c->has_shifted = p[G1_TB] != 0;
     return read_g1(p + G1_TB + 1, &c->shifted);
   };
@@ -170,7 +179,9 @@ inline int marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const VerifierK
   for (int k = 0; k < 2; k++) {
     const LC* lcs = k == 0 ? at_beta : at_gamma;
     const int nl = k == 0 ? 4 : 2;
-    HG1 combined = HG1::identity();
+    HG1 combined = HG1::identity();                      // unbounded part (everything, for marlin_pc)
+    HG1 combined_bounded = HG1::identity();              // sonic_pc: the part committed against the shifted powers
+    int bound_of_point = -1;
     HFr value = zero;
     HFr ch = one;                                        // xi^counter
     for (int l = 0; l < nl; l++) {
@@ -181,10 +192,15 @@ inline int marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const VerifierK
         else lc_comm = lc_comm.add(g1_mul(cm[t.poly].comm, t.c));
       }
       const HFr claimed = lcs[l].claimed - constant;     // constant terms move to the evaluation side
-      combined = combined.add(jac_mul(lc_comm, ch));
+      if (sonic && lcs[l].bounded >= 0) {
+        combined_bounded = combined_bounded.add(jac_mul(lc_comm, ch));
+        bound_of_point = lcs[l].bounded;
+      } else {
+        combined = combined.add(jac_mul(lc_comm, ch));
+      }
       value = value + claimed * ch;
       ch = ch * xi;
-      if (lcs[l].bounded >= 0) {
+      if (!sonic && lcs[l].bounded >= 0) {
         const Comm& c = cm[lcs[l].bounded];
         if (!c.has_shifted) { *err = "degree-bounded commitment without a shifted part"; return -1; }
         const HG1Affine& sp = lcs[l].bounded == G_1 ? vk.shift_h : vk.shift_k;
@@ -196,13 +212,12 @@ inline int marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const VerifierK
     HG1 lhs = combined.add(g1_mul(vk.g, value).neg());
     if (op[k].has_rv) lhs = lhs.add(g1_mul(vk.gamma_g, op[k].rv).neg());
     const G2Aff inner_g2 = hostpair::g2_add(vk.beta_h, hostpair::g2_neg(g2_mul_fr(vk.h, points[k])));
-    HG1Affine pa[2] = {lhs.to_affine(), HG1::from_affine(op[k].w).neg().to_affine()};
-    G2Aff qa[2] = {vk.h, inner_g2};
-    all = hostpair::pairing_product_is_one(pa, qa, 2) && all;
+    HG1Affine pa[3] = {lhs.to_affine(), HG1::from_affine(op[k].w).neg().to_affine(), combined_bounded.to_affine()};
+    G2Aff qa[3] = {vk.h, inner_g2, bound_of_point == G_1 ? vk.neg_h : vk.neg_k};
+    all = hostpair::pairing_product_is_one(pa, qa, sonic && bound_of_point >= 0 ? 3 : 2) && all;
   }
   *ok = all;
   return 0;
 }
 
 }  // namespace hostverify
-#endif

@@ -45,20 +45,27 @@ class UniversalSRS:
         self.powers_of_gamma_g = Bases.srs_powers(fr_mont(self.tau), self.max_degree + 2 if full_gamma else 3,
                                                   scale_mont=fr_mont(self.gamma))
 
-    def verifier_key(self, pk, h_xy_mont):
-        """The group elements of the trimmed verifier key (MarlinKZG10::trim under Marlin::index, src/lib.rs:101-148) for
-        `verify`: g, gamma_g, h, beta_h = [tau]h (KZG10::setup's G2 side, on the device), and the shift powers
-        powers_of_g[max_degree - bound] for the two enforced degree bounds |H| - 2 and |K| - 2."""
+    def verifier_key(self, pk, h_xy_mont, pc="marlin"):
+        """The group elements of the trimmed verifier key (PC::trim under Marlin::index, src/lib.rs:101-148) for `verify`:
+        g, gamma_g, h, beta_h = [tau]h (KZG10::setup's G2 side, on the device), and for the two enforced degree bounds
+        |H| - 2 and |K| - 2 the shift powers -- MarlinKZG10: powers_of_g[max_degree - bound]; SonicKZG10:
+        [tau^-(max_degree - bound)]h (neg_powers_of_h)."""
         from .api import G2Bases
-        beta_h = G2Bases.srs_powers(h_xy_mont, fr_mont(self.tau), 1, first=1)
-        try:
-            bh = beta_h.download()[0]
-        finally:
-            beta_h.free()
+
+        def g2_power(scale):
+            b = G2Bases.srs_powers(h_xy_mont, fr_mont(self.tau), 1, scale_mont=fr_mont(scale))
+            try:
+                return b.download()[0]
+            finally:
+                b.free()
+        shifts = [self.max_degree - (pk.H - 2), self.max_degree - (pk.K - 2)]
+        if pc == "sonic":
+            tinv = pow(self.tau, -1, R_MOD)
+            sp = [g2_power(pow(tinv, d, R_MOD)) for d in shifts]
+        else:
+            sp = [self.powers_of_g.download(d, 1)[0] for d in shifts]
         return [self.powers_of_g.download(0, 1)[0], self.powers_of_gamma_g.download(0, 1)[0],
-                np.ascontiguousarray(h_xy_mont, dtype=np.uint64).reshape(-1), bh,
-                self.powers_of_g.download(self.max_degree - (pk.H - 2), 1)[0],
-                self.powers_of_g.download(self.max_degree - (pk.K - 2), 1)[0]]
+                np.ascontiguousarray(h_xy_mont, dtype=np.uint64).reshape(-1), g2_power(self.tau)] + sp
 
 
 def universal_setup(num_constraints, num_variables, num_non_zero, tau, gamma, pc="marlin"):
@@ -167,23 +174,25 @@ class _VerifierKeyC(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g_xy", "gamma_g_xy", "h_xy", "beta_h_xy", "shift_power_h_xy", "shift_power_k_xy")]
 
 
-def verify(vk_bytes, g_xy, gamma_g_xy, h_xy, beta_h_xy, shift_power_h_xy, shift_power_k_xy, public_input_mont, flat_proof):
-    """Marlin::verify (src/lib.rs:315-433), MarlinKZG10 on BLS12-381, on the host (mh_marlin_verify): True = accept.
-    Group elements: affine Montgomery limbs as uint64 arrays (G1: 12, G2: 24); public_input_mont: (n, 4) uint64 (the
-    unformatted input)."""
+def verify(vk_bytes, g_xy, gamma_g_xy, h_xy, beta_h_xy, shift_power_h_xy, shift_power_k_xy, public_input_mont, flat_proof, pc="marlin"):
+    """Marlin::verify (src/lib.rs:315-433) on the host (mh_marlin_verify), MarlinKZG10 or SonicKZG10 on the library's curve:
+    True = accept.  Group elements: affine Montgomery limbs as uint64 arrays (G1: 2 * FQ_LIMBS, G2: 4 * FQ_LIMBS); the two
+    shift powers are G1 points for pc="marlin" and G2 points ([beta^-(max_degree - bound)]h) for pc="sonic";
+    public_input_mont: (n, 4) uint64 (the unformatted input)."""
     arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (g_xy, gamma_g_xy, h_xy, beta_h_xy, shift_power_h_xy, shift_power_k_xy)]
     vk = _VerifierKeyC(*[a.ctypes.data for a in arrs])
     pub = np.ascontiguousarray(public_input_mont, dtype=np.uint64).reshape(-1, 4)
     ok = C.c_int(0)
-    _lib.check(_lib.load().mh_marlin_verify(bytes(vk_bytes), len(vk_bytes), C.byref(vk), pub.ctypes.data, pub.shape[0],
-                                            bytes(flat_proof), len(flat_proof), C.byref(ok)), "mh_marlin_verify")
+    _lib.check(_lib.load().mh_marlin_verify(bytes(vk_bytes), len(vk_bytes), C.byref(vk), {"marlin": 0, "sonic": 1}[pc], pub.ctypes.data,
+                                            pub.shape[0], bytes(flat_proof), len(flat_proof), C.byref(ok)), "mh_marlin_verify")
     return bool(ok.value)
 
 
 def pairing_product_is_one(g1_xy_mont, g2_xy_mont):
-    """prod_i e(P_i, Q_i) == 1 on the host (mh_pairing_product_is_one); (n, 12) and (n, 24) uint64 arrays."""
-    a = np.ascontiguousarray(g1_xy_mont, dtype=np.uint64).reshape(-1, 12)
-    b = np.ascontiguousarray(g2_xy_mont, dtype=np.uint64).reshape(-1, 24)
+    """prod_i e(P_i, Q_i) == 1 on the host (mh_pairing_product_is_one); (n, 2 FQ_LIMBS) and (n, 4 FQ_LIMBS) uint64 arrays."""
+    _lib.load()
+    a = np.ascontiguousarray(g1_xy_mont, dtype=np.uint64).reshape(-1, 2 * _lib.FQ_LIMBS)
+    b = np.ascontiguousarray(g2_xy_mont, dtype=np.uint64).reshape(-1, 4 * _lib.FQ_LIMBS)
     assert a.shape[0] == b.shape[0]
     ok = C.c_int(0)
     _lib.check(_lib.load().mh_pairing_product_is_one(a.ctypes.data, b.ctypes.data, a.shape[0], C.byref(ok)), "mh_pairing_product_is_one")

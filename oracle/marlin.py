@@ -313,10 +313,12 @@ def proof_bytes(pr):
 
 def verify(pk, public_input, pr, use_pairing=False):
     """src/lib.rs:315-433.  PC::check_combinations' KZG10 equation e(C - [v]G - [rv]gamma_G, H) == e(W, beta_H - [z]H)
-    [ark-poly-commit 0.3 kzg10::check, UPSTREAM-RECALLED] is decided either with the real BLS12-381 pairing
-    (use_pairing=True: oracle/pairing.py, H = the G2 generator, beta_H = [tau]H -- what a verifier without tau does;
-    MarlinKZG10 only) or with the known-tau identity C - [v]G - [rv]gamma_G == [tau - z]W that the pairing equation
-    is equivalent to (default: O(1) group operations, any curve, both PC schemes)."""
+    [ark-poly-commit 0.3 kzg10::check, UPSTREAM-RECALLED] is decided either with the real pairing of the curve
+    (use_pairing=True: oracle/pairing.py, H = the G2 generator, beta_H = [tau]H -- what a verifier without tau does)
+    or with the known-tau identity C - [v]G - [rv]gamma_G == [tau - z]W that the pairing equation
+    is equivalent to (default: O(1) group operations, any curve, both PC schemes).  With use_pairing and SonicKZG10 the
+    degree-bounded part of the combination is paired with [tau^-(max_degree - d)]H (sonic_pc `check_elems`
+    [UPSTREAM-RECALLED, SURVEY B-5]) instead of being unshifted with tau."""
     idx, srs = pk.index, pk.srs
     pub = list(public_input)
     full = [1] + pub
@@ -350,6 +352,7 @@ def verify(pk, public_input, pr, use_pairing=False):
     for k, (pl, point) in enumerate((("beta", beta), ("gamma", gamma))):
         lbls = sorted(l for l, p, _ in qs if p == pl)
         combined, value = None, 0
+        bounded_part, bounded_shift = None, None          # SonicKZG10 + pairing: the part committed against shifted powers
         ctr = 0
         for l in lbls:
             lc = lcs[l]
@@ -359,16 +362,25 @@ def verify(pk, public_input, pr, use_pairing=False):
             claimed = (claimed - const) % R
             lc_comm = None
             sonic = getattr(pk, "pc", "marlin") == "sonic"
+            in_g2 = None
             for c, t in lc:
                 if t is not None:
                     cm = comms[t][0]
                     if sonic and t in bounds:
                         # a degree-bounded Sonic commitment is [p(tau) tau^(max_degree - d)]G (hiding part shifted alike);
-                        # the pairing check divides the shift out with the G2 element, here with tau itself
-                        cm = EC.scalar_mul(cm, pow(srs.tau, -(srs.max_degree - bounds[t]), R))
+                        # the pairing check divides the shift out with the G2 element, the known-tau check with tau itself
+                        if use_pairing:
+                            assert len(lc) == 1
+                            in_g2 = srs.max_degree - bounds[t]
+                        else:
+                            cm = EC.scalar_mul(cm, pow(srs.tau, -(srs.max_degree - bounds[t]), R))
                     lc_comm = EC.add(lc_comm, EC.scalar_mul(cm, c))
             ch = pow(xi, ctr, R); ctr += 1
-            combined = EC.add(combined, EC.scalar_mul(lc_comm, ch))
+            if in_g2 is not None:
+                assert bounded_shift in (None, in_g2)
+                bounded_part, bounded_shift = EC.add(bounded_part, EC.scalar_mul(lc_comm, ch)), in_g2
+            else:
+                combined = EC.add(combined, EC.scalar_mul(lc_comm, ch))
             value = (value + claimed * ch) % R
             if not sonic and len(lc) == 1 and lc[0][1] in bounds:
                 t = lc[0][1]
@@ -382,11 +394,13 @@ def verify(pk, public_input, pr, use_pairing=False):
             lhs = EC.add(lhs, EC.neg(EC.scalar_mul(srs.gamma_g, rv)))
         if use_pairing:
             from . import pairing as PR
-            assert not sonic, "pairing verification is implemented for MarlinKZG10 (SonicKZG10's bound check needs G2 powers)"
             h = PR.G2_GEN
             beta_h = PR.g2_mul(h, srs.tau)                       # vk.beta_h of KZG10::setup
             inner = PR.g2_add(beta_h, PR.g2_neg(PR.g2_mul(h, point)))
-            ok = ok and PR.pairing_product_is_one([(lhs, h), (EC.neg(w), inner)])
+            pairs = [(lhs, h), (EC.neg(w), inner)]
+            if bounded_part is not None:                         # vk.degree_bounds_and_neg_powers_of_h of sonic_pc
+                pairs.append((bounded_part, PR.g2_mul(h, pow(srs.tau, -bounded_shift, R))))
+            ok = ok and PR.pairing_product_is_one(pairs)
         else:
             rhs = EC.scalar_mul(w, (srs.tau - point) % R)
             ok = ok and (lhs == rhs)

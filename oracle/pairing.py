@@ -1,4 +1,4 @@
-"""BLS12-381 pairing for the oracle's verifier (test infrastructure; pure Python ints, slow and obviously structured).
+"""BLS12-381 / BN254 pairing for the oracle's verifier (test infrastructure; pure Python ints, slow and obviously structured).
 
 `Marlin::verify` ends in `PC::check_combinations` (/root/reference src/lib.rs:413-423), which for MarlinKZG10 /
 SonicKZG10 is the KZG10 pairing equation of ark-poly-commit 0.3 `kzg10::check` (third-party, absent here; restated
@@ -16,13 +16,28 @@ final exponentiation (p^12 - 1) / r).  This file evaluates the same bilinear map
 Any non-degenerate bilinear map decides the KZG equation identically, so the sign convention of x (arkworks conjugates
 because x < 0) is immaterial for a verifier; what is pinned here is bilinearity and non-degeneracy
 (tests/test_oracle_pairing.py: e([a]P, [b]Q) = e(P, Q)^(ab), e(P, Q) != 1, e(P, Q)^r = 1).
+
+With ORACLE_CURVE=bn254 (BASELINE configs[4]) the same code evaluates the ate pairing of BN254:
+
+    Fq12 = Fq[w] / (w^12 - 18 w^6 + 82)          (u = w^6 - 9, xi = 9 + u = w^6)
+    G2   = E'(Fq2): y^2 = x^3 + 3 / xi  (D-type twist), untwisted by (x, y) -> (x w^2, y w^3)
+    e(P, Q) = f_{t-1, Q}(P) ^ ((p^12 - 1) / r),  t - 1 = 6 x^2, x = 4965661367192848881
+
+(ark-ec's `Bn::pairing` runs the shorter optimal-ate loop 6x + 2 with two Frobenius line steps; both are non-degenerate
+bilinear maps G1 x G2 -> mu_r, which is all the KZG check uses.)
 """
 from .fields import Q_MOD as P, R_MOD as R, CURVE
 
-assert CURVE == "bls12_381", "oracle/pairing.py implements the BLS12-381 pairing only"
-
-ATE_LOOP_COUNT = 0xd201000000010000
-FQ12_MOD = [2, 0, 0, 0, 0, 0, -2, 0, 0, 0, 0, 0]       # w^12 = 2 w^6 - 2  (low -> high coefficients of the reduction)
+if CURVE == "bls12_381":
+    ATE_LOOP_COUNT = 0xd201000000010000
+    XI_A = 1                                           # xi = XI_A + u
+    TWIST_M = True
+else:
+    ATE_LOOP_COUNT = 6 * 4965661367192848881 ** 2      # t - 1
+    XI_A = 9
+    TWIST_M = False
+# w^6 = xi = XI_A + u and u^2 = -1  =>  (w^6 - XI_A)^2 = -1  =>  w^12 = 2 XI_A w^6 - (XI_A^2 + 1)
+_RED6, _RED0 = 2 * XI_A, XI_A * XI_A + 1
 
 
 # ---- Fq12 as polynomials of degree < 12 over Fq ------------------------------------------------------------------
@@ -57,12 +72,12 @@ def f12_mul(a, b):
         if x:
             for j, y in enumerate(b):
                 t[i + j] += x * y
-    # reduce: w^12 = 2 w^6 - 2
+    # reduce: w^12 = _RED6 w^6 - _RED0
     for k in range(22, 11, -1):
         v = t[k]
         if v:
-            t[k - 6] += 2 * v
-            t[k - 12] -= 2 * v
+            t[k - 6] += _RED6 * v
+            t[k - 12] -= _RED0 * v
     return tuple(x % P for x in t[:12])
 
 
@@ -91,9 +106,9 @@ def _poly_rounded_div(a, b):
 
 
 def f12_inv(a):
-    """extended Euclid over Fq[w] against the modulus w^12 - 2 w^6 + 2"""
+    """extended Euclid over Fq[w] against the modulus w^12 - _RED6 w^6 + _RED0"""
     lm, hm = [1] + [0] * 12, [0] * 13
-    low, high = list(a) + [0], [2, 0, 0, 0, 0, 0, (-2) % P, 0, 0, 0, 0, 0, 1]
+    low, high = list(a) + [0], [_RED0, 0, 0, 0, 0, 0, (-_RED6) % P, 0, 0, 0, 0, 0, 1]
     while _poly_deg(low):
         r = _poly_rounded_div(high, low)
         r += [0] * (13 - len(r))
@@ -118,8 +133,8 @@ def f12_pow(a, e):
 
 
 def f12_from_fq2(c0, c1):
-    """a + b u with u = w^6 - 1"""
-    return f12([(c0 - c1) % P, 0, 0, 0, 0, 0, c1 % P])
+    """a + b u with u = w^6 - XI_A"""
+    return f12([(c0 - XI_A * c1) % P, 0, 0, 0, 0, 0, c1 % P])
 
 
 # ---- Fq2 and G2 arithmetic on the twist: oracle/g2.py ---------------------------------------------------------------
@@ -129,13 +144,15 @@ from .g2 import (f2_add, f2_sub, f2_neg, f2_mul, f2_scale, f2_inv, F2_ZERO, F2_O
 
 # ---- the pairing ----------------------------------------------------------------------------------------------------
 _W = f12([0, 1])
-_W2_INV = f12_inv(f12_mul(_W, _W))
-_W3_INV = f12_inv(f12_mul(f12_mul(_W, _W), _W))
+_W2, _W3 = f12_mul(_W, _W), f12_mul(f12_mul(_W, _W), _W)
+_W2_INV, _W3_INV = f12_inv(_W2), f12_inv(_W3)
 
 
 def _untwist(q):
     (x0, x1), (y0, y1) = q
-    return (f12_mul(f12_from_fq2(x0, x1), _W2_INV), f12_mul(f12_from_fq2(y0, y1), _W3_INV))
+    if TWIST_M:
+        return (f12_mul(f12_from_fq2(x0, x1), _W2_INV), f12_mul(f12_from_fq2(y0, y1), _W3_INV))
+    return (f12_mul(f12_from_fq2(x0, x1), _W2), f12_mul(f12_from_fq2(y0, y1), _W3))
 
 
 def _e12_double(p):

@@ -29,7 +29,8 @@ pub struct mh_r1cs_matrices {
     pub val: [*const u64; 3],
 }
 
-/// `mh_verifier_key` (marlin_hip.h): the group elements of kzg10::VerifierKey / marlin_pc::VerifierKey.
+/// `mh_verifier_key` (marlin_hip.h): the group elements of kzg10::VerifierKey and marlin_pc:: / sonic_pc::VerifierKey
+/// (the two shift powers are G1 points for MarlinKZG10, G2 points for SonicKZG10).
 #[repr(C)]
 pub struct mh_verifier_key {
     pub g_xy: *const u64,
@@ -106,7 +107,7 @@ extern "C" {
                            zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_prove_dev(pk: u64, d_instance_mont: *const c_void, d_witness_mont: *const c_void, zk_seed32: *const u8,
                                zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
-    pub fn mh_marlin_verify(vk_bytes: *const u8, vk_len: usize, vk: *const mh_verifier_key, public_input_mont: *const u64, n_public: usize,
+    pub fn mh_marlin_verify(vk_bytes: *const u8, vk_len: usize, vk: *const mh_verifier_key, pc: c_int, public_input_mont: *const u64, n_public: usize,
                             flat_proof: *const u8, proof_len: usize, ok_out: *mut c_int) -> c_int;
     pub fn mh_pairing_product_is_one(g1_xy_mont: *const u64, g2_xy_mont: *const u64, n: usize, is_one_out: *mut c_int) -> c_int;
     pub fn mh_marlin_proof_serialize(flat_proof: *const u8, flat_len: usize, pc: c_int, out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;

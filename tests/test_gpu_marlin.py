@@ -112,30 +112,30 @@ def test_full_size_proof_verifies(gpu, log_n):
     assert GM.prove(pk, inst, wit, SEED) == proof                    # deterministic given the zk seed
 
 
-@pytest.mark.skipif(F.CURVE != "bls12_381", reason="the host pairing is built for BLS12-381")
-@pytest.mark.parametrize("log_n", [10, 16])
-def test_device_proof_passes_the_products_own_verifier(gpu, log_n):
+@pytest.mark.parametrize("log_n,pc", [(10, "marlin"), (16, "marlin"), (12, "sonic")])
+def test_device_proof_passes_the_products_own_verifier(gpu, log_n, pc):
     """prove on the device -> Marlin::verify on the host with the real pairing (mh_marlin_verify), no tau on the verifier's
-    side: accepts; a wrong public input and a tampered evaluation are rejected (src/test.rs:158-161).  The oracle only
-    supplies a G2 point for h (any point of G2 will do: kzg10::setup draws it at random)."""
+    side, both PC schemes, on the curve of this process: accepts; a wrong public input and a tampered evaluation are
+    rejected (src/test.rs:158-161).  The oracle only supplies a G2 point for h (any point of G2 will do: kzg10::setup
+    draws it at random)."""
     from oracle import g2 as G2
     from tests.util import fr_to_np, fq_to_limbs
     import numpy as np
     rng = FS.test_rng()
     a, b = FS.fr_rand(rng), FS.fr_rand(rng)
     n = 1 << log_n
-    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA)
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc=pc)
     ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
-    pk = GM.index(srs, ncp, ni, mats)
+    pk = GM.index(srs, ncp, ni, mats, pc=pc)
     proof = GM.prove(pk, inst, wit, SEED)
     h = G2.g2_mul(G2.G2_GEN, 0x5eed)
     h_np = np.array(sum([fq_to_limbs(c) for c in (h[0][0], h[0][1], h[1][0], h[1][1])], []), dtype=np.uint64)
-    els = srs.verifier_key(pk, h_np)
+    els = srs.verifier_key(pk, h_np, pc=pc)
     c = a * b % F.R_MOD
-    assert GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), proof)
-    assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([a]), proof)
+    assert GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), proof, pc=pc)
+    assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([a]), proof, pc=pc)
     bad = bytearray(proof); bad[len(proof) - 2 * (2 * F.FQ_BYTES + 34) - 128 + 3] ^= 1
-    assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), bytes(bad))
+    assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), bytes(bad), pc=pc)
 
 
 SHARD_WORKER = r'''
