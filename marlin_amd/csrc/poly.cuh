@@ -148,6 +148,48 @@ __global__ __launch_bounds__(TPB) void spmv_kernel(Fr* __restrict__ out, const u
   ff_store(out + r, acc);
 }
 
+// arithmetize_matrix (constraint_systems.rs:125-262), one thread per entry k < |K| of the joint matrix (indexer.rs:83-102):
+// entry k sits at (row r, column i) of the union of A, B, C; with the domain elements h_r = omega^r and
+// c = omega^reindex(i) (the columns are reindexed by the input subdomain, constraint_systems.rs:150-163; the matrices are
+// transposed, so the "row" polynomial interpolates the column element),
+//     row(k) = c,  col(k) = h_r,  row_col(k) = c h_r,  val_M(k) = M[r][i] c / |H|
+// (u_H(c, c)^-1 = c / |H| because c^|H| = 1).  Repeated entries of a row are summed; k >= nnz pads with omega^0 and 0.
+// val == nullptr: all coefficients are one.
+struct ArithMat { const u64* row_ptr; const u32* col; const Fr* val; };
+__device__ __forceinline__ u64 reindex_by_subdomain_dev(u64 H, u64 X, u64 index) {
+  const u64 period = H / X;
+  if (index < X) return index * period;
+  const u64 i = index - X, x = period - 1;
+  return i + (i / x) + 1;
+}
+__global__ __launch_bounds__(TPB) void arithmetize_kernel(Fr* __restrict__ row_v, Fr* __restrict__ col_v, Fr* __restrict__ rc_v,
+                                                          Fr* __restrict__ va, Fr* __restrict__ vb, Fr* __restrict__ vc,
+                                                          const u32* __restrict__ jrow, const u32* __restrict__ jcol, u64 nnz, u64 K,
+                                                          ArithMat A, ArithMat B, ArithMat C, FrArg omega, FrArg h_inv, u64 H, u64 X) {
+  const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  Fr* vals[3] = {va, vb, vc};
+  if (k >= nnz) {
+    ff_store(row_v + k, Fr::one()); ff_store(col_v + k, Fr::one()); ff_store(rc_v + k, Fr::one());
+    for (int q = 0; q < 3; q++) ff_store(vals[q] + k, Fr::zero());
+    return;
+  }
+  const u32 r = jrow[k], i = jcol[k];
+  const Fr c = ff_pow(omega.v, reindex_by_subdomain_dev(H, X, i));
+  const Fr hr = ff_pow(omega.v, (u64)r);
+  ff_store(row_v + k, c);
+  ff_store(col_v + k, hr);
+  ff_store(rc_v + k, ff_mul(c, hr));
+  const Fr scale = ff_mul(c, h_inv.v);
+  const ArithMat mats[3] = {A, B, C};
+  for (int q = 0; q < 3; q++) {
+    Fr acc = Fr::zero();
+    for (u64 e = mats[q].row_ptr[r]; e < mats[q].row_ptr[r + 1]; e++)
+      if (mats[q].col[e] == i) acc = ff_add(acc, mats[q].val ? ff_load(mats[q].val + e) : Fr::one());
+    ff_store(vals[q] + k, ff_mul(acc, scale));
+  }
+}
+
 // p[0] -= r, p[n] = r: adds r * (X^n - 1) to a polynomial with n coefficients (the hiding term r * v_H of
 // prover.rs:352,360,366) without a host round trip
 __global__ void blind_vanishing_kernel(Fr* __restrict__ p, u64 n, FrArg r) {

@@ -666,6 +666,17 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     }
   }
 
+  // MH_TRACE_INDEX=1: wall time of every phase of the indexer on stderr
+  struct PhaseTrace {
+    bool on; std::chrono::steady_clock::time_point t0;
+    PhaseTrace() : on(getenv("MH_TRACE_INDEX") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+      if (!on) return;
+      auto t1 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[mh_marlin_index] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+      t0 = t1;
+    }
+  } trace;
   std::unique_ptr<ProverKey> pkp(new ProverKey());
   ProverKey& pk = *pkp;
   pk.nc = nc; pk.ni = ni; pk.pc = pc;
@@ -676,20 +687,25 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     for (int i = 0; i < 3; i++) { memcpy(pk.gamma_g[i].x.v, gg + AFF_L * i, FQ_B); memcpy(pk.gamma_g[i].y.v, gg + AFF_L * i + FQ_L, FQ_B); pk.gamma_g[i].inf = false; }
   }
   // ---- joint matrix (indexer.rs:83-102): per row, sorted union of the column sets --------------------
-  std::vector<uint64_t> jptr(nc + 1, 0);
-  std::vector<uint32_t> jcol;
-  for (uint64_t r = 0; r < nc; r++) {
+  std::vector<uint32_t> jcol, jrow;
+  {
+    const uint64_t total = m->row_ptr[0][nc] + m->row_ptr[1][nc] + m->row_ptr[2][nc];
+    jcol.reserve(total); jrow.reserve(total);
     std::vector<uint32_t> cols;
-    for (int k = 0; k < 3; k++)
-      for (uint64_t e = m->row_ptr[k][r]; e < m->row_ptr[k][r + 1]; e++) {
-        if (m->col[k][e] >= nc) return fail(MH_EINVAL, "mh_marlin_index: column index out of range (NonSquareMatrix)");
-        cols.push_back(m->col[k][e]);
-      }
-    std::sort(cols.begin(), cols.end());
-    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-    jcol.insert(jcol.end(), cols.begin(), cols.end());
-    jptr[r + 1] = jcol.size();
+    for (uint64_t r = 0; r < nc; r++) {
+      cols.clear();
+      for (int k = 0; k < 3; k++)
+        for (uint64_t e = m->row_ptr[k][r]; e < m->row_ptr[k][r + 1]; e++) {
+          if (m->col[k][e] >= nc) return fail(MH_EINVAL, "mh_marlin_index: column index out of range (NonSquareMatrix)");
+          cols.push_back(m->col[k][e]);
+        }
+      std::sort(cols.begin(), cols.end());
+      cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+      jcol.insert(jcol.end(), cols.begin(), cols.end());
+      jrow.insert(jrow.end(), cols.size(), (uint32_t)r);
+    }
   }
+  trace.mark("joint matrix (host)");
   pk.nnz = jcol.size();
   pk.H = np2(nc); pk.K = np2(pk.nnz); pk.X = ni;
   pk.logH = log2u(pk.H); pk.logK = log2u(pk.K); pk.logX = log2u(pk.X);
@@ -712,56 +728,41 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     MH_TRY(fetch(pk.srs_max_degree - (K - 2), pk.gamma_g_k));
   }
 
-  // ---- arithmetize_matrix (constraint_systems.rs:125-262) on the host ---------------------------------
-  // val_M(k) = M[r][i] * u_H(col_val, col_val)^-1 = M[r][i] * col_val / |H|   (col_val^|H| = 1)
-  std::vector<HFr> elems(H);
+  // ---- matrices on the device: CSR A, B stay for z_A, z_B (prover.rs:256-276); C only serves the arithmetisation ----
+  Csr* cs[2] = {&pk.A, &pk.B};
+  Csr csC;
+  for (int q = 0; q < 3; q++) {
+    Csr* d = q < 2 ? cs[q] : &csC;
+    uint64_t nz = m->row_ptr[q][nc];
+    d->nnz = nz;
+    MH_TRY(d->row_ptr.alloc((nc + 1) * 8)); MH_TRY(h2d(c, d->row_ptr.p, m->row_ptr[q], (nc + 1) * 8));
+    MH_TRY(d->col.alloc(std::max<uint64_t>(nz, 1) * 4)); MH_TRY(h2d(c, d->col.p, m->col[q], nz * 4));
+    d->has_val = m->val[q] != nullptr;
+    if (d->has_val) { MH_TRY(d->val.alloc(std::max<uint64_t>(nz, 1) * 32)); MH_TRY(h2d(c, d->val.p, m->val[q], nz * 32)); }
+  }
+  // ---- arithmetize_matrix (constraint_systems.rs:125-262): one device thread per entry of the joint matrix --------
+  DBuf* evs[6] = {&pk.ev_row, &pk.ev_col, &pk.ev_val_a, &pk.ev_val_b, &pk.ev_val_c, &pk.ev_row_col};
+  DBuf* pls[6] = {&pk.p_row, &pk.p_col, &pk.p_a_val, &pk.p_b_val, &pk.p_c_val, &pk.p_row_col};   // INDEXER_POLYNOMIALS order
   {
     HFr w = hostff::fr_two_adic_root();
     for (uint32_t i = pk.logH; i < hostff::FR_TWO_ADICITY_H; i++) w = w.sqr();
-    HFr x = HFr::one();
-    for (uint64_t i = 0; i < H; i++) { elems[i] = x; x = x * w; }
+    const HFr h_inv = HFr::from_u64(H).inv();
+    DBuf d_jrow, d_jcol;
+    MH_TRY(d_jrow.alloc(std::max<uint64_t>(pk.nnz, 1) * 4)); MH_TRY(d_jcol.alloc(std::max<uint64_t>(pk.nnz, 1) * 4));
+    MH_TRY(h2d(c, d_jrow.p, jrow.data(), pk.nnz * 4)); MH_TRY(h2d(c, d_jcol.p, jcol.data(), pk.nnz * 4));
+    for (int q = 0; q < 6; q++) { MH_TRY(evs[q]->alloc(K * 32)); MH_TRY(pls[q]->alloc(K * 32)); }
+    auto mat = [](const Csr& s) { return poly::ArithMat{(const u64*)s.row_ptr.p, (const u32*)s.col.p, s.has_val ? (const Fr*)s.val.p : nullptr}; };
+    KLAUNCH(poly::arithmetize_kernel, K, pk.ev_row.fr(), pk.ev_col.fr(), pk.ev_row_col.fr(), pk.ev_val_a.fr(), pk.ev_val_b.fr(), pk.ev_val_c.fr(),
+            (const u32*)d_jrow.p, (const u32*)d_jcol.p, (u64)pk.nnz, (u64)K, mat(pk.A), mat(pk.B), mat(csC), arg(w), arg(h_inv), (u64)H, (u64)X);
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipStreamSynchronize(c.stream));
+    d_jrow.release(); d_jcol.release();
+    csC.row_ptr.release(); csC.col.release(); csC.val.release();
   }
-  const HFr h_inv = HFr::from_u64(H).inv();
-  std::vector<uint64_t> row_v(K * 4), col_v(K * 4), rc_v(K * 4), va(K * 4, 0), vb(K * 4, 0), vc(K * 4, 0);
-  {
-    uint64_t k = 0;
-    std::vector<uint64_t>* vals[3] = {&va, &vb, &vc};
-    for (uint64_t r = 0; r < nc; r++) {
-      uint64_t pos[3] = {m->row_ptr[0][r], m->row_ptr[1][r], m->row_ptr[2][r]};
-      for (uint64_t e = jptr[r]; e < jptr[r + 1]; e++, k++) {
-        uint32_t i = jcol[e];
-        const HFr& col_val = elems[reindex_by_subdomain(H, X, i)];
-        const HFr& row_val = elems[r];
-        memcpy(&row_v[4 * k], col_val.v, 32);       // transpose: row <- column element
-        memcpy(&col_v[4 * k], row_val.v, 32);
-        HFr rc = col_val * row_val;
-        memcpy(&rc_v[4 * k], rc.v, 32);
-        HFr scale = col_val * h_inv;
-        for (int q = 0; q < 3; q++) {
-          // entries of a row may be unsorted / repeated: sum all entries of matrix q at (r, i)
-          HFr acc = HFr::zero(); bool any = false;
-          for (uint64_t ee = m->row_ptr[q][r]; ee < m->row_ptr[q][r + 1]; ee++)
-            if (m->col[q][ee] == i) {
-              HFr v = HFr::one();
-              if (m->val[q]) memcpy(v.v, m->val[q] + 4 * ee, 32);
-              acc = acc + v; any = true;
-            }
-          (void)pos;
-          if (any) { HFr v = acc * scale; memcpy(&(*vals[q])[4 * k], v.v, 32); }
-        }
-      }
-    }
-    HFr e0sq = elems[0] * elems[0];
-    for (; k < K; k++) { memcpy(&row_v[4 * k], elems[0].v, 32); memcpy(&col_v[4 * k], elems[0].v, 32); memcpy(&rc_v[4 * k], e0sq.v, 32); }
-  }
-  DBuf* evs[6] = {&pk.ev_row, &pk.ev_col, &pk.ev_val_a, &pk.ev_val_b, &pk.ev_val_c, &pk.ev_row_col};
-  DBuf* pls[6] = {&pk.p_row, &pk.p_col, &pk.p_a_val, &pk.p_b_val, &pk.p_c_val, &pk.p_row_col};   // INDEXER_POLYNOMIALS order
-  std::vector<uint64_t>* hv[6] = {&row_v, &col_v, &va, &vb, &vc, &rc_v};
-  for (int q = 0; q < 6; q++) {
-    MH_TRY(evs[q]->alloc(K * 32)); MH_TRY(pls[q]->alloc(K * 32));
-    MH_TRY(h2d(c, evs[q]->p, hv[q]->data(), K * 32));
-    MH_TRY(ntt_device(c, evs[q]->p, pls[q]->p, pk.logK, 1));          // interpolate (constraint_systems.rs:234-239)
-  }
+  trace.mark("arithmetize_matrix (device)");
+  for (int q = 0; q < 6; q++) MH_TRY(ntt_device(c, evs[q]->p, pls[q]->p, pk.logK, 1));   // interpolate (constraint_systems.rs:234-239)
+  if (trace.on) hipStreamSynchronize(c.stream);
+  trace.mark("6 interpolations");
   // ---- the same six polynomials on the coset g K: the third round evaluates h_2 there (see mh_marlin_prove) ------
   {
     HFr g = HFr::from_u64(7);
@@ -792,28 +793,25 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     tmp.release();
   }
   MH_HIP(hipStreamSynchronize(c.stream));
+  trace.mark("6 coset evaluations");
   // ---- index commitments: PC::commit(ck, index.iter(), None) (lib.rs:123-126) ----------------------------
   pk.index_comms.resize(6);
-  for (int q = 0; q < 6; q++) {
-    uint64_t xyz[XYZ_L];
-    MH_TRY(msm_device(c, sg->second.d_points, pls[q]->p, 1, K, xyz));
-    pk.index_comms[q].comm = jac_from(xyz).to_affine();
-    pk.index_comms[q].has_shifted = false;
+  {
+    // one batch: the six MSMs share the sort / accumulate / reduce launches (never sharded: every rank indexes in full)
+    const void* b6[6]; const void* s6[6]; size_t n6[6];
+    for (int q = 0; q < 6; q++) { b6[q] = sg->second.d_points; s6[q] = pls[q]->p; n6[q] = K; }
+    uint64_t xyz[6 * XYZ_L];
+    MH_TRY(msm_batch_device(c, 6, b6, s6, n6, 1, xyz));
+    HG1 jac[6]; HG1Affine aff[6];
+    for (int q = 0; q < 6; q++) jac[q] = jac_from(xyz + XYZ_L * q);
+    hostff::batch_to_affine(jac, 6, aff);
+    for (int q = 0; q < 6; q++) { pk.index_comms[q].comm = aff[q]; pk.index_comms[q].has_shifted = false; }
   }
+  trace.mark("6 index commitments");
   // IndexVerifierKey::write (data_structures.rs:36-43)
   fsh::put_u64(pk.vk_bytes, nc); fsh::put_u64(pk.vk_bytes, nc); fsh::put_u64(pk.vk_bytes, pk.nnz);
   for (auto& cm : pk.index_comms) put_comm(pk.vk_bytes, cm, pk.pc);
 
-  // ---- matrices on the device: CSR A, B for z_A, z_B (prover.rs:256-276) -------------------------------
-  Csr* cs[2] = {&pk.A, &pk.B};
-  for (int q = 0; q < 2; q++) {
-    uint64_t nz = m->row_ptr[q][nc];
-    cs[q]->nnz = nz;
-    MH_TRY(cs[q]->row_ptr.alloc((nc + 1) * 8)); MH_TRY(h2d(c, cs[q]->row_ptr.p, m->row_ptr[q], (nc + 1) * 8));
-    MH_TRY(cs[q]->col.alloc(nz * 4)); MH_TRY(h2d(c, cs[q]->col.p, m->col[q], nz * 4));
-    cs[q]->has_val = m->val[q] != nullptr;
-    if (cs[q]->has_val) { MH_TRY(cs[q]->val.alloc(nz * 32)); MH_TRY(h2d(c, cs[q]->val.p, m->val[q], nz * 32)); }
-  }
   // ---- calculate_t structure (prover.rs:411-428): entries grouped by output index, then by matrix ----------
   {
     uint64_t total = m->row_ptr[0][nc] + m->row_ptr[1][nc] + m->row_ptr[2][nc];
@@ -861,6 +859,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     MH_TRY(pk.t_group_ptr.alloc(group_ptr.size() * 8)); MH_TRY(h2d(c, pk.t_group_ptr.p, group_ptr.data(), group_ptr.size() * 8));
     MH_HIP(hipStreamSynchronize(c.stream));
   }
+  trace.mark("calculate_t structure (host)");
   // ---- workspace ------------------------------------------------------------------------------------------------
   const uint64_t big = std::max<uint64_t>(2 * K, 4 * H) + 64;
   MH_TRY(pk.z.alloc(H * 32)); MH_TRY(pk.za_ev.alloc(H * 32)); MH_TRY(pk.zb_ev.alloc(H * 32)); MH_TRY(pk.xpoly.alloc((X + 8) * 32));
@@ -872,6 +871,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
   MH_TRY(pk.scal.alloc(256));
   MH_TRY(ensure_twiddles_public(c, std::max(pk.logK + 1, pk.logH + 2)));
   MH_HIP(hipStreamSynchronize(c.stream));
+  trace.mark("workspace + twiddles");
   uint64_t h = g_next_pk++;
   g_pks[h] = std::move(pkp);
   *pk_out = h;
