@@ -138,6 +138,40 @@ def test_device_proof_passes_the_products_own_verifier(gpu, log_n, pc):
     assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), bytes(bad), pc=pc)
 
 
+TOGGLE_WORKER = r'''
+import sys
+sys.path.insert(0, %(root)r)
+import marlin_amd as M
+from marlin_amd import marlin as GM
+M.init(0)
+n = 1 << %(log_n)d
+srs = GM.universal_setup(n, n, 3 * n, %(tau)d, %(gamma)d, pc=%(pc)r)
+nc, ni, mats, inst, wit = GM.dummy_circuit(%(a)d, %(b)d, 10, n)
+pk = GM.index(srs, nc, ni, mats, pc=%(pc)r)
+sys.stdout.write(pk.vk_bytes().hex() + " " + GM.prove(pk, inst, wit, bytes(range(32))).hex())
+'''
+
+
+@pytest.mark.parametrize("env,pc", [({"MH_FB": "0"}, "marlin"), ({"MH_FB": "0"}, "sonic"), ({"MH_NTT": "32"}, "marlin"),
+                                    ({"MH_FB_ALIAS": "0"}, "marlin"), ({"MH_FB_SEG_THREADS": "8192"}, "marlin")],
+                         ids=lambda v: v if isinstance(v, str) else ",".join("%s=%s" % kv for kv in v.items()))
+def test_alternative_paths_give_the_same_bytes(gpu, env, pc):
+    """The paths the library keeps behind switches -- variable-base MSM for every commitment (what serves a key whose window
+    table does not fit), the 32-bit-limb NTT kernel, separate sorts for jobs that share a scalar vector, another
+    segmentation of the bucket reduction -- produce the same index commitments and the same proof, byte for byte."""
+    import subprocess, sys
+    a, b, log_n = 0x1234567, 0x7654321, 13
+    n = 1 << log_n
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc=pc)
+    ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
+    pk = GM.index(srs, ncp, ni, mats, pc=pc)
+    want = pk.vk_bytes().hex() + " " + GM.prove(pk, inst, wit, bytes(range(32))).hex()
+    code = TOGGLE_WORKER % dict(root=ROOT, log_n=log_n, tau=TAU, gamma=GAMMA, a=a, b=b, pc=pc)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() == want
+
+
 SHARD_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
