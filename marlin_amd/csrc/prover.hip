@@ -39,10 +39,17 @@ inline FrArg arg(const HFr& h) { FrArg a; a.v = dfr(h); return a; }
 inline uint32_t log2u(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }
 inline uint64_t np2(uint64_t n) { return 1ull << log2u(n < 1 ? 1 : n); }
 
+// device allocation owned by a prover key or a scope: released on destruction, so that a failing index / prove does not
+// leak what it had allocated so far (at process exit the runtime may already be gone: hipFree's error is ignored)
 struct DBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  DBuf() = default;
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  ~DBuf() { release(); }
   int alloc(size_t b) {
+    release();
     if (b == 0) b = 32;
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) { p = nullptr; return fail(MH_ENOMEM, "hipMalloc failed in prover key allocation"); }
@@ -93,7 +100,9 @@ struct ProverKey {
   }
 };
 
-std::map<uint64_t, std::unique_ptr<ProverKey>> g_pks;
+// never destroyed: at process exit the HIP runtime may be torn down before this library's statics, and a key's buffers
+// must not be hipFree'd then (mh_shutdown / mh_marlin_pk_free release keys while the runtime is alive)
+std::map<uint64_t, std::unique_ptr<ProverKey>>& g_pks = *new std::map<uint64_t, std::unique_ptr<ProverKey>>();
 uint64_t g_next_pk = 1;
 
 // ---- small launch helpers ------------------------------------------------------------------
