@@ -94,6 +94,13 @@ int mh_ntt_coset_dev(int field, const void* d_in, void* d_out, uint32_t log_n, i
  * that is not on the curve -- which rejects (0, 0) / (0, 1) encodings of the identity instead of multiplying them. */
 int mh_bases_upload(int curve, const uint64_t* xy_mont, size_t n, uint64_t* handle_out);
 int mh_bases_from_dev(int curve, const void* d_xy_mont, size_t n, uint64_t* handle_out); /* adopts a copy */
+/* Upload bases from their ark-serialize 0.3 image (what `Vec<G1Affine>` / kzg10::UniversalParams::powers_of_g look like
+ * in a serialized SRS; replaces `CanonicalDeserialize for GroupAffine` on the way to Marlin::index, src/lib.rs:101-113):
+ * n items back to back, WITHOUT the Vec's u64 length prefix.  compressed != 0: FQ bytes per point (x little-endian, bit 7
+ * of the last byte = "y > -y", bit 6 = infinity); compressed == 0: `serialize_uncompressed`, x || y.  Decoded and
+ * validated on the device (square root per point); any item that is not a finite point of the curve fails the call with
+ * MH_EINVAL (SerializationError::InvalidData) -- the identity included, base sets carry no infinity flag. */
+int mh_bases_upload_serialized(int curve, const uint8_t* bytes, size_t n, int compressed, uint64_t* handle_out);
 /* KZG10::setup's fixed-base powers for a known-tau (test/bench) SRS:
  * bases[i] = [scale * tau^(first + i)]G, i < n, generated on the device (reference:
  * Marlin::universal_setup -> PC::setup, src/lib.rs:79-96).  `first` lets each GPU of a

@@ -33,6 +33,7 @@ SYMBOLS = {
     "mh_ntt_coset": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_ntt_coset_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_bases_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
+    "mh_bases_upload_serialized": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]),
     "mh_bases_from_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
     "mh_srs_powers": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, _u64p]),
     "mh_bases_download": (C.c_int, [C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p]),

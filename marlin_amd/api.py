@@ -134,6 +134,19 @@ class Bases:
         self.n = a.shape[0]
 
     @classmethod
+    def from_serialized(cls, data, n, compressed=True):
+        """n points in ark-serialize 0.3's image (`Vec<G1Affine>` without its length prefix; compressed: x with the sign /
+        infinity flags, uncompressed: x || y), decoded and validated on the device (mh_bases_upload_serialized)."""
+        data = bytes(data)
+        item = (1 if compressed else 2) * 8 * _fql()
+        assert len(data) == n * item, "expected %d bytes, got %d" % (n * item, len(data))
+        h = C.c_uint64()
+        _lib.check(_L().mh_bases_upload_serialized(_curve_id(), data, n, 1 if compressed else 0, C.byref(h)), "mh_bases_upload_serialized")
+        self = cls.__new__(cls)
+        self.handle, self.n = h.value, int(n)
+        return self
+
+    @classmethod
     def srs_powers(cls, tau_mont, n, scale_mont=None, first=0):
         """[scale * tau^(first+i)]G for i < n, generated on the device (KZG10::setup's powers_of_g).
         tau_mont / scale_mont: (4,) uint64 Montgomery Fr; scale defaults to one."""

@@ -213,6 +213,85 @@ static int bases_validate(Context& c, const void* d_points, size_t n) {
   return MH_OK;
 }
 
+// ---- ark-serialize 0.3 images of G1 points, decoded on the device -------------------------------------------------
+// A structured reference string arrives as `Vec<G1Affine>` in ark-serialize's format (kzg10::UniversalParams::powers_of_g,
+// what `UniversalSRS::deserialize` reads before `Marlin::index`, /root/reference src/lib.rs:101-113) [ark-serialize /
+// ark-ec 0.3, third-party, UPSTREAM-RECALLED; same rules as wire_host.h and oracle/marlin.py g1_compressed]:
+//   compressed (CanonicalSerialize::serialize):  x as FQ_B little-endian bytes of the canonical value, flags in the two top
+//     bits of the last byte -- bit 7: y > -y (as canonical integers), bit 6: point at infinity;
+//   uncompressed (serialize_uncompressed):       x (no flags) followed by y with the infinity flag in bit 6.
+// One thread per point: canonical -> Montgomery, y = (x^3 + b)^((p + 1) / 4) (p = 3 mod 4 on both curves), the root with
+// the flagged sign; a coordinate >= p, a non-residue, an inconsistent flag or the identity (no infinity on this ABI's
+// base sets) counts as bad.  ~570 field multiplications per point: 3 M points decode in well under 0.1 s, where a host
+// decodes them at tens of microseconds each.
+__device__ __forceinline__ bool fq_canonical_lt_mod(const Fq& a) {
+  u32 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < Fq::N; i++) { const u64 d = (u64)a.v[i] - CurveFqParams::MOD[i] - borrow; borrow = (u32)(d >> 63); }
+  return borrow != 0;
+}
+__device__ __forceinline__ Fq fq_read_le(const uint8_t* p, uint8_t* flags) {
+  Fq a;
+#pragma unroll
+  for (int i = 0; i < Fq::N; i++) a.v[i] = (u32)p[4 * i] | ((u32)p[4 * i + 1] << 8) | ((u32)p[4 * i + 2] << 16) | ((u32)p[4 * i + 3] << 24);
+  *flags = (uint8_t)((a.v[Fq::N - 1] >> 24) & 0xC0u);
+  a.v[Fq::N - 1] &= 0x3fffffffu;
+  return a;
+}
+// y > -y on canonical integers, i.e. y > (p - 1) / 2, i.e. 2 y > p
+__device__ __forceinline__ bool fq_is_positive(const Fq& y_mont) {
+  const Fq y = ff_from_mont(y_mont);
+  u32 carry = 0, borrow = 0;
+#pragma unroll
+  for (int i = 0; i < Fq::N; i++) {
+    const u32 twice = (y.v[i] << 1) | carry;
+    carry = y.v[i] >> 31;
+    const u64 d = (u64)CurveFqParams::MOD[i] - twice - borrow;             // p - 2y
+    borrow = (u32)(d >> 63);
+  }
+  return carry != 0 || borrow != 0;                                        // 2y > p  (2y = p is impossible: p is odd)
+}
+__global__ __launch_bounds__(128) void g1_deserialize_kernel(const uint8_t* __restrict__ bytes, G1Affine* __restrict__ out, u64 n,
+                                                             int compressed, u32* __restrict__ bad) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int FQB = 4 * Fq::N;
+  const uint8_t* p = bytes + i * (u64)(compressed ? FQB : 2 * FQB);
+  uint8_t fx, fy = 0;
+  Fq x = fq_read_le(p, &fx), y = Fq::zero();
+  bool ok = fq_canonical_lt_mod(x);
+  if (compressed) {
+    ok = ok && !(fx & 0x40u);                                              // the identity cannot be a base
+    x = ff_to_mont(x);
+    const Fq rhs = ff_add(ff_mul(ff_sqr(x), x), G1_CURVE_B_MONT());
+    // e = (p + 1) / 4: p = 3 mod 4, so p + 1 does not carry out of the low two bits' word... computed limb-wise
+    u32 e[Fq::N];
+    u32 carry = 1;
+#pragma unroll
+    for (int k = 0; k < Fq::N; k++) { const u64 t = (u64)CurveFqParams::MOD[k] + carry; e[k] = (u32)t; carry = (u32)(t >> 32); }
+#pragma unroll
+    for (int k = 0; k < Fq::N; k++) e[k] = (e[k] >> 2) | (k + 1 < Fq::N ? e[k + 1] << 30 : carry << 30);
+    Fq acc = Fq::one();
+    for (int k = Fq::N - 1; k >= 0; k--)
+      for (int b = 31; b >= 0; b--) {
+        acc = ff_sqr(acc);
+        if ((e[k] >> b) & 1u) acc = ff_mul(acc, rhs);
+      }
+    y = acc;
+    ok = ok && ff_sqr(y) == rhs;                                           // otherwise x^3 + b is a non-residue
+    if (fq_is_positive(y) != ((fx & 0x80u) != 0)) y = ff_neg(y);
+  } else {
+    ok = ok && fx == 0;
+    y = fq_read_le(p + FQB, &fy);
+    ok = ok && fq_canonical_lt_mod(y) && fy == 0;                          // fy = 0x40 would be the identity
+    x = ff_to_mont(x); y = ff_to_mont(y);
+    ok = ok && ff_sqr(y) == ff_add(ff_mul(ff_sqr(x), x), G1_CURVE_B_MONT());
+  }
+  if (!ok) { atomicAdd(bad, 1u); x = Fq::zero(); y = Fq::zero(); }
+  ff_store(&out[i].x, x);
+  ff_store(&out[i].y, y);
+}
+
 // --------------------------------------------------------------------------------
 // MSM driver
 // --------------------------------------------------------------------------------
@@ -1055,6 +1134,39 @@ int mh_bases_upload(int curve, const uint64_t* xy, size_t n, uint64_t* handle_ou
     MH_HIP(hipStreamSynchronize(c.stream));
     int rc = bases_validate(c, b.d_points, n);
     if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
+  }
+  uint64_t h = c.next_handle++;
+  c.bases[h] = b;
+  *handle_out = h;
+  return MH_OK;
+}
+
+int mh_bases_upload_serialized(int curve, const uint8_t* bytes, size_t n, int compressed, uint64_t* handle_out) {
+  LOCKED_CTX();
+  if (curve != hostff::CURVE_ID) return fail(MH_EINVAL, "unsupported curve");
+  if (!handle_out || (!bytes && n)) return fail(MH_EINVAL, "mh_bases_upload_serialized: null pointer");
+  BaseSet b;
+  b.n = n;
+  if (n) {
+    const size_t item = compressed ? FQ_B : 2 * FQ_B;
+    MH_TRY(c.io.ensure(n * item));
+    MH_TRY(c.tr_sums.ensure(64));
+    u32* d_bad = (u32*)c.tr_sums.ptr;
+    MH_HIP(hipMemcpyAsync(c.io.ptr, bytes, n * item, hipMemcpyHostToDevice, c.stream));
+    MH_HIP(hipMemsetAsync(d_bad, 0, 4, c.stream));
+    MH_HIP(hipMalloc(&b.d_points, n * PT_B));
+    hipLaunchKernelGGL(g1_deserialize_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c.stream, (const uint8_t*)c.io.ptr,
+                       (G1Affine*)b.d_points, (u64)n, compressed ? 1 : 0, d_bad);
+    u32 bad = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    if (e != hipSuccess) { (void)hipFree(b.d_points); return fail(MH_EHIP, std::string("mh_bases_upload_serialized: ") + hipGetErrorString(e)); }
+    if (bad) {
+      (void)hipFree(b.d_points);
+      return fail(MH_EINVAL, "mh_bases_upload_serialized: " + std::to_string(bad) + " point(s) do not decode to a finite point of the curve "
+                             "(SerializationError::InvalidData: coordinate >= p, x^3 + b not a square, bad flags, or the identity)");
+    }
   }
   uint64_t h = c.next_handle++;
   c.bases[h] = b;

@@ -770,7 +770,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
   }
   trace.mark("arithmetize_matrix (device)");
   for (int q = 0; q < 6; q++) MH_TRY(ntt_device(c, evs[q]->p, pls[q]->p, pk.logK, 1));   // interpolate (constraint_systems.rs:234-239)
-  if (trace.on) hipStreamSynchronize(c.stream);
+  if (trace.on) (void)hipStreamSynchronize(c.stream);
   trace.mark("6 interpolations");
   // ---- the same six polynomials on the coset g K: the third round evaluates h_2 there (see mh_marlin_prove) ------
   {

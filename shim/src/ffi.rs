@@ -74,6 +74,7 @@ extern "C" {
     // ---- MSM over G1 (seam B1)
     pub fn mh_bases_upload(curve: c_int, xy_mont: *const u64, n: usize, handle_out: *mut u64) -> c_int;
     pub fn mh_bases_from_dev(curve: c_int, d_xy_mont: *const c_void, n: usize, handle_out: *mut u64) -> c_int;
+    pub fn mh_bases_upload_serialized(curve: c_int, bytes: *const u8, n: usize, compressed: c_int, handle_out: *mut u64) -> c_int;
     pub fn mh_srs_powers(curve: c_int, tau_mont: *const u64, scale_mont: *const u64, first: usize, n: usize, handle_out: *mut u64) -> c_int;
     pub fn mh_bases_download(handle: u64, offset: usize, n: usize, xy_mont_out: *mut u64) -> c_int;
     pub fn mh_bases_free(handle: u64) -> c_int;

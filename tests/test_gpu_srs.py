@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 from oracle import fields as F, curve as EC, poly as OP
-from tests.util import fr_to_np, jac_np_to_affine, rand_fr, limbs_to_fq
+from tests.util import fr_to_np, jac_np_to_affine, rand_fr, limbs_to_fq, points_to_np
 
 pytestmark = pytest.mark.gpu
 TAU = 0x1f3a9c5d7e2b4a6f8091a2b3c4d5e6f708192a3b4c5d6e7f
@@ -94,3 +94,60 @@ def test_fixed_base_commit_full_size(gpu, log_n):
     assert s == vb_full
     fb1, vb1 = gpu.msm_path_counts()
     assert fb1 - fb0 >= 4          # dense, gap and the halves ran on the table (the constant vector is skewed -> fallback)
+
+
+@pytest.mark.parametrize("compressed", [True, False])
+def test_serialized_srs_decodes_on_the_device(gpu, compressed):
+    """`Vec<G1Affine>` in ark-serialize's format (powers_of_g of a serialized SRS) uploaded as bytes and decoded by the
+    device (square root and sign selection per point) equals the points themselves; every way an item can be invalid
+    fails the call (SerializationError::InvalidData)."""
+    from oracle import marlin as MR, fields as F
+    from marlin_amd.api import Bases
+    import marlin_amd as M
+    n = 300
+    pts = EC.srs_powers(0x1f3a9c5d7e2b4a6f, n)                 # both signs of y occur
+    fq = F.FQ_BYTES
+
+    def image(p):
+        if compressed:
+            return MR.g1_compressed(p)
+        return p[0].to_bytes(fq, "little") + p[1].to_bytes(fq, "little")
+    data = b"".join(image(p) for p in pts)
+    if compressed:
+        assert len({b[-1] >> 7 for b in (image(p) for p in pts)}) == 2
+    b = Bases.from_serialized(data, n, compressed)
+    assert (b.download() == points_to_np(pts)).all()
+    # and it multiplies like the same points uploaded as limbs
+    sc = rand_fr(n, 3)
+    d = M.DeviceBuffer.from_numpy(fr_to_np(sc))
+    assert jac_np_to_affine(M.msm_dev(b, d, n)) == EC.msm_naive(pts, sc)
+    b.free()
+    item = len(data) // n
+
+    def corrupt(k, f):
+        t = bytearray(data)
+        t[k * item:(k + 1) * item] = f(bytearray(t[k * item:(k + 1) * item]))
+        return bytes(t)
+    bad = []
+    bad.append(corrupt(7, lambda e: bytearray((F.Q_MOD).to_bytes(fq, "little")) + e[fq:]))          # x = p: not canonical
+    if compressed:
+        bad.append(corrupt(11, lambda e: bytearray(b"\x00" * (fq - 1) + b"\x40")))                   # the identity
+        x = 1
+        while pow((x ** 3 + F.G1_B) % F.Q_MOD, (F.Q_MOD - 1) // 2, F.Q_MOD) == 1:
+            x += 1
+        bad.append(corrupt(13, lambda e: bytearray(x.to_bytes(fq, "little"))))                       # x^3 + b is not a square
+        bad.append(corrupt(17, lambda e: e[:-1] + bytes([e[-1] | 0xC0])))                            # both flags
+    else:
+        bad.append(corrupt(19, lambda e: e[:fq] + bytearray(((int.from_bytes(e[fq:], "little") + 1) % F.Q_MOD).to_bytes(fq, "little"))))   # off the curve
+        bad.append(corrupt(23, lambda e: e[:-1] + bytes([e[-1] | 0x40])))                            # infinity flag on y
+    for t in bad:
+        with pytest.raises(Exception, match="do not decode|InvalidData"):
+            Bases.from_serialized(t, n, compressed)
+    # a flipped sign bit decodes to the negated point, not to an error
+    if compressed:
+        t = corrupt(5, lambda e: e[:-1] + bytes([e[-1] ^ 0x80]))
+        b = Bases.from_serialized(t, n, True)
+        got = b.download()
+        want = points_to_np(pts[:5] + [EC.neg(pts[5])] + pts[6:])
+        assert (got == want).all()
+        b.free()
