@@ -675,17 +675,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     }
   }
 
-  // MH_TRACE_INDEX=1: wall time of every phase of the indexer on stderr
-  struct PhaseTrace {
-    bool on; std::chrono::steady_clock::time_point t0;
-    PhaseTrace() : on(getenv("MH_TRACE_INDEX") != nullptr), t0(std::chrono::steady_clock::now()) {}
-    void mark(const char* what) {
-      if (!on) return;
-      auto t1 = std::chrono::steady_clock::now();
-      fprintf(stderr, "[mh_marlin_index] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-      t0 = t1;
-    }
-  } trace;
+  Trace trace(c);                              // MH_TRACE=1: wall time of every phase on stderr (labels: SURVEY.md Appendix F)
   std::unique_ptr<ProverKey> pkp(new ProverKey());
   ProverKey& pk = *pkp;
   pk.nc = nc; pk.ni = ni; pk.pc = pc;
@@ -714,7 +704,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
       jrow.insert(jrow.end(), cols.size(), (uint32_t)r);
     }
   }
-  trace.mark("joint matrix (host)");
+  trace.mark("Marlin::Index: joint matrix (host)");
   pk.nnz = jcol.size();
   pk.H = np2(nc); pk.K = np2(pk.nnz); pk.X = ni;
   pk.logH = log2u(pk.H); pk.logK = log2u(pk.K); pk.logX = log2u(pk.X);
@@ -768,10 +758,9 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     d_jrow.release(); d_jcol.release();
     csC.row_ptr.release(); csC.col.release(); csC.val.release();
   }
-  trace.mark("arithmetize_matrix (device)");
+  trace.mark("Marlin::Index: arithmetize_matrix x3 (device)");
   for (int q = 0; q < 6; q++) MH_TRY(ntt_device(c, evs[q]->p, pls[q]->p, pk.logK, 1));   // interpolate (constraint_systems.rs:234-239)
-  if (trace.on) (void)hipStreamSynchronize(c.stream);
-  trace.mark("6 interpolations");
+  trace.mark("Marlin::Index: 6 interpolations over K");
   // ---- the same six polynomials on the coset g K: the third round evaluates h_2 there (see mh_marlin_prove) ------
   {
     HFr g = HFr::from_u64(7);
@@ -802,7 +791,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     tmp.release();
   }
   MH_HIP(hipStreamSynchronize(c.stream));
-  trace.mark("6 coset evaluations");
+  trace.mark("Marlin::Index: 6 evaluations on the coset g K");
   // ---- index commitments: PC::commit(ck, index.iter(), None) (lib.rs:123-126) ----------------------------
   pk.index_comms.resize(6);
   {
@@ -816,7 +805,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     hostff::batch_to_affine(jac, 6, aff);
     for (int q = 0; q < 6; q++) { pk.index_comms[q].comm = aff[q]; pk.index_comms[q].has_shifted = false; }
   }
-  trace.mark("6 index commitments");
+  trace.mark("Commit to index polynomials");
   // IndexVerifierKey::write (data_structures.rs:36-43)
   fsh::put_u64(pk.vk_bytes, nc); fsh::put_u64(pk.vk_bytes, nc); fsh::put_u64(pk.vk_bytes, pk.nnz);
   for (auto& cm : pk.index_comms) put_comm(pk.vk_bytes, cm, pk.pc);
@@ -868,7 +857,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
     MH_TRY(pk.t_group_ptr.alloc(group_ptr.size() * 8)); MH_TRY(h2d(c, pk.t_group_ptr.p, group_ptr.data(), group_ptr.size() * 8));
     MH_HIP(hipStreamSynchronize(c.stream));
   }
-  trace.mark("calculate_t structure (host)");
+  trace.mark("Marlin::Index: calculate_t grouping (host)");
   // ---- workspace ------------------------------------------------------------------------------------------------
   const uint64_t big = std::max<uint64_t>(2 * K, 4 * H) + 64;
   MH_TRY(pk.z.alloc(H * 32)); MH_TRY(pk.za_ev.alloc(H * 32)); MH_TRY(pk.zb_ev.alloc(H * 32)); MH_TRY(pk.xpoly.alloc((X + 8) * 32));
@@ -880,7 +869,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
   MH_TRY(pk.scal.alloc(256));
   MH_TRY(ensure_twiddles_public(c, std::max(pk.logK + 1, pk.logH + 2)));
   MH_HIP(hipStreamSynchronize(c.stream));
-  trace.mark("workspace + twiddles");
+  trace.mark("Marlin::Index: workspace + twiddles");
   uint64_t h = g_next_pk++;
   g_pks[h] = std::move(pkp);
   *pk_out = h;
