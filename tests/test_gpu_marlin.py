@@ -134,6 +134,10 @@ def test_device_proof_passes_the_products_own_verifier(gpu, log_n, pc):
     c = a * b % F.R_MOD
     assert GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), proof, pc=pc)
     assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([a]), proof, pc=pc)
+    # through the wire: CanonicalSerialize bytes (compressed points) -> validating deserializer -> verifier
+    wire = GM.proof_serialize(proof, pc)
+    assert len(wire) < len(proof) and GM.proof_deserialize(wire, pc) == proof
+    assert GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), GM.proof_deserialize(wire, pc), pc=pc)
     bad = bytearray(proof); bad[len(proof) - 2 * (2 * F.FQ_BYTES + 34) - 128 + 3] ^= 1
     assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), bytes(bad), pc=pc)
 
