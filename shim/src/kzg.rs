@@ -46,6 +46,23 @@ impl GpuSrs {
     }
 }
 
+impl GpuSrs {
+    /// `mh_bases_upload_serialized`: the SRS as it sits in a file -- `powers_of_g.serialize(..)` /
+    /// `serialize_uncompressed(..)` of ark-serialize 0.3 WITHOUT the `Vec`'s u64 length prefix -- decoded (square root,
+    /// sign flag) and validated on the device instead of by `Vec::<G1Affine>::deserialize` on the host.
+    pub fn upload_serialized(bytes: &[u8], n: usize, compressed: bool, precompute: bool) -> Result<Self, HipError> {
+        ensure_init();
+        let item = if compressed { 48 } else { 96 };
+        assert_eq!(bytes.len(), n * item, "serialized SRS: {} points need {} bytes", n, n * item);
+        let mut handle = 0u64;
+        check(unsafe { ffi::mh_bases_upload_serialized(ffi::MH_CURVE_BLS12_381_G1, bytes.as_ptr(), n, compressed as i32, &mut handle) })?;
+        if precompute && n >= (1 << 14) {
+            check(unsafe { ffi::mh_bases_precompute(handle, 0) })?;
+        }
+        Ok(GpuSrs { handle, len: n })
+    }
+}
+
 impl Drop for GpuSrs {
     fn drop(&mut self) {
         unsafe { ffi::mh_bases_free(self.handle) };
