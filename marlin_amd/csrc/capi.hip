@@ -623,11 +623,12 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   hipError_t e = hipMalloc(&tab, (size_t)W * bs.n * pt30);
   if (e != hipSuccess) return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the window table failed");
   // two standard-form levels ping-pong through scratch while the chain of doublings runs
-  void* tmp = nullptr;
-  e = hipMalloc(&tmp, 2 * bs.n * PT_B);
+  void* tmp = nullptr;                                    // two ping-pong levels in standard form + the un-normalised points of one level
+  e = hipMalloc(&tmp, 2 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd));
   if (e != hipSuccess) { (void)hipFree(tab); return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the doubling scratch failed"); }
+  msmfb::G1XyzzStd* xyzz_scratch = (msmfb::G1XyzzStd*)((char*)tmp + 2 * bs.n * PT_B);
   hipStream_t s = c.stream;
-  const unsigned grid = (unsigned)((bs.n + 127) / 128);
+  const unsigned grid = (unsigned)(((bs.n + msmfb::TAB_BATCH - 1) / msmfb::TAB_BATCH + 127) / 128);
   const G1Affine* prev = (const G1Affine*)bs.d_points;
   // level 0 = [R^-1 mod r] P (see table_level_kernel): R^-1 as a canonical integer is the value whose Montgomery words are 1
   Fr kinv;
@@ -640,7 +641,7 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   for (u32 j = 0; j < W; j++) {
     G1Affine* next_std = (G1Affine*)((char*)tmp + (size_t)(j & 1) * bs.n * PT_B);
     hipLaunchKernelGGL(msmfb::table_level_kernel, dim3(grid), dim3(128), 0, s, prev, next_std,
-                       (msmfb::G1Aff30*)((char*)tab + (size_t)j * bs.n * pt30), (u64)bs.n, j ? (u32)win.bits[j - 1] : 0u, kinv);
+                       (msmfb::G1Aff30*)((char*)tab + (size_t)j * bs.n * pt30), xyzz_scratch, (u64)bs.n, j ? (u32)win.bits[j - 1] : 0u, kinv);
     prev = next_std;
   }
   hipError_t le = hipGetLastError();
