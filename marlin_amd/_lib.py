@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # one library per curve (build-time choice, same ABI); the process picks one with MARLIN_AMD_CURVE
 CURVE = os.environ.get("MARLIN_AMD_CURVE", "bls12_381")
 LIB_PATH = os.path.join(_HERE, {"bls12_381": "libmarlin_hip.so", "bn254": "libmarlin_hip_bn254.so"}[CURVE])
+# A/B measurements of two builds on one box: MARLIN_AMD_LIB=<path to another build of the same ABI>
+LIB_PATH = os.environ.get("MARLIN_AMD_LIB", LIB_PATH)
 
 # every symbol include/marlin_hip.h declares: (restype, argtypes)
 _u64p = C.POINTER(C.c_uint64)
