@@ -335,6 +335,7 @@ def main():
     ntt_ms, ntt_launches = M.prof_get(0)
     msm_ms, _ = M.prof_get(1)
     glue_ms, _ = M.prof_get(3)
+    stages_ms, _ = M.prof_get(4)      # sort + bucket reduction by themselves; they run beside the other half's accumulation
     # pairs the timed launches really process: the prover folds each opening's shifted witness into the witness MSM
     from marlin_amd import workload as W
     msms_run = W.msm_executed(wl.N, pc=args.pc) if workload == "marlin-prove" else wl.msms
@@ -398,7 +399,10 @@ def main():
                    "constraints": wl.N, "curve": "BLS12-381", "pc": "MarlinKZG10",
                    "parallelism": "msm sharded by bucket range x%d (one all_gather of partial points per commit round), AHP rounds replicated" % world},
         "breakdown_ms_per_step": {"ntt": round(ntt_ms / args.steps, 3), "msm": round(msm_ms / args.steps, 3),
-                                  "msm_accum": round(acc_ms / args.steps, 3), "glue": round(glue_ms / args.steps, 3),
+                                  "msm_accum": round(acc_ms / args.steps, 3),
+                                  "msm_sort_and_reduce_stages": round(stages_ms / args.steps, 3),
+                                  "msm_hidden_under_accum": round(max(0.0, acc_ms + stages_ms - msm_ms) / args.steps, 3),
+                                  "glue": round(glue_ms / args.steps, 3),
                                   "host_and_other": round(ms_per_step - (ntt_ms + msm_ms + glue_ms) / args.steps, 3)},
         "roofline": roofline,
         "roofline_valu": valu,

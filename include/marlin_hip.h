@@ -187,6 +187,15 @@ int mh_marlin_prove(uint64_t pk, const uint64_t* instance_mont, const uint64_t* 
 int mh_marlin_prove_dev(uint64_t pk, const void* d_instance_mont, const void* d_witness_mont, const uint8_t* zk_seed32,
                         int zk_chacha_rounds, uint8_t* proof_out, size_t cap, size_t* len_out);
 
+/* Marlin::prove is generic over the caller's `zk_rng: &mut R` (src/lib.rs:151-155); the two entry points above replay
+ * rand_chacha generators.  For any other RngCore the caller draws the field elements itself -- `Fr::rand(zk_rng)`,
+ * mh_marlin_zk_draw_count(pk) of them, in the order the reference consumes them (r_w, r_za, r_zb,
+ * the 3|H| mask coefficients, then 3 per hiding commitment) -- and passes them here (host memory, Montgomery limbs,
+ * 4 per element).  Same proof bytes as the reference with that rng. */
+int mh_marlin_zk_draw_count(uint64_t pk, size_t* n_out);
+int mh_marlin_prove_draws(uint64_t pk, const uint64_t* instance_mont, const uint64_t* witness_mont, const uint64_t* zk_draws_mont,
+                          size_t n_draws, uint8_t* proof_out, size_t cap, size_t* len_out);
+
 /* Wire format (host only, no device needed): the flat ToBytes-layout proof of mh_marlin_prove <-> the bytes of
  * ark-serialize's `CanonicalSerialize for Proof<Fr, PC>` (src/data_structures.rs:100-110; ProverMsg as Option<Vec<F>>,
  * src/ahp/prover.rs:84-99): compressed G1 (x with the y-sign / infinity flags in the top two bits of the last byte), u64
@@ -218,12 +227,24 @@ int mh_marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_k
  * identity; G2 points are taken to be in the order-r subgroup. */
 int mh_pairing_product_is_one(const uint64_t* g1_xy_mont, const uint64_t* g2_xy_mont, size_t n, int* is_one_out);
 
-/* Multi-GPU (one process per GPU): shard every MSM of mh_marlin_prove by points over `world` ranks.  The
- * library is transport-agnostic: `allgather` must gather `bytes` bytes from every rank into recv
- * (rank-major, world * bytes) -- in this repo torch.distributed.all_gather over RCCL/xGMI (marlin_amd/dist.py).
- * Every rank must hold the full SRS and prover key and call mh_marlin_prove with identical arguments. */
+/* Multi-GPU (one process per GPU): shard every MSM of mh_marlin_prove by BUCKET RANGE over `world` ranks.  Every rank
+ * holds the full SRS, window table and prover key, runs the whole prover and recodes every scalar, but sorts,
+ * accumulates and reduces only the digits that fall into ITS partitions of the shared bucket set -- partition v
+ * (2^11 buckets) belongs to rank v mod world (interleaved, because low buckets are heavier).  A rank's result is a
+ * partial sum; ONE all_gather per batch of MSMs exchanges the partial Jacobian points and every rank adds them, so all
+ * ranks derive identical commitments and Fiat-Shamir challenges.  Groups the fixed-base path does not serve on a rank
+ * (a window table with fewer partitions than ranks, short vectors, the skew fallback) are computed in full by that rank;
+ * the payload carries a share/whole flag per job and a whole result takes precedence over shares.
+ * The library is transport-agnostic: `allgather` must gather `bytes` bytes from every rank into recv (rank-major,
+ * world * bytes) -- in this repo torch.distributed.all_gather over RCCL/xGMI (marlin_amd/dist.py).  Every rank must call
+ * mh_marlin_prove with identical arguments. */
 typedef int (*mh_allgather_fn)(const void* send, size_t bytes, void* recv, void* user);
 int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* user);
+/* mh_msm_batch_dev with the jobs sharded over the registered ranks (every rank passes the same full jobs and receives
+ * the combined results): the seam-route MSM (PC::commit -> VariableBaseMSM, src/lib.rs:172,193,213,292) for a
+ * multi-GPU host. */
+int mh_msm_batch_sharded_dev(size_t njobs, const uint64_t* bases_handles, const size_t* base_offsets, const void* const* d_scalars,
+                             const size_t* ns, int scalars_are_montgomery, uint64_t* out_xyz_mont);
 int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv);   /* runs the callback once (host only) */
 
 /* Coefficients (Montgomery Fr) of a prover / indexer polynomial of the last proof made with this key, by the
@@ -232,7 +253,8 @@ int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv);   /* r
 int mh_marlin_get_poly(uint64_t pk, const char* label, uint64_t* out, size_t cap_elems, size_t* len_out);
 
 /* ---- profiling: accumulated HIP-event time per kernel family on the library stream ----
- * family: 0 = ntt passes, 1 = msm (all stages), 2 = msm accum only, 3 = glue.  */
+ * family: 0 = ntt passes, 1 = msm (wall time of the MSM groups, all stages), 2 = msm accum only, 3 = glue, 4 = the msm sort and
+ * bucket-reduction stages by themselves (they run beside the accumulation of the group's other half, on a second stream).  */
 int mh_prof_enable(int on);
 int mh_prof_reset(void);
 int mh_prof_get(int family, double* total_ms_out, uint64_t* launches_out);

@@ -13,5 +13,5 @@ Field elements travel as numpy uint64 arrays of shape (n, 4) (Fr) / (n, 6) (Fq)
 in arkworks' in-memory layout (little-endian limbs, Montgomery form).
 """
 from ._lib import MarlinHipError, load, check, LIB_PATH  # noqa: F401
-from .api import (init, shutdown, device_info, ntt, intt, coset_ntt, ntt_dev, Bases, G2Bases, g2_msm, msm, msm_dev, msm_batch_dev,  # noqa: F401
+from .api import (init, shutdown, device_info, ntt, intt, coset_ntt, ntt_dev, Bases, G2Bases, g2_msm, msm, msm_dev, msm_batch_dev, msm_batch_sharded_dev,  # noqa: F401
                   DeviceBuffer, g1_to_affine, msm_path_counts, prof_enable, prof_reset, prof_get, synchronize)

@@ -48,6 +48,7 @@ SYMBOLS = {
     "mh_msm": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "mh_msm_dev": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "mh_msm_batch_dev": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mh_msm_batch_sharded_dev": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mh_g1_to_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mh_g1_sum": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mh_marlin_index": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u64p]),
@@ -59,6 +60,9 @@ SYMBOLS = {
                                   C.POINTER(C.c_size_t)]),
     "mh_marlin_prove_dev": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_size_t)]),
+    "mh_marlin_zk_draw_count": (C.c_int, [C.c_uint64, C.POINTER(C.c_size_t)]),
+    "mh_marlin_prove_draws": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.POINTER(C.c_size_t)]),
     "mh_marlin_verify": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "mh_pairing_product_is_one": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "mh_marlin_proof_serialize": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

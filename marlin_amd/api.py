@@ -271,6 +271,19 @@ def msm_batch_dev(jobs, montgomery=True):
     return out
 
 
+def msm_batch_sharded_dev(jobs, montgomery=True):
+    """msm_batch_dev with every job sharded by bucket range over the ranks registered with mh_marlin_set_shard
+    (marlin_amd.dist.enable_sharded_prove); every rank passes the same jobs and receives the combined results."""
+    k = len(jobs)
+    handles = (C.c_uint64 * k)(*[j[0].handle for j in jobs])
+    offs = (C.c_size_t * k)(*[int(j[1]) for j in jobs])
+    ptrs = (C.c_void_p * k)(*[(j[2].ptr if isinstance(j[2], DeviceBuffer) else int(j[2])) for j in jobs])
+    ns = (C.c_size_t * k)(*[int(j[3]) for j in jobs])
+    out = np.zeros((k, 3 * _fql()), dtype=np.uint64)
+    _lib.check(_L().mh_msm_batch_sharded_dev(k, handles, offs, ptrs, ns, 1 if montgomery else 0, out.ctypes.data), "mh_msm_batch_sharded_dev")
+    return out
+
+
 def msm_path_counts():
     """(fixed-base groups, variable-base groups) served since mh_init (mh_msm_path_counts)."""
     a, b = C.c_uint64(), C.c_uint64()

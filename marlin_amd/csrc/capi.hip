@@ -403,87 +403,99 @@ static const BaseSet* find_table(Context& c, const void* b, size_t n, size_t& of
   return nullptr;
 }
 
-// One group of <= MAX_JOBS jobs.  skewed = true (and nothing written) when a bucket is so overfull that the caller
-// should take the variable-base path with its pair-tree accumulation instead.
-// shard = {rank, world}: this rank accumulates and reduces only the buckets of the partitions v = rank (mod world) and `out`
-// is its PARTIAL sum (partial = true); when the table has fewer partitions than ranks the group is not sharded (partial = false).
-static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* offs, const void* const* d_scalars, const size_t* ns,
-                        int is_mont, HG1* out, bool& skewed, const int* shard, bool& partial) {
-  namespace F = msmfb;
-  hipStream_t s = c.stream;
-  skewed = false;
-  msm::Windows win;
-  const u32 W = msm::make_windows(bs.tab_c, win);
-  const u32 nbt = 1u << (bs.tab_c - 1);                                  // buckets per job
-  const u32 pshift = F::part_bits(bs.tab_c);
-  const u32 nb = 1u << pshift;                                           // per virtual window
-  const u32 nparts = nbt / nb;
-  const u32 WT = nparts * nj;
-  const size_t WB = (size_t)nbt * nj;
-  F::Own own{0, 1};
-  partial = false;
-  if (shard && shard[1] > 1 && nparts >= (u32)shard[1]) { own.first = (u32)shard[0]; own.stride = (u32)shard[1]; partial = true; }
-  const u32 nown = (nparts - own.first + own.stride - 1) / own.stride;   // owned partitions of every job
-  const u32 nbown = nown * nb;                                           // owned buckets of every job
-  const u32 S = F::split_scalars(W);                                     // scalars per count / split block
-  F::FbJobs jobs;
-  memset(&jobs, 0, sizeof(jobs));
-  jobs.njobs = nj;
-  // A job whose scalars ARE another job's (same device vector, same length) with bases further into the same set --
-  // MarlinKZG10 commits a degree-bounded polynomial against powers and against shifted_powers(d) -- has the same digits,
-  // hence the same sorted bucket lists: it skips the sort stages and reads the other job's lists with its table indices
-  // shifted by the distance of the base ranges (FbWin::delta).  Accumulation and reduction stay per job.
-  std::vector<int> alias(nj, -1);
-  static const bool alias_on = [] { const char* e = getenv("MH_FB_ALIAS"); return !(e && atoi(e) == 0); }();
-  for (int k = 1; k < nj && alias_on; k++)
-    for (int j = 0; j < k; j++)
-      if (alias[j] < 0 && d_scalars[j] == d_scalars[k] && ns[j] == ns[k] && offs[k] >= offs[j]) { alias[k] = j; break; }
-  u64 ent = 0, pco = 0; u32 max_blk = 0;
-  for (int k = 0; k < nj; k++) {
-    jobs.scalars[k] = (const Fr*)d_scalars[k]; jobs.n[k] = ns[k]; jobs.tab_off[k] = (u32)offs[k];
-    jobs.ent_off[k] = ent;
-    if (alias[k] >= 0) { jobs.nblk[k] = 0; jobs.pc_off[k] = pco; continue; }       // no blocks: count / split skip the job
-    ent += (u64)W * ns[k];
-    jobs.nblk[k] = (u32)((ns[k] + S - 1) / S);
-    jobs.pc_off[k] = pco; pco += (u64)nparts * jobs.nblk[k];
-    max_blk = std::max(max_blk, jobs.nblk[k]);
+// One sub-batch of a group of jobs on the fixed-base path: everything the stages need, so that its sort, its
+// accumulation and its bucket reduction can be issued separately (and on different streams, see msm_fb_pipeline).
+// shard = {rank, world}: this rank accumulates and reduces only the buckets of the partitions v = rank (mod world) and the
+// results are its PARTIAL sums (partial = true); when the table has fewer partitions than ranks the group is not sharded.
+struct FbRun {
+  Context& c; const BaseSet& bs; Context::FbWs& ws;
+  int nj = 0, is_mont = 0;
+  std::vector<size_t> offs, ns; std::vector<const void*> sc;
+  msm::Windows win; u32 W = 0, nbt = 0, pshift = 0, nb = 0, nparts = 0, WT = 0; size_t WB = 0;
+  msmfb::Own own{0, 1}; bool partial = false; u32 nbown = 0, S = 0;
+  msmfb::FbJobs jobs; std::vector<int> alias;
+  u64 ent = 0, pco = 0, tile = 0, max_tiles_total = 0; u32 max_blk = 0, seg = 0, nseg = 0, chunks = 1;
+  std::vector<msmfb::FbWin> desc; std::vector<msmfb::FbBlk> blk; std::vector<u32> ptot;
+  bool skewed = false;
+  FbRun(Context& c_, const BaseSet& bs_, Context::FbWs& ws_) : c(c_), bs(bs_), ws(ws_) {}
+
+  int prepare(int is_mont_, const int* shard) {
+    namespace F = msmfb;
+    nj = (int)ns.size(); is_mont = is_mont_;
+    W = msm::make_windows(bs.tab_c, win);
+    nbt = 1u << (bs.tab_c - 1);                                          // buckets per job
+    pshift = F::part_bits(bs.tab_c);
+    nb = 1u << pshift;                                                   // per virtual window
+    nparts = nbt / nb;
+    WT = nparts * nj;
+    WB = (size_t)nbt * nj;
+    own = F::Own{0, 1}; partial = false;
+    if (shard && shard[1] > 1 && nparts >= (u32)shard[1]) { own.first = (u32)shard[0]; own.stride = (u32)shard[1]; partial = true; }
+    const u32 nown = (nparts - own.first + own.stride - 1) / own.stride; // owned partitions of every job
+    nbown = nown * nb;                                                   // owned buckets of every job
+    S = F::split_scalars(W);                                             // scalars per count / split block
+    memset(&jobs, 0, sizeof(jobs));
+    jobs.njobs = nj;
+    // A job whose scalars ARE another job's (same device vector, same length) with bases further into the same set --
+    // MarlinKZG10 commits a degree-bounded polynomial against powers and against shifted_powers(d) -- has the same digits,
+    // hence the same sorted bucket lists: it skips the sort stages and reads the other job's lists with its table indices
+    // shifted by the distance of the base ranges (FbWin::delta).  Accumulation and reduction stay per job.
+    alias.assign(nj, -1);
+    static const bool alias_on = [] { const char* e = getenv("MH_FB_ALIAS"); return !(e && atoi(e) == 0); }();
+    for (int k = 1; k < nj && alias_on; k++)
+      for (int j = 0; j < k; j++)
+        if (alias[j] < 0 && sc[j] == sc[k] && ns[j] == ns[k] && offs[k] >= offs[j]) { alias[k] = j; break; }
+    ent = 0; pco = 0; max_blk = 0;
+    for (int k = 0; k < nj; k++) {
+      jobs.scalars[k] = (const Fr*)sc[k]; jobs.n[k] = ns[k]; jobs.tab_off[k] = (u32)offs[k];
+      jobs.ent_off[k] = ent;
+      if (alias[k] >= 0) { jobs.nblk[k] = 0; jobs.pc_off[k] = pco; continue; }       // no blocks: count / split skip the job
+      ent += (u64)W * ns[k];
+      jobs.nblk[k] = (u32)((ns[k] + S - 1) / S);
+      jobs.pc_off[k] = pco; pco += (u64)nparts * jobs.nblk[k];
+      max_blk = std::max(max_blk, jobs.nblk[k]);
+    }
+    if (ent >= (1ull << 32)) return fail(MH_EINVAL, "msm batch too large for 32-bit entry offsets");
+    tile = (ent + 2047) / 2048;
+    if (tile < 2048) tile = 2048;
+    if (tile > F::MAX_TILE) tile = F::MAX_TILE;
+    max_tiles_total = ent / tile + WT + 1;
+    MH_TRY(ws.dig.ensure(ent * 4)); MH_TRY(ws.val.ensure(ent * 4)); MH_TRY(ws.sorted.ensure(ent * 4));
+    MH_TRY(ws.pc.ensure(pco * 4)); MH_TRY(ws.ptot.ensure((size_t)WT * 8)); MH_TRY(ws.desc.ensure((size_t)WT * sizeof(msmfb::FbWin)));
+    MH_TRY(ws.blk.ensure(8 * max_tiles_total * sizeof(F::FbBlk)));
+    MH_TRY(ws.bh.ensure(max_tiles_total * nb * 4));
+    MH_TRY(ws.tot.ensure(WB * 4)); MH_TRY(ws.base.ensure(WB * 4)); MH_TRY(ws.pend.ensure(WB * 4));
+    MH_TRY(ws.buckets.ensure(WB * sizeof(F::G1Xyzz30)));
+    // segment length of the bucket reduction: >= 49152 threads per launch (measured best: 31.2 ms vs 36.1 ms with SEG fixed,
+    // 32.7 ms at 65536, per 3 proofs), at most SEG buckets each; MH_FB_SEG_THREADS overrides
+    seg = msm::SEG;
+    static const u64 seg_threads = [] { const char* e = getenv("MH_FB_SEG_THREADS"); return e ? (u64)atoll(e) : 49152ull; }();
+    if (seg > nb) seg = nb;                                              // a segment stays inside one partition
+    while (seg > 4 && (u64)nj * (nbown / seg) < seg_threads) seg >>= 1;
+    nseg = nbown / seg;
+    chunks = nseg >= 4096 ? nseg / 256 : 1;                              // reduce2 in two launches when nseg is large
+    MH_TRY(ws.seg.ensure((size_t)nj * (nseg + chunks) * sizeof(F::G1Xyzz30)));
+    MH_TRY(ws.win.ensure((size_t)nj * sizeof(G1Xyzz)));
+    MH_TRY(ws.sums.ensure(64 + F::SIZE_BINS * 4));
+    MH_TRY(ws.perm.ensure(WB * 4));
+    desc.assign(WT, msmfb::FbWin{});
+    ptot.assign(WT, 0);
+    return MH_OK;
   }
-  if (ent >= (1ull << 32)) return fail(MH_EINVAL, "msm batch too large for 32-bit entry offsets");
-  u64 tile = (ent + 2047) / 2048;
-  if (tile < 2048) tile = 2048;
-  if (tile > F::MAX_TILE) tile = F::MAX_TILE;
-  const u64 max_tiles_total = ent / tile + WT + 1;
-  MH_TRY(c.msm_dig.ensure(ent * 4)); MH_TRY(c.fb_val.ensure(ent * 4)); MH_TRY(c.msm_sorted.ensure(ent * 4));
-  MH_TRY(c.fb_pc.ensure(pco * 4)); MH_TRY(c.fb_ptot.ensure((size_t)WT * 8)); MH_TRY(c.fb_desc.ensure((size_t)WT * sizeof(msmfb::FbWin)));
-  MH_TRY(c.fb_blk.ensure(8 * max_tiles_total * sizeof(F::FbBlk)));
-  MH_TRY(c.msm_bh.ensure(max_tiles_total * nb * 4));
-  MH_TRY(c.msm_tot.ensure(WB * 4)); MH_TRY(c.msm_base.ensure(WB * 4)); MH_TRY(c.msm_pend.ensure(WB * 4));
-  MH_TRY(c.msm_buckets.ensure(WB * sizeof(F::G1Xyzz30)));
-  // segment length of the bucket reduction: >= 49152 threads per launch (measured best: 31.2 ms vs 36.1 ms with SEG fixed,
-  // 32.7 ms at 65536, per 3 proofs), at most SEG buckets each; MH_FB_SEG_THREADS overrides
-  u32 seg = msm::SEG;
-  static const u64 seg_threads = [] { const char* e = getenv("MH_FB_SEG_THREADS"); return e ? (u64)atoll(e) : 49152ull; }();
-  if (seg > nb) seg = nb;                                                // a segment stays inside one partition
-  while (seg > 4 && (u64)nj * (nbown / seg) < seg_threads) seg >>= 1;
-  const u32 nseg = nbown / seg;
-  const u32 chunks = nseg >= 4096 ? nseg / 256 : 1;                      // reduce2 in two launches when nseg is large
-  MH_TRY(c.msm_seg.ensure((size_t)nj * (nseg + chunks) * sizeof(F::G1Xyzz30)));
-  MH_TRY(c.msm_win.ensure((size_t)nj * sizeof(G1Xyzz)));
-  MH_TRY(c.tr_sums.ensure(64 + F::SIZE_BINS * 4));
-  MH_TRY(c.fb_perm.ensure(WB * 4));
-  std::vector<msmfb::FbWin> desc(WT);
-  std::vector<F::FbBlk> blk;
-  std::vector<u32> ptot(WT);
-  {
-    ProfScope ps(c, PF_MSM);
-    u32* key = (u32*)c.msm_dig.ptr; u32* val = (u32*)c.fb_val.ptr;
-    u32* d_ptot = (u32*)c.fb_ptot.ptr; u32* d_pstart = d_ptot + WT;
-    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)c.fb_pc.ptr, W, win, is_mont, nparts, pshift, S, own);
-    hipLaunchKernelGGL(F::pscan_kernel, dim3(nparts, nj), dim3(1024), 0, s, jobs, (u32*)c.fb_pc.ptr, d_ptot, nparts);
+
+  // count / split / hist / scatter + the size order of the buckets; two host round trips on `s` (partition totals for the
+  // descriptors, largest bucket for the skew decision).  skewed = true: the caller takes the variable-base path instead.
+  int sort(hipStream_t s) {
+    namespace F = msmfb;
+    ProfScope ps(c, PF_MSM_STAGES, s);
+    u32* key = (u32*)ws.dig.ptr; u32* val = (u32*)ws.val.ptr;
+    u32* d_ptot = (u32*)ws.ptot.ptr; u32* d_pstart = d_ptot + WT;
+    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)ws.pc.ptr, W, win, is_mont, nparts, pshift, S, own);
+    hipLaunchKernelGGL(F::pscan_kernel, dim3(nparts, nj), dim3(1024), 0, s, jobs, (u32*)ws.pc.ptr, d_ptot, nparts);
     hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
-    hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)c.fb_pc.ptr,
+    hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)ws.pc.ptr,
                        (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S, own);
-    MH_HIP(hipMemcpyAsync(ptot.data(), c.fb_ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipMemcpyAsync(ptot.data(), ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count.  The XCD of
     // a window is its rank among the windows that HAVE entries, mod 8: with the MSM sharded over G ranks a rank owns the
@@ -515,82 +527,199 @@ static int msm_fb_group(Context& c, const BaseSet& bs, int nj, const size_t* off
       for (size_t li = x; li < live.size(); li += 8)
         for (u32 t = 0; t < desc[live[li]].ntiles; t++) blk[(k++ << 3) | x] = F::FbBlk{live[li], t};
     }
-    MH_HIP(hipMemcpyAsync(c.fb_desc.ptr, desc.data(), (size_t)WT * sizeof(msmfb::FbWin), hipMemcpyHostToDevice, s));
-    if (grid_tiles) MH_HIP(hipMemcpyAsync(c.fb_blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
-    const msmfb::FbWin* fbw = (const msmfb::FbWin*)c.fb_desc.ptr;
-    const F::FbBlk* dblk = (const F::FbBlk*)c.fb_blk.ptr;
+    MH_HIP(hipMemcpyAsync(ws.desc.ptr, desc.data(), (size_t)WT * sizeof(msmfb::FbWin), hipMemcpyHostToDevice, s));
+    if (grid_tiles) MH_HIP(hipMemcpyAsync(ws.blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
+    const msmfb::FbWin* fbw = (const msmfb::FbWin*)ws.desc.ptr;
+    const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;
     const size_t lds = (size_t)nb * 4;
     if (grid_tiles) {
       hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), lds, s, fbw, dblk, (const u32*)key,
-                         (u32*)c.msm_bh.ptr, nb, (u32)tile);
+                         (u32*)ws.bh.ptr, nb, (u32)tile);
     }
-    hipLaunchKernelGGL(F::colscan_kernel, dim3((nb + 255) / 256, WT), dim3(256), 0, s, fbw, (u32*)c.msm_bh.ptr, (u32*)c.msm_tot.ptr, nb);
-    u32* d_max = (u32*)c.tr_sums.ptr;                  // [0] largest bucket, [1] buckets with deferred entries
+    hipLaunchKernelGGL(F::colscan_kernel, dim3((nb + 255) / 256, WT), dim3(256), 0, s, fbw, (u32*)ws.bh.ptr, (u32*)ws.tot.ptr, nb);
+    u32* d_max = (u32*)ws.sums.ptr;                    // [0] largest bucket, [1] buckets with deferred entries
     MH_HIP(hipMemsetAsync(d_max, 0, 8, s));
-    hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, nb, d_max);
+    hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)ws.tot.ptr, (u32*)ws.base.ptr, nb, d_max);
     for (int k = 0; k < nj; k++)
       if (alias[k] >= 0) {          // an aliasing job has the bucket sizes and list positions of the job whose lists it reads
-        MH_HIP(hipMemcpyAsync((u32*)c.msm_tot.ptr + (size_t)k * nbt, (const u32*)c.msm_tot.ptr + (size_t)alias[k] * nbt, (size_t)nbt * 4, hipMemcpyDeviceToDevice, s));
-        MH_HIP(hipMemcpyAsync((u32*)c.msm_base.ptr + (size_t)k * nbt, (const u32*)c.msm_base.ptr + (size_t)alias[k] * nbt, (size_t)nbt * 4, hipMemcpyDeviceToDevice, s));
+        MH_HIP(hipMemcpyAsync((u32*)ws.tot.ptr + (size_t)k * nbt, (const u32*)ws.tot.ptr + (size_t)alias[k] * nbt, (size_t)nbt * 4, hipMemcpyDeviceToDevice, s));
+        MH_HIP(hipMemcpyAsync((u32*)ws.base.ptr + (size_t)k * nbt, (const u32*)ws.base.ptr + (size_t)alias[k] * nbt, (size_t)nbt * 4, hipMemcpyDeviceToDevice, s));
       }
     if (grid_tiles) {
       hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::scatter_lds_bytes(nb), s, fbw, dblk, (const u32*)key,
-                         (const u32*)val, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr, nb, (u32)tile);
+                         (const u32*)val, (const u32*)ws.bh.ptr, (const u32*)ws.base.ptr, (u32*)ws.sorted.ptr, nb, (u32)tile);
     }
+    // buckets ordered by size, largest first (before the skew decision comes back: a few tens of microseconds, wasted
+    // only on the skewed batches that leave this path anyway)
+    u32* d_szh = (u32*)ws.sums.ptr + 16;
+    MH_HIP(hipMemsetAsync(d_szh, 0, F::SIZE_BINS * 4, s));
+    hipLaunchKernelGGL(F::size_hist_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, s, (const u32*)ws.tot.ptr, (u64)WB, d_szh);
+    hipLaunchKernelGGL(F::size_scan_kernel, dim3(1), dim3(1024), 0, s, d_szh);
+    hipLaunchKernelGGL(F::size_perm_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, s, (const u32*)ws.tot.ptr, (u64)WB, d_szh,
+                       (u32*)ws.perm.ptr);
     u32 mx = 0;
     MH_HIP(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     const u64 avg = ent / WB + 1;
-    if (mx > 4096 && (u64)mx > 32 * avg) { skewed = true; partial = false; return MH_OK; }
-    // buckets ordered by size, largest first
-    u32* d_szh = (u32*)c.tr_sums.ptr + 16;
-    MH_HIP(hipMemsetAsync(d_szh, 0, F::SIZE_BINS * 4, s));
-    hipLaunchKernelGGL(F::size_hist_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u64)WB, d_szh);
-    hipLaunchKernelGGL(F::size_scan_kernel, dim3(1), dim3(1024), 0, s, d_szh);
-    hipLaunchKernelGGL(F::size_perm_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u64)WB, d_szh,
-                       (u32*)c.fb_perm.ptr);
+    skewed = mx > 4096 && (u64)mx > 32 * avg;
+    return MH_OK;
+  }
+
+  int accum(hipStream_t s) {
+    namespace F = msmfb;
+    const msmfb::FbWin* fbw = (const msmfb::FbWin*)ws.desc.ptr;
+    u32* d_max = (u32*)ws.sums.ptr;
     {
-      ProfScope pa(c, PF_MSM_ACCUM);
+      ProfScope pa(c, PF_MSM_ACCUM, s);
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
       // resident waves per SIMD of the accumulate kernel (register budget 512 / waves): MH_ACC_WAVES = 3 | 4
       static const int acc_waves = [] { const char* e = getenv("MH_ACC_WAVES"); int w = e ? atoi(e) : 3; return w == 4 ? 4 : 3; }();
       if (acc_waves == 4)
         hipLaunchKernelGGL(F::accum30_kernel<4>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
-                           (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
-                           (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
+                           (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
       else
         hipLaunchKernelGGL(F::accum30_kernel<3>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
-                           (u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr, (const u32*)c.fb_perm.ptr,
-                           (F::G1Xyzz30*)c.msm_buckets.ptr, (u32*)c.msm_pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
+                           (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
     }
+    ProfScope ps(c, PF_MSM_STAGES, s);
     hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw,
-                       (const F::G1Aff30*)bs.d_table, (const u32*)c.msm_sorted.ptr, (const u32*)c.msm_base.ptr, (const u32*)c.msm_tot.ptr,
-                       (const u32*)c.msm_pend.ptr, (const u32*)(d_max + 1), (F::G1Xyzz30*)c.msm_buckets.ptr, nb, (u64)WB);
-    // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
-    F::G1Xyzz30* seg30 = (F::G1Xyzz30*)c.msm_seg.ptr;
-    hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)c.msm_buckets.ptr,
+                       (const F::G1Aff30*)bs.d_table, (const u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr,
+                       (const u32*)ws.pend.ptr, (const u32*)(d_max + 1), (F::G1Xyzz30*)ws.buckets.ptr, nb, (u64)WB);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+  }
+
+  // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
+  int reduce(hipStream_t s) {
+    namespace F = msmfb;
+    ProfScope ps(c, PF_MSM_STAGES, s);
+    F::G1Xyzz30* seg30 = (F::G1Xyzz30*)ws.seg.ptr;
+    hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
                        seg30, nbt, nseg, (u32)nj, seg, nb, own);
     const size_t r2lds = 256 * sizeof(F::G1Xyzz30);
     if (chunks > 1) {
       F::G1Xyzz30* mid = seg30 + (size_t)nj * nseg;
       hipLaunchKernelGGL(F::reduce2_30_kernel, dim3(chunks, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, mid, (G1Xyzz*)nullptr, nseg, 0);
       hipLaunchKernelGGL(F::reduce2_30_kernel, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)mid, (F::G1Xyzz30*)nullptr,
-                         (G1Xyzz*)c.msm_win.ptr, chunks, 1);
+                         (G1Xyzz*)ws.win.ptr, chunks, 1);
     } else {
       hipLaunchKernelGGL(F::reduce2_30_kernel, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, (F::G1Xyzz30*)nullptr,
-                         (G1Xyzz*)c.msm_win.ptr, nseg, 1);
+                         (G1Xyzz*)ws.win.ptr, nseg, 1);
     }
     MH_HIP(hipGetLastError());
+    return MH_OK;
   }
-  std::vector<uint64_t> sums((size_t)nj * XYZZ_L);
-  MH_HIP(hipMemcpyAsync(sums.data(), c.msm_win.ptr, sums.size() * 8, hipMemcpyDeviceToHost, s));
-  MH_HIP(hipStreamSynchronize(s));
+
+  // the nj sums to the host (synchronises `s`)
+  int finish(hipStream_t s, HG1* out) {
+    std::vector<uint64_t> sums((size_t)nj * XYZZ_L);
+    MH_HIP(hipMemcpyAsync(sums.data(), ws.win.ptr, sums.size() * 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < nj; k++) {
+      const uint64_t* p = sums.data() + (size_t)k * XYZZ_L;
+      HFq X, Y, ZZ, ZZZ;
+      memcpy(X.v, p, FQ_B); memcpy(Y.v, p + FQ_L, FQ_B); memcpy(ZZ.v, p + 2 * FQ_L, FQ_B); memcpy(ZZZ.v, p + 3 * FQ_L, FQ_B);
+      out[k] = HG1::from_xyzz(X, Y, ZZ, ZZZ);
+    }
+    return MH_OK;
+  }
+};
+
+// One group of <= MAX_JOBS jobs on the fixed-base path.  skewed = true (and nothing written) when a bucket is so overfull
+// that the caller should take the variable-base path with its pair-tree accumulation instead.
+//
+// The accumulate kernel is bound by VALU issue and takes 80 % of the group's time; the sort before it is bound by LDS and
+// HBM latency and the bucket reduction after it is a chain of dependent additions at one wave per SIMD.  So the group
+// runs as TWO sub-batches A, B (jobs that share sorted lists stay together) in a software pipeline over two streams:
+//     main stream :  sort(A)  accum(A)             accum(B)   reduce(B)
+//     side stream :                    sort(B)                reduce(A)
+// sort(B) fills the issue slots accum(A) leaves free and reduce(A) those of accum(B); only sort(A) and reduce(B) stay
+// exposed.  The split minimises the modelled makespan over all 2-partitions of the jobs (<= 2^8): the exposed sort wants
+// few entries in A, the exposed reduction few jobs in B (its cost is per bucket set, not per scalar).  MH_FB_SPLIT=0
+// keeps the whole group on the main stream.
+static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* offs, const void* const* d_scalars, const size_t* ns,
+                           int is_mont, HG1* out, bool& skewed, const int* shard, bool& partial) {
+  skewed = false;
+  hipStream_t s0 = c.stream, s1 = c.stream2;
+  ProfScope wall(c, PF_MSM, s0);
+  msm::Windows win;
+  const u32 W = msm::make_windows(bs.tab_c, win);
+  // atoms: a job plus the jobs that would alias it (same scalars, same length, bases further into the set)
+  std::vector<int> atom_of(nj, -1);
+  std::vector<std::vector<int>> atoms;
   for (int k = 0; k < nj; k++) {
-    const uint64_t* p = sums.data() + (size_t)k * XYZZ_L;
-    HFq X, Y, ZZ, ZZZ;
-    memcpy(X.v, p, FQ_B); memcpy(Y.v, p + FQ_L, FQ_B); memcpy(ZZ.v, p + 2 * FQ_L, FQ_B); memcpy(ZZZ.v, p + 3 * FQ_L, FQ_B);
-    out[k] = HG1::from_xyzz(X, Y, ZZ, ZZZ);
+    if (atom_of[k] >= 0) continue;
+    atom_of[k] = (int)atoms.size(); atoms.push_back({k});
+    for (int j = k + 1; j < nj; j++)
+      if (atom_of[j] < 0 && d_scalars[j] == d_scalars[k] && ns[j] == ns[k]) { atom_of[j] = atom_of[k]; atoms.back().push_back(j); }
   }
+  static const int split_on = [] { const char* e = getenv("MH_FB_SPLIT"); return e ? atoi(e) : 1; }();
+  u64 tot_ent = 0;
+  for (int k = 0; k < nj; k++) tot_ent += (u64)W * ns[k];
+  uint32_t best_mask = 0;
+  if (split_on && s1 && atoms.size() >= 2 && tot_ent >= (16ull << 20)) {
+    // modelled times in picoseconds (2^20-constraint proof on MI355X: sort 16 ps per entry, accumulate 132 ps per entry,
+    // bucket reduction 0.52 ms per set of 2^19 buckets)
+    const double nbown_frac = (double)(1u << (bs.tab_c - 1)) / (double)(1u << 19) / ((shard && shard[1] > 1) ? (double)shard[1] : 1.0);
+    const double shard_frac = (shard && shard[1] > 1) ? 1.0 / (double)shard[1] : 1.0;
+    double best = 1e300;
+    const int na = (int)atoms.size();
+    for (uint32_t m = 1; m + 1 < (1u << na); m++) {            // m = atoms of A; both sides non-empty
+      double sortA = 0, sortB = 0, accA = 0, accB = 0, redA = 0, redB = 0;
+      for (int a = 0; a < na; a++) {
+        const double e = (double)W * (double)ns[atoms[a][0]];
+        const double srt = 16.0 * e * (0.3 + 0.7 * shard_frac);          // count / split recode every scalar on every rank
+        const double acc = 132.0 * e * (double)atoms[a].size() * shard_frac;
+        const double red = 0.52e9 * nbown_frac * (double)atoms[a].size();
+        if (m & (1u << a)) { sortA += srt; accA += acc; redA += red; } else { sortB += srt; accB += acc; redB += red; }
+      }
+      // concurrent kernels share the VALU: what runs beside an accumulation is modelled as half hidden
+      const double t = sortA + std::max(accA, sortB) + 0.5 * std::min(accA, sortB) + std::max(accB, redA) + 0.5 * std::min(accB, redA) + redB;
+      if (t < best) { best = t; best_mask = m; }
+    }
+  }
+  FbRun A(c, bs, c.fbws[0]), B(c, bs, c.fbws[1]);
+  std::vector<int> idxA, idxB;
+  for (int k = 0; k < nj; k++) {
+    const bool inA = best_mask == 0 || (best_mask & (1u << atom_of[k]));
+    FbRun& r = inA ? A : B;
+    (inA ? idxA : idxB).push_back(k);
+    r.offs.push_back(offs[k]); r.sc.push_back(d_scalars[k]); r.ns.push_back(ns[k]);
+  }
+  MH_TRY(A.prepare(is_mont, shard));
+  partial = A.partial;
+  if (idxB.empty()) {
+    MH_TRY(A.sort(s0));
+    if (A.skewed) { skewed = true; partial = false; return MH_OK; }
+    MH_TRY(A.accum(s0)); MH_TRY(A.reduce(s0));
+    return A.finish(s0, out);
+  }
+  MH_TRY(B.prepare(is_mont, shard));
+  hipEvent_t* ev = c.fb_ev;
+  // the side stream starts behind everything already queued on the main stream (the scalars are produced there)
+  MH_HIP(hipEventRecord(ev[0], s0)); MH_HIP(hipStreamWaitEvent(s1, ev[0], 0));
+  auto bail = [&](int rc) { (void)hipStreamSynchronize(s1); (void)hipStreamSynchronize(s0); return rc; };
+  int rc = A.sort(s0);
+  if (rc != MH_OK) return bail(rc);
+  if (A.skewed) { skewed = true; partial = false; return bail(MH_OK); }
+  if ((rc = A.accum(s0)) != MH_OK) return bail(rc);
+  MH_HIP(hipEventRecord(ev[1], s0));                                   // accum(A) done
+  if ((rc = B.sort(s1)) != MH_OK) return bail(rc);                     // beside accum(A)
+  if (B.skewed) { skewed = true; partial = false; return bail(MH_OK); }
+  MH_HIP(hipEventRecord(ev[2], s1)); MH_HIP(hipStreamWaitEvent(s0, ev[2], 0));
+  if ((rc = B.accum(s0)) != MH_OK) return bail(rc);
+  MH_HIP(hipStreamWaitEvent(s1, ev[1], 0));
+  if ((rc = A.reduce(s1)) != MH_OK) return bail(rc);                   // beside accum(B)
+  MH_HIP(hipEventRecord(ev[3], s1));
+  if ((rc = B.reduce(s0)) != MH_OK) return bail(rc);
+  MH_HIP(hipStreamWaitEvent(s0, ev[3], 0));                            // main stream is again behind everything
+  std::vector<HG1> ra(idxA.size()), rb(idxB.size());
+  if ((rc = A.finish(s0, ra.data())) != MH_OK) return bail(rc);
+  if ((rc = B.finish(s0, rb.data())) != MH_OK) return bail(rc);
+  for (size_t i = 0; i < idxA.size(); i++) out[idxA[i]] = ra[i];
+  for (size_t i = 0; i < idxB.size(); i++) out[idxB[i]] = rb[i];
   return MH_OK;
 }
 
@@ -704,7 +833,7 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
       if (ok && (u64)bs->tab_W * nsum >= 8ull * nj * (1ull << (bs->tab_c - 1))) {
         std::vector<HG1> res(nj);
         bool skewed = false, part = false;
-        MH_TRY(msm_fb_group(c, *bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, shard, part));
+        MH_TRY(msm_fb_pipeline(c, *bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, shard, part));
         if (!skewed) {
           c.n_fb_groups++;
           for (int k = 0; k < nj; k++) {
@@ -959,6 +1088,8 @@ int mh_init(int device_id) {
     return fail(MH_ENODEV, std::string("device is not gfx950: ") + prop.gcnArchName);
   MH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   c.own_stream = true;
+  MH_HIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+  for (auto& e : c.fb_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   c.device = device_id;
   c.inited = true;
   return MH_OK;
@@ -989,7 +1120,9 @@ int mh_shutdown(void) {
   c.bases.clear();
   for (auto& kv : c.g2_bases) if (kv.second.d_points) (void)hipFree(kv.second.d_points);
   c.g2_bases.clear();
-  c.fb_val.release(); c.fb_pc.release(); c.fb_ptot.release(); c.fb_desc.release(); c.fb_blk.release(); c.fb_perm.release();
+  c.fbws[0].release_all(); c.fbws[1].release_all();
+  if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
+  for (auto& e : c.fb_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }
   for (auto& r : c.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   c.prof.clear();

@@ -65,7 +65,9 @@ struct BaseSet {
 
 struct G2Set { void* d_points = nullptr; size_t n = 0; };   // G2Affine[n] (x.c0 | x.c1 | y.c0 | y.c1, Montgomery)
 
-enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_COUNT = 4 };
+// PF_MSM: wall time of the MSM groups on the main stream (accumulation included); PF_MSM_STAGES: the sort and bucket-reduction
+// stages by themselves, on whichever stream they ran (they overlap the accumulation of the other sub-batch)
+enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_MSM_STAGES = 4, PF_COUNT = 5 };
 
 struct ProfRec { int family; hipEvent_t a, b; };
 
@@ -88,7 +90,14 @@ struct Context {
   std::map<uint64_t, G2Set> g2_bases;
   uint64_t next_handle = 1;
   Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win, msm_pend;
-  Scratch fb_val, fb_pc, fb_ptot, fb_desc, fb_blk, fb_perm;   // fixed-base path (msm_fb.cuh)
+  // fixed-base path (msm_fb.cuh): two workspaces, because a group of jobs runs as two sub-batches whose sort / bucket
+  // reduction overlap the other's accumulation on a second stream (capi.hip: msm_fb_pipeline)
+  struct FbWs {
+    Scratch dig, val, sorted, pc, ptot, desc, blk, bh, tot, base, pend, buckets, seg, win, sums, perm;
+    void release_all() { for (Scratch* b : {&dig, &val, &sorted, &pc, &ptot, &desc, &blk, &bh, &tot, &base, &pend, &buckets, &seg, &win, &sums, &perm}) b->release(); }
+  } fbws[2];
+  hipStream_t stream2 = nullptr;     // library-owned side stream of the fixed-base pipeline
+  hipEvent_t fb_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t n_fb_groups = 0, n_vb_groups = 0;  // job groups that ran on the fixed-base / variable-base path
   Scratch tr_off[3], tr_cnt[2], tr_p[2], tr_sums, tr_ob, tr_pre, tr_prod, tr_scr;   // pair-tree accumulation
 
@@ -96,8 +105,8 @@ struct Context {
   bool prof_on = false;
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
-  double prof_ms[PF_COUNT] = {0, 0, 0, 0};
-  uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0};
+  double prof_ms[PF_COUNT] = {0, 0, 0, 0, 0};
+  uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0, 0};
 };
 
 Context& ctx();
@@ -106,15 +115,16 @@ struct ProfScope {
   Context& c;
   int fam;
   hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(Context& c_, int fam_) : c(c_), fam(fam_) {
+  hipStream_t st;
+  ProfScope(Context& c_, int fam_, hipStream_t s_ = nullptr) : c(c_), fam(fam_), st(s_ ? s_ : c_.stream) {
     if (!c.prof_on) return;
     auto get = [&]() { hipEvent_t e; if (!c.ev_pool.empty()) { e = c.ev_pool.back(); c.ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
     a = get(); b = get();
-    (void)hipEventRecord(a, c.stream);
+    (void)hipEventRecord(a, st);
   }
   ~ProfScope() {
     if (!a) return;
-    (void)hipEventRecord(b, c.stream);
+    (void)hipEventRecord(b, st);
     c.prof.push_back({fam, a, b});
   }
 };

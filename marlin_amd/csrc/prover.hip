@@ -134,7 +134,9 @@ int get_fr(Context& c, HFr* out, const Fr* src) {
   return MH_OK;
 }
 
-// ark_ff::batch_inversion (+ optional scaling) of n elements in place; scratch: n + n / 16 + 64 elements
+// scratch: level l parks its n_l prefix products and hands n_{l+1} = ceil(n_l / 8192) * 256 thread totals to the next
+// level, which again needs n_{l+1} prefix slots, until n_l <= 512 (host): n + 2 (n_1 + n_2 + ...) + 256 elements, i.e.
+// at most n + n / 15 + 3 * 256 (n = 2^20: n + 2 * 32768 + 2 * 1024 + 256 = n + 67840).  Callers pass max(2K, 4H) + 64.
 // ark_ff::batch_inversion (prover.rs:663, mod.rs:314) of n device elements, zeros left untouched, every inverse optionally
 // multiplied by `scale`.  Montgomery's trick in levels: a level's threads multiply up 32 elements each (binv_fwd), the
 // per-thread products are inverted by the next level, and a backward sweep applies them (binv_bwd).  The ONE inversion
@@ -286,9 +288,14 @@ struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user
 
 HG1 jac_from(const uint64_t* xyz);
 struct MsmJob { const char* bases; const Fr* scalars; uint64_t n; };
-// all jobs in one launch sequence (msm_batch_device) and ONE all_gather for all partial points.  Jobs the fixed-base
-// path did not serve (short vectors, skewed digits) are computed in full by every rank and counted once (rank 0's copy).
-int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<HG1>& out) {
+// all jobs in one launch sequence (msm_batch_device) and ONE all_gather for all partial points.
+// Payload per rank: nj Jacobian points | one error word | nj flag words (1 = this rank's point is its SHARE of the sum,
+// 0 = it is the WHOLE sum).  Which of the two a rank produces is decided rank by rank -- a short vector or a table with
+// fewer partitions than ranks is computed in full everywhere, and the skew fallback (largest bucket of the rank's OWN
+// partitions) can strike on one rank only: the hot digit lives in exactly one partition.  So the combination rule is
+// per job: if any rank reports a whole sum, the lowest such rank's point IS the result (the shares of the others are
+// discarded); otherwise the result is the sum of all shares.
+int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<HG1>& out, int is_mont = 1) {
   const int nj = (int)jobs.size();
   out.assign(nj, HG1::identity());
   if (nj == 0) return MH_OK;
@@ -298,28 +305,29 @@ int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<H
   const bool sharded = g_shard.world > 1;
   const int sh[2] = {g_shard.rank, g_shard.world};
   std::vector<uint8_t> partial(nj, 0);
-  int rc = msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), 1, part.data(), sharded ? sh : nullptr, sharded ? partial.data() : nullptr);
+  int rc = msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), is_mont, part.data(), sharded ? sh : nullptr, sharded ? partial.data() : nullptr);
   if (!sharded) { MH_TRY(rc); for (int j = 0; j < nj; j++) out[j] = jac_from(part.data() + XYZ_L * j); return MH_OK; }
   if (!g_shard.cb) return fail(MH_EINVAL, "sharded prove: no all_gather callback registered");
-  // a rank whose launch failed still enters the collective (with an error marker in the spare word after the points) so
-  // that the other ranks do not block in it; every rank then fails together
-  std::vector<uint64_t> send(part.size() + 1, 0), all((part.size() + 1) * g_shard.world);
+  // a rank whose launch failed still enters the collective (with the error word set) so that the other ranks do not
+  // block in it; every rank then fails together
+  const size_t npts = part.size(), stride = npts + 1 + (size_t)nj;
+  std::vector<uint64_t> send(stride, 0), all(stride * g_shard.world);
   if (rc == MH_OK) {
-    HG1 id = HG1::identity();
-    for (int j = 0; j < nj; j++) {
-      uint64_t* o = send.data() + XYZ_L * j;
-      if (partial[j] || g_shard.rank == 0) memcpy(o, part.data() + XYZ_L * j, XYZ_L * 8);
-      else { memcpy(o, id.X.v, FQ_B); memcpy(o + FQ_L, id.Y.v, FQ_B); memcpy(o + 2 * FQ_L, id.Z.v, FQ_B); }
-    }
+    memcpy(send.data(), part.data(), npts * 8);
+    for (int j = 0; j < nj; j++) send[npts + 1 + j] = partial[j] ? 1 : 0;
   } else {
-    send[part.size()] = 1;
+    send[npts] = 1;
   }
   if (g_shard.cb(send.data(), send.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather callback failed");
   MH_TRY(rc);
   for (int g = 0; g < g_shard.world; g++)
-    if (all[(size_t)g * send.size() + part.size()] != 0) return fail(MH_EHIP, "sharded prove: the MSM of another rank failed");
-  for (int j = 0; j < nj; j++)
-    for (int g = 0; g < g_shard.world; g++) out[j] = out[j].add(jac_from(all.data() + (size_t)g * send.size() + XYZ_L * j));
+    if (all[(size_t)g * stride + npts] != 0) return fail(MH_EHIP, "sharded prove: the MSM of another rank failed");
+  for (int j = 0; j < nj; j++) {
+    int whole = -1;
+    for (int g = 0; g < g_shard.world && whole < 0; g++) if (all[(size_t)g * stride + npts + 1 + j] == 0) whole = g;
+    if (whole >= 0) { out[j] = jac_from(all.data() + (size_t)whole * stride + XYZ_L * j); continue; }
+    for (int g = 0; g < g_shard.world; g++) out[j] = out[j].add(jac_from(all.data() + (size_t)g * stride + XYZ_L * j));
+  }
   return MH_OK;
 }
 
@@ -379,9 +387,37 @@ void host_axpy(std::vector<HFr>& acc, const HFr& f, const std::vector<HFr>& p) {
 }
 bool host_is_zero(const std::vector<HFr>& p) { for (auto& x : p) if (!x.is_zero()) return false; return true; }
 
+// The prover's `zk_rng: &mut R` (/root/reference src/lib.rs:151-155).  Every draw `Marlin::prove` makes from it is one
+// `F::rand`, so the generator is either the reference's own ChaChaRng, replayed here and on the
+// device, or -- for a caller with any other `RngCore` -- the list of field elements that caller drew, in consumption order
+// (mh_marlin_prove_draws): r_w, r_za, r_zb, the 3|H| mask coefficients, then 3 per hiding commitment.
+struct ZkSource {
+  fsh::ChaChaRng chacha;
+  const uint64_t* draws = nullptr;        // host memory, Montgomery limbs; nullptr = use chacha
+  size_t n = 0, pos = 0;
+  bool bad = false;
+  HFr fr() {
+    if (!draws) return fsh::fr_rand(chacha);
+    if (pos >= n) { bad = true; return HFr::zero(); }
+    HFr x; memcpy(x.v, draws + 4 * pos, 32); pos++;
+    if (HFr::geq_mod(x.v)) bad = true;
+    return x;
+  }
+};
+
 // DensePolynomial::rand(needed - 1, zk_rng) on the device (rng.cuh): out[0..needed) <- the next `needed`
 // accepted Fp256::rand draws of the ChaCha stream; advances the host generator past the consumed words.
-int device_poly_rand(Context& c, ProverKey& pk, fsh::ChaChaRng& zk, Fr* out, uint64_t needed, Fr* cand, u32* flag) {
+int device_poly_rand(Context& c, ProverKey& pk, ZkSource& src, Fr* out, uint64_t needed, Fr* cand, u32* flag) {
+  if (src.draws) {                        // caller-supplied draws: the next `needed` elements, range-checked on the host
+    if (src.pos + needed > src.n) { src.bad = true; return fail(MH_EINVAL, "mh_marlin_prove_draws: too few zk draws"); }
+    const uint64_t* p = src.draws + 4 * src.pos;
+    for (uint64_t i = 0; i < needed; i++) if (HFr::geq_mod(p + 4 * i)) return fail(MH_EINVAL, "mh_marlin_prove_draws: draw out of range");
+    MH_HIP(hipMemcpyAsync(out, p, needed * 32, hipMemcpyHostToDevice, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));
+    src.pos += needed;
+    return MH_OK;
+  }
+  fsh::ChaChaRng& zk = src.chacha;
   if (zk.word_pos() % 8) return fail(MH_EINVAL, "zk_rng is not aligned to a field-element draw");
   uint64_t c0 = zk.word_pos() / 8, produced = 0;
   rng::Key key; memcpy(key.k, zk.key, 32);
@@ -437,8 +473,7 @@ inline void put_comm(std::vector<uint8_t>& out, const fsh::Commitment& cm, int p
 // The rng order equals the reference's sequential loop because the MSMs consume no randomness; all the MSMs of the
 // call run as ONE batch.
 struct CommitReq { const Fr* poly; uint64_t len; bool has_bound; uint64_t bound; bool hiding; };
-template <class Rng>
-int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs, Rng* rng, std::vector<fsh::Commitment>& comms,
+int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs, ZkSource* rng, std::vector<fsh::Commitment>& comms,
                   std::vector<PolyRand>& rands) {
   auto it = c.bases.find(pk.srs_g);
   if (it == c.bases.end()) return fail(MH_EINVAL, "prover key refers to a freed SRS handle");
@@ -455,7 +490,7 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
       if (q.has_bound && q.len > q.bound + 1) return fail(MH_EINVAL, "polynomial exceeds its degree bound");
       if (off + q.len > it->second.n) return fail(MH_EINVAL, "polynomial degree exceeds the SRS");
       jobs.push_back({pts + off * PT_B, q.poly, q.len});
-      if (q.hiding) for (int k = 0; k < 3; k++) rands[i].rand.blind.push_back(fsh::fr_rand(*rng));
+      if (q.hiding) for (int k = 0; k < 3; k++) rands[i].rand.blind.push_back(rng->fr());
     }
     // the 3-coefficient hiding MSMs run on host threads while the device works on the batch
     std::vector<std::future<HG1>> hid(reqs.size());
@@ -481,14 +516,14 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
     const CommitReq& q = reqs[i];
     if (q.len > it->second.n) return fail(MH_EINVAL, "polynomial degree exceeds the SRS");
     jobs.push_back({pts, q.poly, q.len});
-    if (q.hiding) for (int k = 0; k < 3; k++) rands[i].rand.blind.push_back(fsh::fr_rand(*rng));   // P::rand(hiding_bound + 1)
+    if (q.hiding) for (int k = 0; k < 3; k++) rands[i].rand.blind.push_back(rng->fr());   // P::rand(hiding_bound + 1)
     comms[i].has_shifted = q.has_bound; rands[i].has_shifted = q.has_bound;
     if (q.has_bound) {
       if (q.len > q.bound + 1) return fail(MH_EINVAL, "polynomial exceeds its degree bound");
       uint64_t off = pk.srs_max_degree - q.bound;
       if (off + q.len > it->second.n) return fail(MH_EINVAL, "shifted powers exceed the SRS");
       jobs.push_back({pts + off * PT_B, q.poly, q.len});
-      if (q.hiding) for (int k = 0; k < 3; k++) rands[i].shifted.blind.push_back(fsh::fr_rand(*rng));
+      if (q.hiding) for (int k = 0; k < 3; k++) rands[i].shifted.blind.push_back(rng->fr());
     }
   }
   // the 3-coefficient hiding MSMs run on host threads while the device works on the batch
@@ -560,6 +595,30 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
   std::lock_guard<std::recursive_mutex> lk(c.mu);     // g_shard is read by a running mh_marlin_prove under this lock
   g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
   return MH_OK;                                 // the window table does not depend on the number of ranks (bucket-range sharding)
+}
+
+// mh_msm_batch_dev across the ranks registered with mh_marlin_set_shard: every rank passes the SAME jobs (full scalar
+// vectors, full base sets), computes its bucket range of each and receives the combined results
+int mh_msm_batch_sharded_dev(size_t njobs, const uint64_t* handles, const size_t* base_offsets, const void* const* d_scalars,
+                             const size_t* ns, int is_mont, uint64_t* out_xyz) {
+  LOCKED_CTX();
+  if (njobs && (!handles || !base_offsets || !d_scalars || !ns || !out_xyz)) return fail(MH_EINVAL, "mh_msm_batch_sharded_dev: null pointer");
+  std::vector<MsmJob> jobs(njobs);
+  for (size_t j = 0; j < njobs; j++) {
+    auto it = c.bases.find(handles[j]);
+    if (it == c.bases.end()) return fail(MH_EINVAL, "mh_msm_batch_sharded_dev: unknown bases handle");
+    if (base_offsets[j] > it->second.n || ns[j] > it->second.n - base_offsets[j])
+      return fail(MH_EINVAL, "mh_msm_batch_sharded_dev: base_offset + n exceeds the uploaded base set");
+    if (ns[j] && !d_scalars[j]) return fail(MH_EINVAL, "mh_msm_batch_sharded_dev: null scalars");
+    jobs[j] = {(const char*)it->second.d_points + base_offsets[j] * PT_B, (const Fr*)d_scalars[j], ns[j]};
+  }
+  std::vector<HG1> res;
+  MH_TRY(sharded_msm_batch(c, jobs, res, is_mont));
+  for (size_t j = 0; j < njobs; j++) {
+    uint64_t* o = out_xyz + XYZ_L * j;
+    memcpy(o, res[j].X.v, FQ_B); memcpy(o + FQ_L, res[j].Y.v, FQ_B); memcpy(o + 2 * FQ_L, res[j].Z.v, FQ_B);
+  }
+  return MH_OK;
 }
 
 // ---- verifier (host only; verify_host.h, pairing_host.h) -----------------------------------------------------
@@ -918,19 +977,38 @@ int mh_marlin_get_poly(uint64_t pk_handle, const char* label, uint64_t* out, siz
 // witness: nc - X elements (padding witnesses included).  zk_rng = ChaCha(zk_seed, rounds) drawn in the
 // order of SURVEY.md Appendix C.  proof_out: the flat ToBytes-layout proof.
 static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, bool inputs_on_device,
-                             const uint8_t* zk_seed, int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out);
+                             const uint8_t* zk_seed, int zk_rounds, const uint64_t* zk_draws, size_t n_draws, uint8_t* proof_out, size_t cap,
+                             size_t* len_out);
 int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, const uint8_t* zk_seed,
                     int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out) {
-  return marlin_prove_impl(pk_handle, instance, witness, false, zk_seed, zk_rounds, proof_out, cap, len_out);
+  return marlin_prove_impl(pk_handle, instance, witness, false, zk_seed, zk_rounds, nullptr, 0, proof_out, cap, len_out);
 }
 // the same with the assignment already in device memory (a witness generator that runs on the GPU, or a caller that
 // uploaded it ahead of time): no PCIe transfer inside the call
 int mh_marlin_prove_dev(uint64_t pk_handle, const void* d_instance, const void* d_witness, const uint8_t* zk_seed,
                         int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out) {
-  return marlin_prove_impl(pk_handle, (const uint64_t*)d_instance, (const uint64_t*)d_witness, true, zk_seed, zk_rounds, proof_out, cap, len_out);
+  return marlin_prove_impl(pk_handle, (const uint64_t*)d_instance, (const uint64_t*)d_witness, true, zk_seed, zk_rounds, nullptr, 0, proof_out, cap, len_out);
+}
+// Marlin::prove for a caller whose `zk_rng` is not a ChaCha generator (src/lib.rs:151-155 is generic over R: RngCore): the
+// caller draws the field elements itself -- `F::rand(zk_rng)`, mh_marlin_zk_draw_count of them, in the order the reference
+// consumes them -- and hands them over (host memory, Montgomery limbs).
+int mh_marlin_zk_draw_count(uint64_t pk_handle, size_t* n_out) {
+  LOCKED_CTX();
+  auto it = g_pks.find(pk_handle);
+  if (it == g_pks.end() || !n_out) return fail(MH_EINVAL, "mh_marlin_zk_draw_count: bad argument");
+  // r_w, r_za, r_zb | 3|H| mask coefficients | 3 each for w, z_a, z_b, g_1 (+ g_1's shifted commitment with MarlinKZG10)
+  *n_out = 3 + 3 * it->second->H + (it->second->pc == 1 ? 12 : 15);
+  return MH_OK;
+}
+int mh_marlin_prove_draws(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, const uint64_t* zk_draws, size_t n_draws,
+                          uint8_t* proof_out, size_t cap, size_t* len_out) {
+  if (!zk_draws) return fail(MH_EINVAL, "mh_marlin_prove_draws: null draws");
+  static const uint8_t no_seed[32] = {0};
+  return marlin_prove_impl(pk_handle, instance, witness, false, no_seed, 20, zk_draws, n_draws, proof_out, cap, len_out);
 }
 static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, bool inputs_on_device,
-                             const uint8_t* zk_seed, int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out) {
+                             const uint8_t* zk_seed, int zk_rounds, const uint64_t* zk_draws, size_t n_draws, uint8_t* proof_out, size_t cap,
+                             size_t* len_out) {
   LOCKED_CTX();
   auto pit = g_pks.find(pk_handle);
   if (pit == g_pks.end()) return fail(MH_EINVAL, "mh_marlin_prove: unknown prover key");
@@ -940,7 +1018,8 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   const uint64_t H = pk.H, K = pk.K, X = pk.X, nc = pk.nc;
   const uint64_t nw = nc - X;
   const uint32_t lgH = pk.logH, lgK = pk.logK, lgX = pk.logX;
-  fsh::ChaChaRng zk(zk_seed, zk_rounds);
+  ZkSource zk;
+  if (zk_draws) { zk.draws = zk_draws; zk.n = n_draws; } else zk.chacha = fsh::ChaChaRng(zk_seed, zk_rounds);
   Trace tr(c);
   Fr* S[8]; for (int i = 0; i < 8; i++) S[i] = pk.S[i].fr();
   const Fr* tw = (const Fr*)c.tw;
@@ -981,13 +1060,13 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     KLAUNCH(poly::w_evals_kernel, H, S[2], (const Fr*)(pk.z.fr() + X), (u64)nw, (const Fr*)S[1], (u64)H, (u64)(H / X)); }
   MH_TRY(ntt_device(c, S[2], S[3], lgH, 1));
   // + r * v_H: the reference multiplies by FFT (prover.rs:352); the product is exactly [-r, 0.., 0, r]
-  HFr r_w = fsh::fr_rand(zk);
+  HFr r_w = zk.fr();
   hipLaunchKernelGGL(poly::blind_vanishing_kernel, dim3(1), dim3(64), 0, c.stream, S[3], (u64)H, arg(r_w));
   const uint64_t w_len = H + 1 - X;                                       // (w + r v_H) / v_X, remainder zero
   MH_TRY(div_vanishing(c, pk.w.fr(), S[3], H + 1, X, S[4]));
   auto blind_h = [&](Fr* dst, const Fr* evals, HFr* r_out) -> int {
     MH_TRY(ntt_device(c, evals, dst, lgH, 1));
-    HFr r = fsh::fr_rand(zk); *r_out = r;
+    HFr r = zk.fr(); *r_out = r;
     hipLaunchKernelGGL(poly::blind_vanishing_kernel, dim3(1), dim3(64), 0, c.stream, dst, (u64)H, arg(r));
     return MH_OK;
   };
@@ -1288,6 +1367,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
                    {"h_1", {pk.h1.fr(), h1_len}}, {"g_2", {pk.g2.fr(), g2_len}}, {"h_2", {pk.h2.fr(), h2_len}},
                    {"row", {pk.p_row.fr(), K}}, {"col", {pk.p_col.fr(), K}}, {"a_val", {pk.p_a_val.fr(), K}},
                    {"b_val", {pk.p_b_val.fr(), K}}, {"c_val", {pk.p_c_val.fr(), K}}, {"row_col", {pk.p_row_col.fr(), K}}};
+  if (zk.bad) return fail(MH_EINVAL, "mh_marlin_prove_draws: too few zk draws, or a draw that is not a reduced field element");
   // ---------------- Proof (lib.rs:305-310), flat ToBytes layout ------------------------------------------------
   std::vector<uint8_t> out;
   fsh::Commitment* all[9] = {&c_w, &c_za, &c_zb, &c_mask, &c_t, &c_g1, &c_h1, &c_g2, &c_h2};

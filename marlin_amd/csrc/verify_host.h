@@ -48,11 +48,20 @@ inline bool g1_on_curve(const HG1Affine& a) {
   if (a.inf) return true;
   return a.y.sqr() == a.x.sqr() * a.x + HFq::from_u64(hostff::G1_B);
 }
-// GroupAffine ToBytes image: x || y || infinity byte
+// [r]P = O: `GroupAffine::deserialize` (what a stock arkworks verifier runs on proof bytes before Marlin::verify,
+// src/data_structures.rs:100-110) rejects points outside the prime-order subgroup; BLS12-381's G1 has a cofactor, so an
+// on-curve point may carry a cofactor component (BN254's G1 has cofactor 1: every curve point passes)
+inline bool g1_in_subgroup(const HG1Affine& a) {
+  if (a.inf || hostff::CURVE_ID == 1) return true;
+  uint64_t r[4];
+  for (int i = 0; i < 4; i++) r[i] = HFr::MOD_LIMB(i);
+  return HG1::from_affine(a).mul(r, 4).is_identity();
+}
+// GroupAffine ToBytes image: x || y || infinity byte; the same acceptance rule as wire::get_g1_compressed
 inline bool read_g1(const uint8_t* p, HG1Affine* out) {
   out->inf = p[2 * hostff::FQ_B] != 0;
   if (out->inf) { out->x = HFq::zero(); out->y = HFq::zero(); return true; }
-  return read_fq(p, &out->x) && read_fq(p + hostff::FQ_B, &out->y) && g1_on_curve(*out);
+  return read_fq(p, &out->x) && read_fq(p + hostff::FQ_B, &out->y) && g1_on_curve(*out) && g1_in_subgroup(*out);
 }
 constexpr size_t G1_TB = 2 * hostff::FQ_B + 1;       // 97 (BLS12-381) / 65 (BN254)
 

@@ -158,6 +158,26 @@ def prove(pk, instance_mont, witness_mont, zk_seed, zk_rounds=20):
     return bytes(out[:n.value])
 
 
+def zk_draw_count(pk):
+    n = C.c_size_t()
+    _lib.check(_lib.load().mh_marlin_zk_draw_count(pk.handle, C.byref(n)), "mh_marlin_zk_draw_count")
+    return n.value
+
+
+def prove_draws(pk, instance_mont, witness_mont, zk_draws_mont):
+    """Marlin::prove with the caller's own `zk_rng` draws ((zk_draw_count(pk), 4) uint64 Montgomery, consumption order):
+    the entry point for a host whose rng is not a ChaCha generator (src/lib.rs:151-155)."""
+    x = np.ascontiguousarray(instance_mont, dtype=np.uint64)
+    w = np.ascontiguousarray(witness_mont, dtype=np.uint64)
+    d = np.ascontiguousarray(zk_draws_mont, dtype=np.uint64)
+    assert x.shape == (pk.num_instance, 4) and w.shape == (pk.num_constraints - pk.num_instance, 4) and d.ndim == 2 and d.shape[1] == 4
+    out = (C.c_uint8 * 4096)()
+    n = C.c_size_t()
+    _lib.check(_lib.load().mh_marlin_prove_draws(pk.handle, x.ctypes.data, w.ctypes.data, d.ctypes.data, d.shape[0], out, 4096,
+                                                 C.byref(n)), "mh_marlin_prove_draws")
+    return bytes(out[:n.value])
+
+
 def prove_dev(pk, d_instance, d_witness, zk_seed, zk_rounds=20):
     """Marlin::prove with the formatted input and the witness already on the device (DeviceBuffer or device pointers):
     mh_marlin_prove_dev.  Returns the flat ToBytes-layout proof."""

@@ -44,6 +44,15 @@ pub fn g1_slice_to_limbs(v: &[G1Affine]) -> Vec<u64> {
     out
 }
 
+/// The same, `None` when a base is the identity (legal for `VariableBaseMSM`, not expressible at this boundary: the
+/// caller then keeps the host path instead of panicking).
+pub fn g1_slice_to_limbs_checked(v: &[G1Affine]) -> Option<Vec<u64>> {
+    if v.iter().any(|p| p.infinity) {
+        return None;
+    }
+    Some(g1_slice_to_limbs(v))
+}
+
 /// Jacobian X || Y || Z (18 limbs, Z = 0 for the identity) -> `G1Projective`.
 pub fn g1_from_jacobian_limbs(l: &[u64]) -> G1Projective {
     G1Projective::new(fq_from_mont(&l[0..6]), fq_from_mont(&l[6..12]), fq_from_mont(&l[12..18]))

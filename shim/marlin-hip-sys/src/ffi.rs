@@ -1,6 +1,6 @@
 //! Raw bindings: one declaration per prototype of `include/marlin_hip.h`, in the header's order.
 //! `tests/test_capi_symbols.py` (Python side of this repository) checks header <-> exported symbols;
-//! `shim/tests/ffi_symbols.rs` takes the address of every item below so that a missing symbol is a
+//! `tests/ffi_symbols.rs` takes the address of every item below so that a missing symbol is a
 //! link error, not a run-time surprise.
 //!
 //! UNCOMPILED (no Rust toolchain in the development image) -- see Cargo.toml.
@@ -86,6 +86,8 @@ extern "C" {
     pub fn mh_msm_dev(bases_handle: u64, base_offset: usize, d_scalars: *const c_void, scalars_are_montgomery: c_int, n: usize, out_xyz_mont: *mut u64) -> c_int;
     pub fn mh_msm_batch_dev(njobs: usize, bases_handles: *const u64, base_offsets: *const usize, d_scalars: *const *const c_void,
                             ns: *const usize, scalars_are_montgomery: c_int, out_xyz_mont: *mut u64) -> c_int;
+    pub fn mh_msm_batch_sharded_dev(njobs: usize, bases_handles: *const u64, base_offsets: *const usize, d_scalars: *const *const c_void,
+                                    ns: *const usize, scalars_are_montgomery: c_int, out_xyz_mont: *mut u64) -> c_int;
     pub fn mh_g1_to_affine(xyz_mont: *const u64, xy_mont_out: *mut u64, is_infinity_out: *mut c_int) -> c_int;
     pub fn mh_g1_sum(xyz_points: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
 
@@ -108,6 +110,9 @@ extern "C" {
                            zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_prove_dev(pk: u64, d_instance_mont: *const c_void, d_witness_mont: *const c_void, zk_seed32: *const u8,
                                zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
+    pub fn mh_marlin_zk_draw_count(pk: u64, n_out: *mut usize) -> c_int;
+    pub fn mh_marlin_prove_draws(pk: u64, instance_mont: *const u64, witness_mont: *const u64, zk_draws_mont: *const u64, n_draws: usize,
+                                 proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_verify(vk_bytes: *const u8, vk_len: usize, vk: *const mh_verifier_key, pc: c_int, public_input_mont: *const u64, n_public: usize,
                             flat_proof: *const u8, proof_len: usize, ok_out: *mut c_int) -> c_int;
     pub fn mh_pairing_product_is_one(g1_xy_mont: *const u64, g2_xy_mont: *const u64, n: usize, is_one_out: *mut c_int) -> c_int;

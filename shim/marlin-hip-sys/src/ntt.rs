@@ -7,6 +7,9 @@
 //! the domain size; natural order in and out; the inverse multiplies by n^-1; coset variants multiply by powers of
 //! `F::multiplicative_generator()` (7 for BLS12-381 Fr) before / after.
 //!
+//! Lives in the leaf crate so that the patched `ark-poly` depends on `marlin-hip-sys` only (no cycle through
+//! `marlin-hip` -> `ark-poly`).
+//!
 //! UNCOMPILED (see Cargo.toml).
 use crate::convert::{fr_slice_to_limbs, limbs_to_fr_slice};
 use crate::{check, ensure_init, ffi};

@@ -7,17 +7,16 @@
 //! (`VariableBaseMSM` upstream), exactly as this repository's `prover.hip: kzg_commit` does.
 //!
 //! UNCOMPILED (see Cargo.toml).
-use crate::convert::{fr_slice_to_limbs, g1_from_jacobian_limbs, g1_slice_to_limbs};
+use crate::convert::{fr_slice_to_limbs, g1_from_jacobian_limbs};
 use crate::{check, ensure_init, ffi, HipError};
 use ark_bls12_381::{Bls12_381, Fr, G1Affine, G1Projective};
 use ark_ec::msm::VariableBaseMSM;
-use ark_ec::{AffineCurve, ProjectiveCurve};
+use ark_ec::ProjectiveCurve;
 use ark_ff::{PrimeField, Zero};
 use ark_poly::univariate::DensePolynomial;
 use ark_poly::UVPolynomial;
 use ark_poly_commit::kzg10;
 use ark_std::rand::RngCore;
-use std::collections::HashMap;
 use std::sync::Mutex;
 
 /// MSMs shorter than this stay on the host: a launch + PCIe round trip costs more than ~2^10 host additions.
@@ -36,7 +35,9 @@ impl GpuSrs {
     /// the wrappers call this.
     pub fn upload(powers_of_g: &[G1Affine], precompute: bool) -> Result<Self, HipError> {
         ensure_init();
-        let limbs = g1_slice_to_limbs(powers_of_g);
+        // an SRS never contains the identity; a base set that does cannot cross this boundary (no infinity flag)
+        let limbs = crate::convert::g1_slice_to_limbs_checked(powers_of_g)
+            .ok_or(HipError::Unsupported("base set contains the identity"))?;
         let mut handle = 0u64;
         check(unsafe { ffi::mh_bases_upload(ffi::MH_CURVE_BLS12_381_G1, limbs.as_ptr(), powers_of_g.len(), &mut handle) })?;
         if precompute && powers_of_g.len() >= (1 << 14) {
@@ -69,30 +70,78 @@ impl Drop for GpuSrs {
     }
 }
 
-/// Process-wide cache: committer keys are plain upstream structs (no room for a handle), so the device copy of
-/// `ck.powers` is looked up by the address and length of the slice.  Entries live as long as the process (an
-/// `IndexProverKey` is proved against many times); `forget` drops one when its key is dropped.
-pub(crate) struct SrsCache(Mutex<HashMap<(usize, usize), std::sync::Arc<GpuSrs>>>);
+/// Process-wide cache of device copies of `ck.powers`.  Committer keys are plain upstream structs (no room for a handle:
+/// `Marlin`'s `IndexProverKey` embeds `PC::CommitterKey` as is), so the device copy is found through the slice itself.
+/// The key is (address, length) PLUS a fingerprint of the contents -- the points at indices 0, 1, len / 2, len - 1 --
+/// checked on every lookup: a `Vec` that was freed and whose address and length were reused by a different base vector
+/// (another tau: every point differs) misses, is uploaded afresh and replaces the stale entry.  The cache is bounded
+/// (`MAX_ENTRIES`, least recently used out first; the device memory goes when the last `Arc` does), so distinct keys do
+/// not accumulate uploads and window tables for the life of the process.
+pub(crate) struct SrsCache(Mutex<Vec<CacheEntry>>);
+struct CacheEntry {
+    ptr: usize,
+    len: usize,
+    fingerprint: [G1Affine; 4],
+    srs: std::sync::Arc<GpuSrs>,
+    last_use: u64,
+}
+const MAX_ENTRIES: usize = 8;
+
+fn fingerprint(powers: &[G1Affine]) -> [G1Affine; 4] {
+    let n = powers.len();
+    [powers[0], powers[1.min(n - 1)], powers[n / 2], powers[n - 1]]
+}
 
 pub(crate) fn srs_cache() -> &'static SrsCache {
     static CACHE: std::sync::OnceLock<SrsCache> = std::sync::OnceLock::new();
-    CACHE.get_or_init(|| SrsCache(Mutex::new(HashMap::new())))
+    CACHE.get_or_init(|| SrsCache(Mutex::new(Vec::new())))
 }
 
+static CLOCK: std::sync::atomic::AtomicU64 = std::sync::atomic::AtomicU64::new(0);
+
 impl SrsCache {
+    /// The device copy of `powers` (uploading and building the window table on a miss).  Called by the wrappers'
+    /// `trim` -- where upstream fixes the SRS slice -- and again by `commit` / `open`, which then hit.
     pub(crate) fn get_or_upload(&self, powers: &[G1Affine]) -> Result<std::sync::Arc<GpuSrs>, HipError> {
-        let key = (powers.as_ptr() as usize, powers.len());
+        assert!(!powers.is_empty(), "empty committer key");
+        let (ptr, len, fp) = (powers.as_ptr() as usize, powers.len(), fingerprint(powers));
+        let now = CLOCK.fetch_add(1, std::sync::atomic::Ordering::Relaxed);
         let mut m = self.0.lock().unwrap();
-        if let Some(s) = m.get(&key) {
-            return Ok(s.clone());
+        if let Some(i) = m.iter().position(|e| e.ptr == ptr && e.len == len) {
+            if m[i].fingerprint == fp {
+                m[i].last_use = now;
+                return Ok(m[i].srs.clone());
+            }
+            m.swap_remove(i); // same address and length, other contents: the old vector is gone
         }
-        let s = std::sync::Arc::new(GpuSrs::upload(powers, true)?);
-        m.insert(key, s.clone());
-        Ok(s)
+        let srs = std::sync::Arc::new(GpuSrs::upload(powers, true)?);
+        if m.len() >= MAX_ENTRIES {
+            let oldest = (0..m.len()).min_by_key(|&i| m[i].last_use).unwrap();
+            m.swap_remove(oldest);
+        }
+        m.push(CacheEntry { ptr, len, fingerprint: fp, srs: srs.clone(), last_use: now });
+        Ok(srs)
+    }
+
+    /// The entry whose allocation CONTAINS `slice`, as (device copy, offset) -- never uploads.  Used by the transparent
+    /// MSM hook, which must not create device state for arbitrary base slices.
+    pub(crate) fn resolve_containing(&self, slice: &[G1Affine]) -> Option<(std::sync::Arc<GpuSrs>, usize)> {
+        let (lo, bytes) = (slice.as_ptr() as usize, core::mem::size_of::<G1Affine>());
+        let m = self.0.lock().unwrap();
+        for e in m.iter() {
+            if lo >= e.ptr && (lo - e.ptr) % bytes == 0 {
+                let off = (lo - e.ptr) / bytes;
+                if off + slice.len() <= e.len {
+                    return Some((e.srs.clone(), off));
+                }
+            }
+        }
+        None
     }
 
     pub(crate) fn forget(&self, powers: &[G1Affine]) {
-        self.0.lock().unwrap().remove(&(powers.as_ptr() as usize, powers.len()));
+        let (ptr, len) = (powers.as_ptr() as usize, powers.len());
+        self.0.lock().unwrap().retain(|e| !(e.ptr == ptr && e.len == len));
     }
 }
 
@@ -181,29 +230,60 @@ pub fn kzg_open_with_witness(
     Ok(kzg10::Proof { w: w.into_affine(), random_v })
 }
 
-/// Hook for the optional patched ark-ec (vendor/ark-ec-hip/msm_hip.patch): `Some(result)` when `G` is BLS12-381 G1
-/// and the MSM is large enough for the device, `None` to let ark-ec's own Pippenger run.  `scalars` are canonical
-/// `BigInteger256`s (what `VariableBaseMSM::multi_scalar_mul` receives), passed with `scalars_are_montgomery = 0`.
-/// The base slice is resolved to (handle, offset) through `srs_cache`: slices of one `powers_of_g` allocation share
-/// the upload made for the enclosing allocation's first sighting, later sub-slices are uploaded on demand.
-pub fn msm_hook<G: AffineCurve + 'static>(
-    bases: &[G],
-    scalars: &[<G::ScalarField as PrimeField>::BigInt],
-) -> Option<G::Projective> {
-    use std::any::{Any, TypeId};
+/// Hook for the optional patched ark-ec (vendor/ark-ec-hip/msm_hip.patch adds a run-time hook REGISTRY to ark-ec; ark-ec
+/// cannot depend on this crate -- ark-bls12-381, which the leaf crate needs, depends on ark-ec).  [`install_msm_hook`]
+/// registers [`msm_hook_erased`].  The hook answers only for base slices that lie inside a committer key registered by
+/// `PC::trim` of the wrappers (`SrsCache::resolve_containing`: no upload, no table build, no device state for arbitrary
+/// slices), checks the slice's end points against the device copy, and declines -- `false`, ark-ec's own Pippenger runs --
+/// for any other curve, for short MSMs, for unknown slices, for a mismatch, or on a library error.  `scalars` are canonical
+/// `BigInteger256`s (what `multi_scalar_mul` receives), passed with `scalars_are_montgomery = 0`.  The identity cannot be
+/// an uploaded base (`GpuSrs::upload` refuses it), so registered slices contain none.
+pub fn msm_hook(bases: &[G1Affine], scalars: &[[u64; 4]]) -> Option<G1Projective> {
     let n = core::cmp::min(bases.len(), scalars.len());
-    if TypeId::of::<G>() != TypeId::of::<G1Affine>() || n < GPU_MSM_THRESHOLD {
+    if n < GPU_MSM_THRESHOLD {
         return None;
     }
-    // SAFETY: G == G1Affine was just checked
-    let bases: &[G1Affine] = unsafe { core::slice::from_raw_parts(bases.as_ptr() as *const G1Affine, n) };
-    let srs = srs_cache().get_or_upload(bases).ok()?;
+    let bases = &bases[..n];
+    let (srs, offset) = srs_cache().resolve_containing(bases)?;
+    // the device copy must still be this memory's image: compare the first and the last point of the slice
+    let mut ends = [0u64; 24];
+    check(unsafe { ffi::mh_bases_download(srs.handle, offset, 1, ends.as_mut_ptr()) }).ok()?;
+    check(unsafe { ffi::mh_bases_download(srs.handle, offset + n - 1, 1, ends[12..].as_mut_ptr()) }).ok()?;
+    let want = crate::convert::g1_slice_to_limbs_checked(&[bases[0], bases[n - 1]])?;
+    if want[..] != ends[..] {
+        return None;
+    }
     let mut limbs = Vec::with_capacity(n * 4);
     for s in &scalars[..n] {
-        limbs.extend_from_slice(s.as_ref());
+        limbs.extend_from_slice(s);
     }
     let mut out = [0u64; 18];
-    check(unsafe { ffi::mh_msm(srs.handle, 0, limbs.as_ptr(), 0, n, out.as_mut_ptr()) }).ok()?;
-    let p: G1Projective = g1_from_jacobian_limbs(&out);
-    (Box::new(p) as Box<dyn Any>).downcast::<G::Projective>().ok().map(|b| *b)
+    check(unsafe { ffi::mh_msm(srs.handle, offset, limbs.as_ptr(), 0, n, out.as_mut_ptr()) }).ok()?;
+    Some(g1_from_jacobian_limbs(&out))
+}
+
+/// The type-erased form the patched ark-ec calls: `g` identifies `G` (only `ark_bls12_381::G1Affine` is served), `bases` /
+/// `scalars` point at `n_bases` `G` values / `n_scalars` `BigInteger256`s, `out` at an uninitialised `G::Projective`.
+pub fn msm_hook_erased(g: std::any::TypeId, bases: *const u8, n_bases: usize, scalars: *const u64, n_scalars: usize, out: *mut u8) -> bool {
+    if g != std::any::TypeId::of::<G1Affine>() {
+        return false;
+    }
+    // SAFETY: the patched `multi_scalar_mul::<G>` passes its own argument slices and `G == G1Affine` was just checked;
+    // `BigInteger256` is a newtype of `[u64; 4]`
+    let b: &[G1Affine] = unsafe { core::slice::from_raw_parts(bases as *const G1Affine, n_bases) };
+    let s: &[[u64; 4]] = unsafe { core::slice::from_raw_parts(scalars as *const [u64; 4], n_scalars) };
+    match msm_hook(b, s) {
+        Some(p) => {
+            unsafe { core::ptr::write(out as *mut G1Projective, p) };
+            true
+        }
+        None => false,
+    }
+}
+
+/// Registers the hook with the patched ark-ec (a no-op route unless `[patch.crates-io] ark-ec` is enabled in Cargo.toml).
+#[cfg(feature = "ark-ec-hook")]
+pub fn install_msm_hook() {
+    ensure_init();
+    ark_ec::msm::set_multi_scalar_mul_hook(Some(msm_hook_erased));
 }

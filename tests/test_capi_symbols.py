@@ -43,13 +43,13 @@ def test_product_does_not_use_oracle():
 
 
 def test_rust_shim_binds_the_whole_header():
-    """shim/src/ffi.rs (uncompiled Rust side of the boundary) declares exactly the header's entry points, and
-    shim/tests/ffi_symbols.rs takes the address of each of them."""
+    """shim/marlin-hip-sys/src/ffi.rs (uncompiled Rust side of the boundary) declares exactly the header's entry points, and
+    its tests/ffi_symbols.rs takes the address of each of them."""
     names = _declared()
-    ffi = open(os.path.join(ROOT, "shim", "src", "ffi.rs")).read()
+    ffi = open(os.path.join(ROOT, "shim", "marlin-hip-sys", "src", "ffi.rs")).read()
     bound = sorted(set(re.findall(r"pub fn (mh_[a-z0-9_]+)\s*\(", ffi)))
     assert bound == names, (set(names) - set(bound), set(bound) - set(names))
-    link = open(os.path.join(ROOT, "shim", "tests", "ffi_symbols.rs")).read()
+    link = open(os.path.join(ROOT, "shim", "marlin-hip-sys", "tests", "ffi_symbols.rs")).read()
     for n in names:
         assert "%s as usize" % n in link, n
 
@@ -82,3 +82,45 @@ def test_c_example_proves_and_verifies(tmp_path):
     r = subprocess.run([_build_c_example(tmp_path), "12"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "verify = 1, verify(wrong input) = 0" in r.stdout
+
+
+def test_rust_crates_have_no_dependency_cycle():
+    """the patched ark-poly depended on marlin-hip, which depends on ark-poly -- cargo rejects that before
+    compiling a line.  The hook now lives in the LEAF crate marlin-hip-sys: read the manifests / the patch and check the
+    package graph (path dependencies and the [patch] redirections) for cycles."""
+    shim = os.path.join(ROOT, "shim")
+
+    def deps(path):
+        out, on = [], False
+        for line in open(path):
+            t = line.strip()
+            if t.startswith("["):
+                on = t in ("[dependencies]", "[dev-dependencies]")
+                continue
+            m = re.match(r"^([A-Za-z0-9_-]+)\s*=", t)
+            if on and m:
+                out.append(m.group(1))
+        return out
+    graph = {"marlin-hip": deps(os.path.join(shim, "Cargo.toml")), "marlin-hip-sys": deps(os.path.join(shim, "marlin-hip-sys", "Cargo.toml"))}
+    patch = open(os.path.join(shim, "vendor", "ark-poly-hip", "radix2_hip.patch")).read()
+    added = re.findall(r"^\+([A-Za-z0-9_-]+)\s*=\s*\{", patch, flags=re.M)
+    assert added == ["marlin-hip-sys"], added
+    # upstream edges that matter (ark-* 0.3 manifests, recalled): none of these reaches ark-poly
+    graph.update({"ark-poly": ["ark-ff", "ark-serialize", "ark-std"] + added, "ark-bls12-381": ["ark-ec", "ark-ff", "ark-std"],
+                  "ark-bn254": ["ark-ec", "ark-ff", "ark-std"], "ark-ec": ["ark-ff", "ark-serialize", "ark-std"],
+                  "ark-ff": ["ark-serialize", "ark-std"], "ark-serialize": ["ark-std"], "ark-std": [],
+                  "ark-poly-commit": ["ark-poly", "ark-ec", "ark-ff", "ark-serialize", "ark-std", "ark-relations"],
+                  "ark-relations": ["ark-ff", "ark-std"], "ark-marlin": ["ark-poly-commit", "ark-poly", "ark-relations", "ark-ff", "ark-serialize", "ark-std"]})
+    assert "ark-poly" not in graph["marlin-hip-sys"] and "marlin-hip" not in graph["marlin-hip-sys"]
+    state = {}
+
+    def visit(n, stack):
+        if state.get(n) == 2:
+            return
+        assert state.get(n) != 1, "dependency cycle: %s" % " -> ".join(stack + [n])
+        state[n] = 1
+        for d in graph.get(n, []):
+            visit(d, stack + [n])
+        state[n] = 2
+    for n in list(graph):
+        visit(n, [])

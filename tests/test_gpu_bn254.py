@@ -29,3 +29,10 @@ def test_bn254_marlin_and_sonic_provers():
     parity, general R1CS, 2^20-constraint proofs verified by the oracle (BASELINE.json configs[4])."""
     out = _run(["tests/test_gpu_marlin.py"], extra=["-k", "not golden and not two_ranks"])
     assert " passed" in out
+
+
+def test_bn254_sonic_2p20_whole_proof_pinned():
+    """BASELINE configs[4] byte-pinned: every commitment, evaluation and opening of a 2^20-constraint BN254 + SonicKZG10
+    proof recomputed on the CPU (tests/cpu_open.py over libref_hotpath_bn254.so)."""
+    out = _run(["tests/test_gpu_parity_pins.py"], extra=["-k", "bn254_sonic"])
+    assert "1 passed" in out

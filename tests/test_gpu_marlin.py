@@ -196,10 +196,13 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,log_n,pc", [(2, 12, "marlin"), (3, 12, "marlin"), (2, 16, "sonic"), (4, 16, "marlin")])
+@pytest.mark.parametrize("world,log_n,pc", [(2, 12, "marlin"), (3, 12, "marlin"), (2, 16, "sonic"), (4, 16, "marlin"),
+                                            (8, 12, "marlin"), (8, 16, "marlin")])
 def test_sharded_prove_ranks_equal_single(gpu, tmp_path, world, log_n, pc):
-    """MSM sharding by bucket range across 2, 3 and 4 ranks (gloo exchange, all ranks on the one GPU of this box), both PC
-    schemes, yields the very same proof bytes as the unsharded prover."""
+    """MSM sharding by bucket range across 2, 3, 4 and 8 ranks (gloo exchange, all ranks on the one GPU of this box), both PC
+    schemes, yields the very same proof bytes as the unsharded prover.  At 2^12 the window table has 2 partitions (c = 13:
+    2^12 buckets), fewer than 3, 4 or 8 ranks: those groups run unsharded on every rank and rank 0's copy counts; at 2^16
+    it has 64 and every rank owns 8 (world = 8, the target of BASELINE configs[3])."""
     import subprocess, sys
     a, b = 0x1234567, 0x7654321
     n = 1 << log_n
@@ -215,6 +218,59 @@ def test_sharded_prove_ranks_equal_single(gpu, tmp_path, world, log_n, pc):
         assert p.wait(timeout=300) == 0
     for r in range(world):
         assert open(tmp_path / ("proof%d.bin" % r), "rb").read() == want
+
+
+SKEW_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+import marlin_amd as M
+from marlin_amd import dist as MD
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+M.init(0)
+n = %(n)d
+one = M.api.FR_ONE_MONT
+tau = np.array([0x1234567, 0, 0, 0], dtype=np.uint64)          # any field element serves as tau here
+B = M.Bases.srs_powers(tau, n)
+B.precompute(%(c)d)
+rng = np.random.default_rng(7)
+dense = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+hot = dense.copy()
+hot[: n - n // 8] = np.array([0x1234, 0, 0, 0], dtype=np.uint64)   # Montgomery words: ONE non-zero digit, bucket 0x1233
+d_dense, d_hot = M.DeviceBuffer.from_numpy(dense), M.DeviceBuffer.from_numpy(hot)
+jobs = [(B, 0, d_hot, n), (B, 0, d_dense, n), (B, 5, d_hot, n - 5)]
+single = M.msm_batch_dev(jobs, montgomery=True)
+fb0, vb0 = M.msm_path_counts()
+MD.enable_sharded_prove(dist)
+sharded = M.msm_batch_sharded_dev(jobs, montgomery=True)
+fb1, vb1 = M.msm_path_counts()
+aff = lambda a: [tuple(M.g1_to_affine(r)[0]) for r in a]
+assert aff(single) == aff(sharded), "rank %%d: sharded result differs" %% rank
+open(os.path.join(%(out)r, "r%%d.txt" %% rank), "w").write("%%d %%d" %% (fb1 - fb0, vb1 - vb0))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_msm_with_skewed_digits(gpu, tmp_path, world):
+    """ADVICE r02 (capi.hip skew fallback x sharding): 7/8 of the scalars are ONE value whose Montgomery words have a single
+    non-zero digit, so 7/8 of the entries fall into one bucket -- which lives in exactly one rank's partitions.  Only that
+    rank's largest-bucket test trips: it alone leaves the fixed-base path and computes the WHOLE sums of the group on the
+    variable-base path, while its peers return shares.  The share / whole flags in the all_gather payload make every rank
+    take the whole results.  Checked against the unsharded batch on every rank; the path counters show that the ranks really
+    did disagree."""
+    import subprocess, sys
+    script = tmp_path / "skew_worker.py"
+    script.write_text(SKEW_WORKER % {"root": ROOT, "out": str(tmp_path), "n": 1 << 16, "c": 16})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29713 + world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    counts = [tuple(int(x) for x in open(tmp_path / ("r%d.txt" % r)).read().split()) for r in range(world)]
+    assert any(vb > 0 for _, vb in counts), counts           # some rank fell back to the variable-base path ...
+    assert any(vb == 0 for _, vb in counts), counts          # ... and some rank did not: the decision differed across ranks
 
 
 def _random_r1cs(nc, ni_raw, seed):
@@ -418,3 +474,29 @@ def test_bench_gpus_2_runs_two_sharded_ranks(gpu):
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["constraints"] == 1 << 14
+
+
+@pytest.mark.parametrize("pc", ["marlin", "sonic"])
+def test_prove_with_caller_supplied_zk_draws(gpu, pc):
+    """`Marlin::prove` is generic over `R: RngCore` (src/lib.rs:151-155).  mh_marlin_prove_draws takes the field elements
+    the caller's rng produced, in consumption order; fed with the draws of ChaCha20Rng(SEED) --
+    generated independently by tests/zkstream.py -- it must return the very proof mh_marlin_prove(SEED) returns; one draw
+    too few, or a draw >= r, is MH_EINVAL."""
+    import numpy as np
+    import marlin_amd as M
+    from tests import zkstream as ZS
+    n = 1 << 12
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc=pc)
+    ncp, ni, mats, inst, wit = GM.dummy_circuit(0x1234567, 0x7654321, 10, n)
+    pk = GM.index(srs, ncp, ni, mats, pc=pc)
+    want = GM.prove(pk, inst, wit, SEED)
+    nd = GM.zk_draw_count(pk)
+    assert nd == 3 + 3 * pk.H + (12 if pc == "sonic" else 15)
+    draws = ZS.fr_draws(SEED, nd)
+    assert GM.prove_draws(pk, inst, wit, draws) == want
+    with pytest.raises(M.MarlinHipError):
+        GM.prove_draws(pk, inst, wit, draws[:-1])
+    bad = draws.copy()
+    bad[5] = np.array([0xffffffffffffffff] * 4, dtype=np.uint64)
+    with pytest.raises(M.MarlinHipError):
+        GM.prove_draws(pk, inst, wit, bad)

@@ -4,9 +4,12 @@
   (tests/golden/marlin_proofs_large.json, tests/golden/make_golden.py large);
 * the device's `DensePolynomial::rand` (rng.cuh: ChaCha blocks in parallel + rejection sampling as stream
   compaction) against the sequential `Fp256::rand` stream at 2^16 / 2^18 (3|H| draws, prover.rs:370-380);
-* at 2^18 (configs[1]) and 2^20 (configs[2]): every one of the 9 commitments (11 G1 elements) of the proof recomputed
-  on the CPU from the device-exported polynomials with the C restatement's Pippenger (oracle/c/ref_hotpath.c) plus the
-  hiding part re-derived from the zk_rng stream -- "verifies" becomes "every commitment is the unique right point".
+* at 2^18 (configs[1]), 2^20 (configs[2]), 2^22 (configs[3] on one GPU) and, in the BN254 subprocess, BN254 +
+  SonicKZG10 at 2^20 (configs[4]): the WHOLE proof -- 9 commitments (11 G1 elements), 4 evaluations, both opening
+  proofs W_beta / W_gamma / random_v -- recomputed on the CPU from the device-exported polynomials the way the
+  reference computes them (tests/cpu_open.py: one MSM per KZG10::commit / witness with the C restatement's Pippenger,
+  linear combinations and synthetic division on the CPU, hiding parts re-derived from the zk_rng stream) and compared
+  byte for byte -- "verifies" becomes "every group element and field element of the proof is the unique right one".
 """
 import hashlib
 import json
@@ -68,53 +71,60 @@ def test_device_mask_polynomial_equals_sequential_stream(gpu, log_n):
     assert np.array_equal(got, want), "first mismatch at coefficient %d" % int(np.nonzero((got != want).any(axis=1))[0][0])
 
 
-@BLS
-@pytest.mark.parametrize("log_n", [18, 20])
-def test_every_commitment_pinned_by_cpu_msm(gpu, log_n):
-    from oracle import cref
-    from tests import zkstream as ZS
-    from tests.util import limbs_to_fq
-    from tests.verify_adapter import parse_proof
+ALL_LABELS = ["w", "z_a", "z_b", "mask_poly", "t", "g_1", "h_1", "g_2", "h_2", "row", "col", "a_val", "b_val", "c_val", "row_col"]
+
+
+def _whole_proof_pinned(log_n, pc):
+    """prove on the device, export the 15 polynomials, recompute on the CPU -- the reference's way, one MSM per
+    KZG10::commit / witness, tests/cpu_open.py -- all 9 commitments (11 G1 elements for MarlinKZG10), the 4 evaluations
+    and BOTH opening proofs (W_beta, W_gamma, random_v): the flat proof bytes must be identical."""
+    from oracle import cref, marlin as MR
+    from tests import zkstream as ZS, cpu_open as CO
     rng = FS.test_rng()
     a, b = FS.fr_rand(rng), FS.fr_rand(rng)
     n = 1 << log_n
-    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA)
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc=pc)
     ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
-    pk = GM.index(srs, ncp, ni, mats)
-    proof = parse_proof(GM.prove(pk, inst, wit, SEED))
+    pk = GM.index(srs, ncp, ni, mats, pc=pc)
+    flat = GM.prove(pk, inst, wit, SEED)
     H, K, D = pk.H, pk.K, srs.max_degree
     bases = srs.powers_of_g.download()
     assert bases.shape == (D + 1, 2 * F.FQ_LIMBS64)
-    threads = os.cpu_count() or 1
-    zk = ZS.prove_zk_draws(SEED, H)
-    gamma_pows = [EC.scalar_mul(EC.G1_GEN, GAMMA * pow(TAU, i, F.R_MOD) % F.R_MOD) for i in range(3)]
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cpc = CO.CpuPC(bases, D, TAU, GAMMA, threads)
+    polys = {l: pk.get_poly(l) for l in ALL_LABELS}
+    got = CO.recompute_proof(cpc, polys, ZS.prove_zk_draws(SEED, H), pk.vk_bytes(), [a * b % F.R_MOD], flat, H, K, pc)
+    want = parse_proof_flat(flat, pc)
+    bad = [(r, i) for r in range(3) for i in range(len(want.commitments[r])) if got.commitments[r][i] != want.commitments[r][i]]
+    assert not bad, "commitments (round, index) differ: %r" % bad
+    assert got.evaluations == want.evaluations
+    assert got.pc_proof[0] == want.pc_proof[0], "opening at beta (W, random_v)"
+    assert got.pc_proof[1] == want.pc_proof[1], "opening at gamma (W, random_v)"
+    assert MR.proof_bytes(got) == flat
 
-    def commit(label, offset, blind):
-        coeffs = pk.get_poly(label)
-        xyz = cref.msm(bases[offset:offset + len(coeffs)], coeffs, montgomery=True, threads=threads)
-        xy, inf = cref.g1_to_affine(xyz)
-        L = F.FQ_LIMBS64
-        pt = None if inf else (limbs_to_fq(xy[:L]), limbs_to_fq(xy[L:]))
-        if blind is not None:
-            pt = EC.add(pt, EC.msm_naive(gamma_pows, blind))
-        return pt
 
-    c1, c2, c3 = proof.commitments
-    want = {
-        "w": (c1[0], None, zk["blind_w"], None), "z_a": (c1[1], None, zk["blind_za"], None), "z_b": (c1[2], None, zk["blind_zb"], None),
-        "mask_poly": (c1[3], None, None, None), "t": (c2[0], None, None, None),
-        "g_1": (c2[1], H - 2, zk["blind_g1"], zk["blind_g1_shifted"]), "h_1": (c2[2], None, None, None),
-        "g_2": (c3[0], K - 2, None, None), "h_2": (c3[1], None, None, None),
-    }
-    bad = []
-    for label, ((comm, shifted), bound, blind, sblind) in want.items():
-        if commit(label, 0, blind) != comm:
-            bad.append(label)
-        if bound is None:
-            assert shifted is None
-        elif shifted is None or commit(label, D - bound, sblind) != shifted[0]:
-            bad.append(label + " (shifted)")
-    assert not bad, bad
+def parse_proof_flat(flat, pc):
+    from tests.verify_adapter import parse_proof
+    return parse_proof(flat, pc)
+
+
+@BLS
+@pytest.mark.parametrize("log_n", [18, 20, 22])
+def test_whole_proof_pinned_by_cpu_recomputation(gpu, log_n):
+    """BASELINE configs[1], [2] and (one GPU) [3]: MarlinKZG10 on BLS12-381."""
+    _whole_proof_pinned(log_n, "marlin")
+
+
+@pytest.mark.skipif(F.CURVE != "bn254", reason="BASELINE configs[4] is BN254; runs in tests/test_gpu_bn254.py's subprocess")
+def test_whole_proof_pinned_bn254_sonic_2p20(gpu):
+    """BASELINE configs[4]: BN254 + SonicKZG10 at 2^20 constraints, against libref_hotpath_bn254.so."""
+    _whole_proof_pinned(20, "sonic")
+
+
+@BLS
+def test_whole_proof_pinned_sonic_2p16_reference_bench_shape(gpu):
+    """benches/bench.rs:75-83's own shape (2^16 constraints, SonicKZG10, BLS12-381)."""
+    _whole_proof_pinned(16, "sonic")
 
 
 @BLS

@@ -51,3 +51,34 @@ def test_c_msm_known_dlog_large():
     k = sum(s * a for s, a in zip(sc, dl)) % F.R_MOD
     out = cref.msm(b, fr_to_np(sc), threads=8)
     assert jac_np_to_affine(out) == EC.scalar_mul(EC.G1_GEN, k)
+
+
+def test_c_poly_helpers_match_python():
+    """the dense-polynomial helpers behind the large-size opening pins (tests/test_gpu_parity_pins.py): linear
+    combination, synthetic division by (X - z), Horner evaluation, shifted accumulation"""
+    a, b = rand_fr(50, 1), rand_fr(30, 2)
+    c1, c2 = 5, F.R_MOD - 3
+    got = np_to_fr(cref.lincomb([(c1, fr_to_np(a)), (c2, fr_to_np(b))], threads=2))
+    assert got == [(c1 * a[i] + c2 * (b[i] if i < 30 else 0)) % F.R_MOD for i in range(50)]
+    assert np_to_fr(cref.lincomb([(c1, fr_to_np(a))], n=20)) == [c1 * x % F.R_MOD for x in a[:20]]
+    for z in (0, 1, 123456789, F.R_MOD - 1):
+        q, rem = cref.div_linear(fr_to_np(a), z)
+        assert np_to_fr(q) == OP.divide_by_linear(a, z)
+        assert rem == OP.poly_eval(a, z) == cref.poly_eval(fr_to_np(a), z)
+    q, rem = cref.div_linear(fr_to_np(a[:1]), 7)
+    assert len(q) == 0 and rem == a[0]
+    dst = fr_to_np(a)
+    cref.add_at(dst, 20, fr_to_np(b))
+    assert np_to_fr(dst) == [(a[i] + (b[i - 20] if i >= 20 else 0)) % F.R_MOD for i in range(50)]
+
+
+def test_c_restatement_on_bn254():
+    """the same pins for the BN254 build (libref_hotpath_bn254.so; BASELINE.json configs[4]); the oracle picks its curve
+    at import, so the checks run in a subprocess"""
+    import os, subprocess, sys
+    if F.CURVE == "bn254":
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_oracle_c.py"], cwd=root,
+                       env=dict(os.environ, ORACLE_CURVE="bn254"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
