@@ -141,6 +141,72 @@ class MarlinProve:
         return self.proof
 
 
+class SeamRoute:
+    """The route BASELINE.json's north_star describes literally: the reference's Rust host code unchanged, every
+    `GeneralEvaluationDomain::{fft, ifft}` going to mh_ntt (seam B2, src/ahp/prover.rs:280-287 and the 30 call sites of
+    SURVEY.md Appendix A) and every `VariableBaseMSM::multi_scalar_mul` under PC::commit / PC::open_combinations
+    (src/lib.rs:172,193,213,292) to mh_msm (seam B1) -- with HOST pointers, because the Rust prover keeps its
+    polynomials in `Vec<Fr>`.  One step = the 30 transforms and the 15 large MSMs of one prove on host vectors of the
+    right sizes (pageable memory, like a Vec), against the SRS resident on the device with its window table built once
+    (PC::trim).  Everything else the Rust prover does on the host between those calls is NOT included: this is a lower
+    bound of what the seam route costs per proof, to be read beside the device-resident prover's number."""
+
+    def __init__(self, M, log_n, bases=None, seed=3):
+        from marlin_amd import workload as W, _lib
+        self.M, self.lib, self.curve = M, _lib.load(), _lib.CURVE_ID
+        self.N = 1 << log_n
+        H, K = self.N, 4 * self.N
+        self.ntts = W.ntt_inventory(H, K)
+        self.msms, _ = W.msm_inventory(H, K)
+        D = max(3 * H - 1, K - 1)
+        # base offsets: shifted_powers(d) = powers_of_g[max_degree - d ..]
+        self.offsets = [0] * len(self.msms)
+        for i, (n, what) in enumerate(self.msms):
+            if "shifted" in what:
+                self.offsets[i] = D - ((H - 2) if "g_1" in what else (K - 2))
+        if bases is None:
+            tau = np.array([0x9c5d7e2b4a6f8091, 0x1f3a, 0, 0], dtype=np.uint64)
+            bases = M.Bases.srs_powers(tau, D + 1)
+            bases.precompute()
+        self.bases = bases
+        rng = np.random.default_rng(seed)
+        self.data = rand_fr_np(rng, 1 << max(lg for lg, _, _ in self.ntts))      # a Vec<Fr> of the largest domain
+        self.scal = rand_fr_np(rng, K)
+        self.out = np.zeros(18, dtype=np.uint64)
+        self.ntt_s = self.msm_s = 0.0
+
+    def step(self, dist=None, torch=None):
+        t0 = time.perf_counter()
+        for lg, inverse, _ in self.ntts:
+            rc = self.lib.mh_ntt(self.curve, self.data.ctypes.data, lg, 1 if inverse else 0)
+            assert rc == 0
+        t1 = time.perf_counter()
+        for (n, _), off in zip(self.msms, self.offsets):
+            rc = self.lib.mh_msm(self.bases.handle, off, self.scal.ctypes.data, 1, n, self.out.ctypes.data)
+            assert rc == 0, self.lib.mh_last_error()
+        t2 = time.perf_counter()
+        self.ntt_s += t1 - t0
+        self.msm_s += t2 - t1
+
+
+def seam_route_measure(M, log_n, bases, steps=2):
+    sr = SeamRoute(M, log_n, bases)
+    sr.step()                                        # warm-up: staging buffers, MSM workspace
+    sr.ntt_s = sr.msm_s = 0.0
+    for _ in range(steps):
+        sr.step()
+    H = 1 << log_n
+    ntt_bytes = sum(64 << lg for lg, _, _ in sr.ntts)                  # each transform crosses PCIe both ways
+    msm_bytes = sum(32 * n for n, _ in sr.msms)                        # scalars only: the bases are resident
+    return {"ms_per_proof": round((sr.ntt_s + sr.msm_s) * 1e3 / steps, 2), "ntt_ms": round(sr.ntt_s * 1e3 / steps, 2),
+            "msm_ms": round(sr.msm_s * 1e3 / steps, 2), "steps": steps,
+            "pcie_bytes_per_proof": ntt_bytes + msm_bytes,
+            "what": "seam route lower bound: the reference's 30 transforms through mh_ntt and 15 MSMs through mh_msm with "
+                    "HOST pointers (pageable, like Vec<Fr>), SRS + window table resident; the Rust host work between the "
+                    "calls is not included.  Compare with ms_per_step of the device-resident prover (mh_marlin_prove_dev)",
+            "constraints_per_s": round(H / ((sr.ntt_s + sr.msm_s) / steps), 1)}
+
+
 def _cpu_inventory(cref, W, log_n, ntt_threads, msm_threads, rng):
     """NTT + MSM inventory of one prove at 2^log_n constraints on the C restatement:
     (seconds NTT, seconds MSM, busy threads of the MSM part)."""
@@ -232,7 +298,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["marlin-prove", "hotpath-inventory"], default=None)
+    ap.add_argument("--workload", choices=["marlin-prove", "hotpath-inventory", "seam-route"], default=None)
+    ap.add_argument("--no-seam-route", action="store_true", help="skip the (untimed, ~1 s) seam-route measurement of the default run")
+    ap.add_argument("--cpu-baseline-log", type=int, default=18,
+                    help="log2 constraints of the CPU baseline's all-core sample (default 18, ~20 s; 20 = the headline size, minutes)")
     ap.add_argument("--simulate-rank", default=None, metavar="R/G",
                     help="MEASUREMENT AID, one GPU: run what rank R of G would run (its bucket range of every MSM + the replicated "
                          "AHP rounds) with the exchange replaced by a local copy; the proof is not valid and the JSON line says so")
@@ -302,6 +371,8 @@ def main():
             from marlin_amd import dist as MD
             sr, sg = (int(x) for x in args.simulate_rank.split("/"))
             MD.enable_simulated_shard(sr, sg)
+    elif workload == "seam-route":
+        wl = SeamRoute(M, args.log_constraints)
     else:
         wl = HotPathInventory(M, args.log_constraints, rank, world)
 
@@ -327,6 +398,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # which physical devices took part: every rank reports (rank, local device, PCI bus id / uuid), all-gathered -- lets a
+    # scaling record prove that N distinct GPUs ran
+    def _dev_ident():
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+            return {"rank": rank, "local_device": local_rank, "pci": bus, "uuid": str(getattr(pr, "uuid", "")), "name": pr.name}
+        except Exception as e:
+            return {"rank": rank, "local_device": local_rank, "error": str(e)[:80]}
+    ranks_seen = [_dev_ident()]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks_seen[0])
+        ranks_seen = gathered
+
     ms_per_step = elapsed * 1e3 / args.steps
     value = wl.N / (elapsed / args.steps)
 
@@ -345,13 +431,24 @@ def main():
     bytes_per_launch = 128.0 * msm_pairs_rank * args.steps / max(1, acc_launches)
     avg_launch_ms = acc_ms / max(1, acc_launches)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    traffic = None
+    # HBM traffic of the accumulate kernel comes from a SEPARATE rocprofv3 --pmc capture (tools/profile.sh: counters cannot
+    # be read inside this process), i.e. from another run -- usually another box -- than the one timed here; traffic_source
+    # says which.  The capture is scaled to this run's launch size (bytes per input pair x pairs per launch).
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("msm_accum_bytes_per_launch")
+            pj = json.load(open(pmc))
+            per_pair = pj.get("msm_accum_bytes_per_pair")
+            if per_pair:
+                traffic = per_pair * msm_pairs_rank * args.steps / max(1, acc_launches)
+            else:
+                traffic = pj.get("msm_accum_bytes_per_launch")
+            traffic_source = {"file": "profiles/pmc_traffic.json", "capture": pj.get("source"), "box": pj.get("box"),
+                              "build": pj.get("build"), "fetch_size_factor": pj.get("fetch_size_factor"),
+                              "same_run_as_timing": False}
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
     # NTT bytes: the transforms this workload executes (the prover runs 16 of the reference's 30, see workload.ntt_executed)
     if workload == "marlin-prove":
         from marlin_amd import workload as _W
@@ -378,7 +475,7 @@ def main():
                     "32-bit VALU ops on gfx950 (profiles/r02a_microbench_controls.txt); mix counted in the ISA "
                     "(profiles/r02b_accum_loop_isa.txt)"}
     roofline = {"bound": "hbm", "kernel": valu["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(avg_launch_ms, 4),
                 "note": "algorithmic bytes = 128 B per (scalar, base) pair (SURVEY.md 8d); the MSM is VALU-issue bound "
                         "(~4.2k VALU instr per bucket addition, %d additions per pair), see roofline_valu and DESIGN.md; "
@@ -406,6 +503,9 @@ def main():
                                   "host_and_other": round(ms_per_step - (ntt_ms + msm_ms + glue_ms) / args.steps, 3)},
         "roofline": roofline,
         "roofline_valu": valu,
+        "accum_launches_per_step": acc_launches / max(1, args.steps),
+        "ranks_seen": ranks_seen,
+        "distinct_devices": len({(r.get("pci"), r.get("uuid")) for r in ranks_seen}),
     }
     from marlin_amd import _lib as _L
     curve_name = {"bls12_381": "BLS12-381", "bn254": "BN254"}[_L.CURVE]
@@ -421,8 +521,20 @@ def main():
         out["note"] = ("simulation of one rank of a multi-GPU run on one GPU (exchange replaced by a local copy): ms_per_step is "
                        "that rank's time without the all_gather; the proofs made are not valid; not a benchmark result")
         args.no_cpu_baseline = True
+    if workload == "seam-route":
+        out["metric"] = "marlin_seam_route_constraints_per_sec"
+        out["config"]["workload"] = ("seam-route: the reference's 30 NTTs through mh_ntt and 15 MSMs through mh_msm with HOST pointers "
+                                     "(north_star's literal route; lower bound, Rust host work excluded), DummyCircuit 2^%d, %s" % (args.log_constraints, curve_name))
+        out["breakdown_ms_per_step"]["host_pointer_ntt_calls"] = round(wl.ntt_s * 1e3 / (args.steps + args.warmup), 3)
+        out["breakdown_ms_per_step"]["host_pointer_msm_calls"] = round(wl.msm_s * 1e3 / (args.steps + args.warmup), 3)
+        args.no_cpu_baseline = True
+    elif workload == "marlin-prove" and rank == 0 and world == 1 and not args.no_seam_route and not args.simulate_rank:
+        try:
+            out["seam_route"] = seam_route_measure(M, args.log_constraints, wl.srs.powers_of_g)
+        except Exception as e:                      # a side measurement must not cost the headline line
+            out["seam_route"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(log_n_all=args.cpu_baseline_log)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

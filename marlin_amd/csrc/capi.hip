@@ -573,8 +573,12 @@ struct FbRun {
       ProfScope pa(c, PF_MSM_ACCUM, s);
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
       // resident waves per SIMD of the accumulate kernel (register budget 512 / waves): MH_ACC_WAVES = 3 | 4
-      static const int acc_waves = [] { const char* e = getenv("MH_ACC_WAVES"); int w = e ? atoi(e) : 3; return w == 4 ? 4 : 3; }();
-      if (acc_waves == 4)
+      static const int acc_waves = [] { const char* e = getenv("MH_ACC_WAVES"); int w = e ? atoi(e) : 3; return w == 4 ? 4 : (w == 2 ? 2 : 3); }();
+      if (acc_waves == 2)
+        hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
+                           (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
+      else if (acc_waves == 4)
         hipLaunchKernelGGL(F::accum30_kernel<4>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
                            (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
@@ -655,7 +659,7 @@ static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* 
     for (int j = k + 1; j < nj; j++)
       if (atom_of[j] < 0 && d_scalars[j] == d_scalars[k] && ns[j] == ns[k]) { atom_of[j] = atom_of[k]; atoms.back().push_back(j); }
   }
-  static const int split_on = [] { const char* e = getenv("MH_FB_SPLIT"); return e ? atoi(e) : 1; }();
+  static const int split_on = [] { const char* e = getenv("MH_FB_SPLIT"); return e ? atoi(e) : 0; }();
   u64 tot_ent = 0;
   for (int k = 0; k < nj; k++) tot_ent += (u64)W * ns[k];
   uint32_t best_mask = 0;

@@ -440,7 +440,9 @@ __device__ __noinline__ void x30_add_slow(X30& acc, const X30& b) {
   acc = x30_from_std(a);
 }
 // acc += b   [EFD add-2008-s]  12M + 2S
-__device__ __noinline__ void x30_add(X30& acc, const X30& b) {
+__device__ __forceinline__ void x30_add_inl(X30& acc, const X30& b);
+__device__ __noinline__ void x30_add(X30& acc, const X30& b) { x30_add_inl(acc, b); }
+__device__ __forceinline__ void x30_add_inl(X30& acc, const X30& b) {
   if (x30_is_identity(b)) return;
   if (x30_is_identity(acc)) { acc = b; return; }
   const Fq30 U1 = f30_mul(acc.x, b.zz);
@@ -614,10 +616,16 @@ __global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restri
   const u32 hi = lo + seg;
   X30 running = x30_identity(), acc = x30_identity();
   const G1Xyzz30* B = buckets + (u64)w * nb;
+  static_assert(true, "");
   for (u32 b = hi; b-- > lo;) {
     X30 t = x30_load(B + b);
+#ifdef MH_REDUCE_INLINE
+    x30_add_inl(running, t);
+    x30_add_inl(acc, running);
+#else
     x30_add(running, t);
     x30_add(acc, running);
+#endif
   }
   if (lo) {
     X30 m = x30_identity();

@@ -225,10 +225,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
   u32* tile = lds30;
   u32* twl = lds30 + NL * tw_words;                  // first pass only: tw30[0 .. R)
 
-  // ---- load: row r (stride n / R), column c -> tile row bitrev_B(r); missing tail reads as zero
-  for (u32 idx = tid; idx < (R << LOGC); idx += THREADS) {
-    const u32 c = idx & (C - 1), r = idx >> LOGC;
-    const u64 gi = (jbase + c) + (u64)r * stride;
+  // ---- load, with stage 0 of the pass fused in.  Row r (stride n / R) of column c belongs in tile row bitrev_B(r), and stage 0
+  // pairs the tile rows 2u, 2u + 1 = the loaded rows r, r + R / 2 (r < R / 2): one work item loads both, runs the butterfly
+  // and stores the results -- one LDS round trip and one barrier less per pass.  Its twiddle is tw[P + k] (k = column mod P);
+  // in the first pass (P = 1) that is omega_2^0 = 1 for every butterfly of the stage and the multiplication is skipped:
+  // the inputs are reduced field elements there, so a + b < 2 r and a - b + 2 r < 3 r keep the bounds of the lazy
+  // arithmetic.  A missing tail (in_len) reads as zero.
+  auto load_elem = [&](u64 gi) -> Fr30 {
     Fr30 v;
     if (flags & 4u) {                                  // a pass in between: 9 lazy limbs per element, as the previous pass left them
       const u32* p = (const u32*)x + 9 * gi;
@@ -239,15 +242,37 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
 #pragma unroll
       for (int l = 0; l < NL; l++) v.v[l] = 0;
     }
-    const u32 rr = B ? (__brev(r) >> (32 - B)) : 0;
-    tile_store<PAD>(tile, tw_words, (rr << LOGC) + c, v);
-  }
+    return v;
+  };
   if (logP == 0 && TWLDS)
     for (u32 idx = tid; idx < R * NL; idx += THREADS) twl[idx] = tw30[idx];
+  {
+    const u32 half = R >> 1;
+    const u64 Pm = (1ull << logP) - 1;
+    for (u32 idx = tid; idx < (half << LOGC); idx += THREADS) {
+      const u32 c = idx & (C - 1), r = idx >> LOGC;
+      const u64 g0 = (jbase + c) + (u64)r * stride;
+      Fr30 a = load_elem(g0), b = load_elem(g0 + (u64)half * stride);
+      if (logP == 0) {
+        const Fr30 d = sub30(a, b);
+        a = add30(a, b);
+        b = d;
+      } else {
+        const u32* w = tw30 + 9 * ((1ull << logP) + ((jbase + c) & Pm));
+        u32 wl[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) wl[l] = w[l];
+        butterfly(a, b, wl);
+      }
+      const u32 rr = __brev(r) >> (32 - B);            // even: r < R / 2
+      tile_store<PAD>(tile, tw_words, (rr << LOGC) + c, a);
+      tile_store<PAD>(tile, tw_words, ((rr + 1) << LOGC) + c, b);
+    }
+  }
   __syncthreads();
 
-  // ---- B stages in rounds of 3 (then 2 or 1)
-  for (u32 t = 0; t < B;) {
+  // ---- stages 1 .. B - 1 in rounds of MAXNS (then fewer)
+  for (u32 t = 1; t < B;) {
     const u32 ns = B - t >= (u32)MAXNS ? (u32)MAXNS : B - t;
     if (logP == 0 && TWLDS) {
       if (MAXNS >= 3 && ns == 3) round_stages<MAXNS >= 3 ? 3 : 1, LOGC, true, THREADS, PAD>(tile, tw_words, twl, B, t, 0, jbase);

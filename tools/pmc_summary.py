@@ -1,8 +1,24 @@
 """Aggregate rocprofv3 counter_collection CSVs per kernel: FETCH_SIZE / WRITE_SIZE (KiB units per
-the guide; FETCH_SIZE doubled for gfx950's wide-read under-count, MI355X_MICROARCH.md §HBM)."""
+the guide; FETCH_SIZE doubled for gfx950's wide-read under-count, MI355X_MICROARCH.md §HBM).
+
+The x2 of the guide is calibrated on coalesced 16 B/lane streams; for the accumulate kernel's access pattern -- one random
+128-byte table point per lane -- the factor measured by tools/fetch_calib.sh (profiles/*fetch_calib.json,
+gather128_list_kernel) is used instead when that file is given as argv[2] (or found as profiles/fetch_calib.json).
+argv[3] / LAUNCHES_PER_PROVE: accumulate launches of one prove (the groups of a prove run as two sub-batches each: 8)."""
 import csv, json, sys, os, collections
 
 d = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+calib_path = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] else os.path.join(ROOT, "profiles", "fetch_calib.json")
+GATHER_FACTOR, GATHER_SRC = 2.0, "MI355X_MICROARCH.md stream factor x2 (uncalibrated for gathers)"
+if os.path.exists(calib_path):
+    try:
+        cj = json.load(open(calib_path))
+        GATHER_FACTOR = float(cj["gather128_list_kernel"]["factor_known_over_counter"])
+        GATHER_SRC = "%s: known bytes / FETCH_SIZE of a 128-B random gather per lane" % os.path.relpath(calib_path, ROOT)
+    except Exception:
+        pass
+LAUNCHES = int(sys.argv[3]) if len(sys.argv) > 3 else int(os.environ.get("LAUNCHES_PER_PROVE", "8"))
 res = collections.defaultdict(lambda: {"launches": 0, "FETCH_SIZE_KiB": 0.0, "WRITE_SIZE_KiB": 0.0})
 for fn, key in (("pmc_fetch.csv", "FETCH_SIZE"), ("pmc_write.csv", "WRITE_SIZE")):
     p = os.path.join(d, fn)
@@ -42,9 +58,13 @@ def last_n(fn, key, name, n):
 
 
 for name in ("accum30_kernel", "msm::accum_kernel"):
-    f = last_n("pmc_fetch.csv", "FETCH_SIZE", name, 4)
-    w = last_n("pmc_write.csv", "WRITE_SIZE", name, 4)
+    f = last_n("pmc_fetch.csv", "FETCH_SIZE", name, LAUNCHES)
+    w = last_n("pmc_write.csv", "WRITE_SIZE", name, LAUNCHES)
     if f is not None and w is not None:
-        out["prove_only:" + name] = {"dispatches": 4, "fetch_bytes_per_launch_x2corrected": f * 1024 * 2,
-                                     "write_bytes_per_launch": w * 1024, "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024}
+        out["prove_only:" + name] = {"dispatches": LAUNCHES, "fetch_bytes_per_launch_x2corrected": f * 1024 * 2,
+                                     "fetch_bytes_per_launch_raw": f * 1024,
+                                     "fetch_bytes_per_launch_gather_calibrated": f * 1024 * GATHER_FACTOR,
+                                     "fetch_size_factor": GATHER_FACTOR, "fetch_size_factor_source": GATHER_SRC,
+                                     "write_bytes_per_launch": w * 1024,
+                                     "hbm_bytes_per_launch": f * 1024 * GATHER_FACTOR + w * 1024}
 print(json.dumps(out, indent=1, sort_keys=True))
