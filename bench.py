@@ -158,6 +158,7 @@ class SeamRoute:
         H, K = self.N, 4 * self.N
         self.ntts = W.ntt_inventory(H, K)
         self.msms, _ = W.msm_inventory(H, K)
+        self.alg_ntt_bytes, self.alg_msm_bytes = W.algorithmic_bytes(H, K)
         D = max(3 * H - 1, K - 1)
         # base offsets: shifted_powers(d) = powers_of_g[max_degree - d ..]
         self.offsets = [0] * len(self.msms)
@@ -169,6 +170,7 @@ class SeamRoute:
             bases = M.Bases.srs_powers(tau, D + 1)
             bases.precompute()
         self.bases = bases
+        self.srs = type("Srs", (), {"powers_of_g": bases})()
         rng = np.random.default_rng(seed)
         self.data = rand_fr_np(rng, 1 << max(lg for lg, _, _ in self.ntts))      # a Vec<Fr> of the largest domain
         self.scal = rand_fr_np(rng, K)

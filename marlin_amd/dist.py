@@ -1,11 +1,14 @@
 """Multi-GPU sharding of the MSM (one process per GPU, torch.distributed; backend "nccl" = RCCL over
 xGMI on the GPU box, "gloo" in the CPU tests).
 
-Inside mh_marlin_prove rank g sorts, accumulates and reduces the buckets [g 2^(c-1) / G, (g+1) 2^(c-1) / G) of
-every MSM (bucket-range sharding; `msm_sharded` below is the plain point-sharded variant for
-callers that hold only a slice of the bases); the per-rank partial results (one Jacobian point, 144 bytes) are
-exchanged with ONE all_gather per batch of MSMs and summed on every rank, so all ranks derive the same
-commitments and the same Fiat-Shamir challenges.  Elliptic-curve addition is not an RCCL reduction operator,
+Inside mh_marlin_prove every rank recodes every scalar but sorts, accumulates and reduces only the digits that fall
+into ITS partitions of the shared bucket set: partition v (2^11 consecutive buckets) belongs to rank v mod G --
+interleaved, because the low buckets are the heavier ones (bucket-range sharding).  A window table with
+fewer partitions than ranks (small SRS), a short vector or the skew fallback make a rank compute a group in full
+instead; the payload carries a share / whole flag per job and a whole result takes precedence.  `msm_sharded` below
+is the plain point-sharded variant for callers that hold only a slice of the bases.  The per-rank partial results
+(one Jacobian point, 144 bytes) are exchanged with ONE all_gather per batch of MSMs and summed on every rank, so
+all ranks derive the same commitments and the same Fiat-Shamir challenges.  Elliptic-curve addition is not an RCCL reduction operator,
 hence all_gather + local adds instead of all_reduce.
 """
 import ctypes as C
@@ -64,22 +67,44 @@ _keepalive = {}
 
 
 def enable_sharded_prove(dist, device=None):
-    """After this call mh_marlin_prove multiplies only this rank's slice of every MSM and combines the
-    partial points across ranks (mh_marlin_set_shard)."""
+    """After this call mh_marlin_prove sorts, accumulates and reduces only this rank's partitions of every MSM's bucket set
+    and combines the partial points across ranks (mh_marlin_set_shard).  The exchange runs four times per proof inside the
+    timed region, so the callback does as little as Python allows: the payload (<= 1.4 KB) is copied into a persistent
+    (pinned, when the transport is RCCL) staging tensor, ONE all_gather_into_tensor moves it, and the result is copied
+    straight into the library's receive buffer -- no per-call allocation, no list of tensors, no numpy round trips."""
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
+    st = {"n": 0}
+
+    def _buffers(nbytes):
+        if st["n"] != nbytes:
+            pin = device is not None
+            st["send_h"] = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pin)
+            st["recv_h"] = torch.empty(nbytes * world, dtype=torch.uint8, pin_memory=pin)
+            if device is not None:
+                st["send_d"] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                st["recv_d"] = torch.empty(nbytes * world, dtype=torch.uint8, device=device)
+            st["n"] = nbytes
+        return st
+
+    def _gather(dst, src):
+        try:
+            dist.all_gather_into_tensor(dst, src)
+        except (RuntimeError, NotImplementedError, AttributeError):      # a backend without the flat variant
+            parts = list(dst.view(world, -1).unbind(0))
+            dist.all_gather(parts, src)
 
     def _cb(send, nbytes, recv, _user):
         try:
-            src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
-            t = torch.from_numpy(src.copy())
+            b = _buffers(nbytes)
+            C.memmove(b["send_h"].data_ptr(), send, nbytes)
             if device is not None:
-                t = t.to(device)
-            out = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(out, t)
-            dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
-            for g, o in enumerate(out):
-                dst[g * nbytes:(g + 1) * nbytes] = o.cpu().numpy()
+                b["send_d"].copy_(b["send_h"], non_blocking=True)
+                _gather(b["recv_d"], b["send_d"])
+                b["recv_h"].copy_(b["recv_d"])                  # synchronises the transport's stream with the host
+            else:
+                _gather(b["recv_h"], b["send_h"])
+            C.memmove(recv, b["recv_h"].data_ptr(), nbytes * world)
             return 0
         except Exception as e:      # never unwind into C
             import sys

@@ -500,3 +500,40 @@ def test_prove_with_caller_supplied_zk_draws(gpu, pc):
     bad[5] = np.array([0xffffffffffffffff] * 4, dtype=np.uint64)
     with pytest.raises(M.MarlinHipError):
         GM.prove_draws(pk, inst, wit, bad)
+
+
+RCCL_WORKER = r'''
+import os, sys, ctypes as C
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch, torch.distributed as dist
+import marlin_amd as M
+from marlin_amd import dist as MD, _lib
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+M.init(0)
+MD.enable_sharded_prove(dist, device=torch.device("cuda", 0))
+send = np.arange(1, 41, dtype=np.uint64)                 # the size of a two-job payload: 2 x 18 limbs + error word + flags
+recv = np.zeros(40, dtype=np.uint64)
+for _ in range(3):                                       # persistent staging buffers are reused
+    recv[:] = 0
+    _lib.check(_lib.load().mh_marlin_test_allgather(send.ctypes.data, send.nbytes, recv.ctypes.data), "test_allgather")
+    assert np.array_equal(send, recv)
+t = torch.ones(8, device="cuda"); dist.all_reduce(t); assert float(t.sum()) == 8.0
+print("rccl world=1 ok:", torch.cuda.get_device_name(0))
+dist.destroy_process_group()
+'''
+
+
+def test_exchange_callback_over_rccl_world_1(gpu, tmp_path):
+    """The transport bench.py uses on a multi-GPU node -- torch.distributed backend "nccl" = RCCL, device tensors, the
+    persistent pinned staging of marlin_amd/dist.py -- executed for real on this one-GPU box as a communicator of ONE rank
+    (RCCL refuses two ranks on one device, so the N > 1 tests use gloo): the library's exchange hook runs the registered
+    callback, the payload comes back intact.  A wrong stream, dtype or buffer handling in the RCCL branch fails here."""
+    import subprocess, sys
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29791", WORLD_SIZE="1", RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl world=1 ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

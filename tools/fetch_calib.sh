@@ -3,8 +3,8 @@
 # rocprofv3 --pmc FETCH_SIZE over tools/fetch_calib (known byte counts) -> <outdir>/fetch_calib.json with the factor
 # known_bytes / (FETCH_SIZE KiB * 1024) per access pattern.
 set -u
-OUT=${1:-gpurun_out/fetch_calib}; mkdir -p $OUT
 REPO=$(pwd)
+OUT=${1:-gpurun_out/fetch_calib}; case $OUT in /*) ;; *) OUT=$REPO/$OUT;; esac; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 $REPO/tools/fetch_calib 2048 16777216 > $OUT/plain.log 2>&1
