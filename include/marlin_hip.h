@@ -247,6 +247,27 @@ int mh_msm_batch_sharded_dev(size_t njobs, const uint64_t* bases_handles, const 
                              const size_t* ns, int scalars_are_montgomery, uint64_t* out_xyz_mont);
 int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv);   /* runs the callback once (host only) */
 
+/* ---- building blocks of the slice-sharded multi-GPU pipeline (src/ahp/prover.rs:351-366,532-535,655-688 are
+ * the transforms it distributes) ----
+ * A polynomial of the distributed prover lives as G = world slices: coefficient vectors CYCLIC (rank r holds x[r + G j]:
+ * "C-layout", independent of zero-padding), evaluation vectors on a domain of n = G m points in BLOCKS OF k mod m (rank r
+ * holds X[k] for (k mod m) in [r m / G, (r + 1) m / G), locally ordered local[k1 (m / G) + t] = X[r m / G + t + m k1]:
+ * "M-layout"; a point of a subdomain has the same owner in the larger domain).
+ * mh_ntt_dist_dev: one transform of 2^log_n points with ONE all-to-all of 32 n / G^2 bytes per peer (4-step NTT):
+ * forward takes the C-layout slice (n / G elements) and returns the M-layout block, inverse the other way round; results
+ * equal mh_ntt on the gathered vector.  world must be a power of two <= 16, n >= world^2.  The all-to-all works on DEVICE
+ * buffers: chunk q (bytes_per_peer bytes) of d_send goes to rank q, chunk q of d_recv comes from rank q; it must return
+ * with d_recv complete (torch.distributed.all_to_all_single over RCCL in marlin_amd/dist.py). */
+typedef int (*mh_alltoall_fn)(const void* d_send, size_t bytes_per_peer, void* d_recv, void* user);
+int mh_marlin_set_alltoall(mh_alltoall_fn alltoall, void* user);
+int mh_ntt_dist_dev(int field, const void* d_in_local, void* d_out_local, uint32_t log_n, int inverse);
+/* MSMs of C-layout slices: scalar i of job j multiplies base first_index[j] + i * stride of the handle's set (first_index =
+ * rank + offset of the polynomial's base range, stride = world); needs the set's window table, which serves every rank's
+ * slice as it is.  combine != 0: the partial points of all ranks are all-gathered and added (every rank returns the full
+ * results, as after PC::commit); combine == 0: this rank's partial sums. */
+int mh_msm_batch_sliced_dev(uint64_t bases_handle, size_t njobs, const size_t* first_index, size_t stride, const void* const* d_scalars_local,
+                            const size_t* ns_local, int scalars_are_montgomery, int combine, uint64_t* out_xyz_mont);
+
 /* Coefficients (Montgomery Fr) of a prover / indexer polynomial of the last proof made with this key, by the
  * reference's label ("w","z_a","z_b","mask_poly","t","g_1","h_1","g_2","h_2","row","col","a_val","b_val",
  * "c_val","row_col"; src/ahp/mod.rs:33-45).  out == NULL queries the length. */

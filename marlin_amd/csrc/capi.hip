@@ -410,7 +410,7 @@ static const BaseSet* find_table(Context& c, const void* b, size_t n, size_t& of
 struct FbRun {
   Context& c; const BaseSet& bs; Context::FbWs& ws;
   int nj = 0, is_mont = 0;
-  std::vector<size_t> offs, ns; std::vector<const void*> sc;
+  std::vector<size_t> offs, ns, strides; std::vector<const void*> sc;
   msm::Windows win; u32 W = 0, nbt = 0, pshift = 0, nb = 0, nparts = 0, WT = 0; size_t WB = 0;
   msmfb::Own own{0, 1}; bool partial = false; u32 nbown = 0, S = 0;
   msmfb::FbJobs jobs; std::vector<int> alias;
@@ -444,10 +444,10 @@ struct FbRun {
     static const bool alias_on = [] { const char* e = getenv("MH_FB_ALIAS"); return !(e && atoi(e) == 0); }();
     for (int k = 1; k < nj && alias_on; k++)
       for (int j = 0; j < k; j++)
-        if (alias[j] < 0 && sc[j] == sc[k] && ns[j] == ns[k] && offs[k] >= offs[j]) { alias[k] = j; break; }
+        if (alias[j] < 0 && sc[j] == sc[k] && ns[j] == ns[k] && offs[k] >= offs[j] && strides[j] == strides[k]) { alias[k] = j; break; }
     ent = 0; pco = 0; max_blk = 0;
     for (int k = 0; k < nj; k++) {
-      jobs.scalars[k] = (const Fr*)sc[k]; jobs.n[k] = ns[k]; jobs.tab_off[k] = (u32)offs[k];
+      jobs.scalars[k] = (const Fr*)sc[k]; jobs.n[k] = ns[k]; jobs.tab_off[k] = (u32)offs[k]; jobs.tab_stride[k] = (u32)strides[k];
       jobs.ent_off[k] = ent;
       if (alias[k] >= 0) { jobs.nblk[k] = 0; jobs.pc_off[k] = pco; continue; }       // no blocks: count / split skip the job
       ent += (u64)W * ns[k];
@@ -562,6 +562,7 @@ struct FbRun {
     MH_HIP(hipStreamSynchronize(s));
     const u64 avg = ent / WB + 1;
     skewed = mx > 4096 && (u64)mx > 32 * avg;
+    for (size_t st : strides) if (st != 1) skewed = false;     // a strided slice has no variable-base fallback: the buckets are accumulated as they are
     return MH_OK;
   }
 
@@ -644,7 +645,7 @@ struct FbRun {
 // few entries in A, the exposed reduction few jobs in B (its cost is per bucket set, not per scalar).  MH_FB_SPLIT=0
 // keeps the whole group on the main stream.
 static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* offs, const void* const* d_scalars, const size_t* ns,
-                           int is_mont, HG1* out, bool& skewed, const int* shard, bool& partial) {
+                           int is_mont, HG1* out, bool& skewed, const int* shard, bool& partial, const size_t* strides = nullptr) {
   skewed = false;
   hipStream_t s0 = c.stream, s1 = c.stream2;
   ProfScope wall(c, PF_MSM, s0);
@@ -657,7 +658,7 @@ static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* 
     if (atom_of[k] >= 0) continue;
     atom_of[k] = (int)atoms.size(); atoms.push_back({k});
     for (int j = k + 1; j < nj; j++)
-      if (atom_of[j] < 0 && d_scalars[j] == d_scalars[k] && ns[j] == ns[k]) { atom_of[j] = atom_of[k]; atoms.back().push_back(j); }
+      if (atom_of[j] < 0 && d_scalars[j] == d_scalars[k] && ns[j] == ns[k] && (!strides || strides[j] == strides[k])) { atom_of[j] = atom_of[k]; atoms.back().push_back(j); }
   }
   static const int split_on = [] { const char* e = getenv("MH_FB_SPLIT"); return e ? atoi(e) : 0; }();
   u64 tot_ent = 0;
@@ -690,7 +691,7 @@ static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* 
     const bool inA = best_mask == 0 || (best_mask & (1u << atom_of[k]));
     FbRun& r = inA ? A : B;
     (inA ? idxA : idxB).push_back(k);
-    r.offs.push_back(offs[k]); r.sc.push_back(d_scalars[k]); r.ns.push_back(ns[k]);
+    r.offs.push_back(offs[k]); r.sc.push_back(d_scalars[k]); r.ns.push_back(ns[k]); r.strides.push_back(strides ? strides[k] : 1);
   }
   MH_TRY(A.prepare(is_mont, shard));
   partial = A.partial;
@@ -934,6 +935,46 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
       HG1 r = combine_windows(wj, p);
       uint64_t* o = out_xyz + XYZ_L * live[g0 + k];
       memcpy(o, r.X.v, FQ_B); memcpy(o + FQ_L, r.Y.v, FQ_B); memcpy(o + 2 * FQ_L, r.Z.v, FQ_B);
+    }
+  }
+  return MH_OK;
+}
+
+// MSMs over STRIDED selections of one tabled base set: job j multiplies scalar i with base first[j] + i * stride (the cyclic
+// slice of a coefficient vector a rank holds in the distributed layout of ntt_dist.cuh: first = rank + offset, stride = number
+// of ranks).  Fixed-base path only -- the window table is indexed, no base is ever copied -- and never the skew fallback.
+int msm_batch_strided_device(Context& c, const BaseSet& bs, int njobs, const size_t* first, size_t stride, const void* const* d_scalars,
+                             const size_t* ns, int is_mont, uint64_t* out_xyz) {
+  if (!bs.d_table) return fail(MH_EINVAL, "strided MSM: the base set has no window table (mh_bases_precompute)");
+  if (stride == 0) return fail(MH_EINVAL, "strided MSM: stride must be positive");
+  HG1 id = HG1::identity();
+  for (int j = 0; j < njobs; j++) { memcpy(out_xyz + XYZ_L * j, id.X.v, FQ_B); memcpy(out_xyz + XYZ_L * j + FQ_L, id.Y.v, FQ_B); memcpy(out_xyz + XYZ_L * j + 2 * FQ_L, id.Z.v, FQ_B); }
+  std::vector<int> live;
+  for (int j = 0; j < njobs; j++)
+    if (ns[j]) {
+      if (first[j] + (ns[j] - 1) * stride >= bs.n) return fail(MH_EINVAL, "strided MSM: selection reaches past the base set");
+      live.push_back(j);
+    }
+  MH_TRY(msm_set_attrs());
+  size_t g_next = 0;
+  for (size_t g0 = 0; g0 < live.size(); g0 = g_next) {
+    int nj = 0;
+    u64 ent_est = 0;
+    while (nj < msm::MAX_JOBS && g0 + nj < live.size()) {
+      const u64 e = (u64)bs.tab_W * ns[live[g0 + nj]];
+      if (nj && ent_est + e >= (1ull << 32) - (1ull << 26)) break;
+      ent_est += e; nj++;
+    }
+    g_next = g0 + nj;
+    std::vector<size_t> offs(nj), nn(nj), st(nj, stride); std::vector<const void*> sc(nj);
+    for (int k = 0; k < nj; k++) { offs[k] = first[live[g0 + k]]; nn[k] = ns[live[g0 + k]]; sc[k] = d_scalars[live[g0 + k]]; }
+    std::vector<HG1> res(nj);
+    bool skewed = false, part = false;
+    MH_TRY(msm_fb_pipeline(c, bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, nullptr, part, st.data()));
+    c.n_fb_groups++;
+    for (int k = 0; k < nj; k++) {
+      uint64_t* o = out_xyz + XYZ_L * live[g0 + k];
+      memcpy(o, res[k].X.v, FQ_B); memcpy(o + FQ_L, res[k].Y.v, FQ_B); memcpy(o + 2 * FQ_L, res[k].Z.v, FQ_B);
     }
   }
   return MH_OK;

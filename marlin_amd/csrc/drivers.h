@@ -13,6 +13,9 @@ int msm_device(Context& c, const void* d_bases, const void* d_scalars, int is_mo
 // shard = {rank, world} shards fixed-base groups by bucket range; partial[j] = 1 then marks out_xyz[j] as this rank's share
 int msm_batch_device(Context& c, int njobs, const void* const* d_bases, const void* const* d_scalars, const size_t* ns, int is_mont,
                      uint64_t* out_xyz, const int* shard = nullptr, uint8_t* partial = nullptr);
+// MSMs over strided selections (base first[j] + i * stride) of one tabled base set; fixed-base path only
+int msm_batch_strided_device(Context& c, const BaseSet& bs, int njobs, const size_t* first, size_t stride, const void* const* d_scalars,
+                             const size_t* ns, int is_mont, uint64_t* out_xyz);
 // fixed-base window table for a base set (msm_fb.cuh); window_bits = 0 picks a width from the set's size
 int bases_precompute(Context& c, BaseSet& bs, uint32_t window_bits);
 // twiddle table (tw[2^(l-1) + e] = omega_{2^l}^e) covering at least log_n levels

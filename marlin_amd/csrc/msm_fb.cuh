@@ -105,6 +105,7 @@ struct FbJobs {
   u64 ent_off[msm::MAX_JOBS];    // job's region in key / val / sorted (W * n entries)
   u64 pc_off[msm::MAX_JOBS];     // job's region in the per-block partition counts (nparts * nblk)
   u32 tab_off[msm::MAX_JOBS];    // index of the job's first base inside the table's base set
+  u32 tab_stride[msm::MAX_JOBS]; // scalar i multiplies base tab_off + i * tab_stride (1: a contiguous range; G: rank's cyclic slice)
   u32 nblk[msm::MAX_JOBS];
   u32 njobs;
 };
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const 
   if (live) {
     Fr s = ff_load(jobs.scalars[job] + i);
     if (!is_mont) s = ff_to_mont(s);
-    const u32 t0 = jobs.tab_off[job] + (u32)i;
+    const u32 t0 = jobs.tab_off[job] + (u32)i * jobs.tab_stride[job];
     msm::for_each_digit(s, W, win, [&](u32 w, u32 e) {
       u32 b = e & 0x7fffffffu;
       if (b) {

@@ -18,6 +18,7 @@
 #include "g1.cuh"
 #include "host_ff.h"
 #include "poly.cuh"
+#include "ntt_dist.cuh"
 #include "rng.cuh"
 #include "wire_host.h"
 #include "verify_host.h"
@@ -284,7 +285,7 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
 // exchanges the 144-byte partial points and every rank adds them, so all ranks see identical commitments.  Unlike a
 // split of the points, this shrinks the sort, the accumulation AND the bucket reduction by the number of ranks and keeps
 // the window width of the one-GPU table.
-struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; } g_shard;
+struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; mh_alltoall_fn a2a = nullptr; void* a2a_user = nullptr; } g_shard;
 
 HG1 jac_from(const uint64_t* xyz);
 struct MsmJob { const char* bases; const Fr* scalars; uint64_t n; };
@@ -595,6 +596,122 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
   std::lock_guard<std::recursive_mutex> lk(c.mu);     // g_shard is read by a running mh_marlin_prove under this lock
   g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
   return MH_OK;                                 // the window table does not depend on the number of ranks (bucket-range sharding)
+}
+
+// ---- distributed building blocks (the slice-sharded pipeline) ---------------------------------------------
+int mh_marlin_set_alltoall(mh_alltoall_fn alltoall, void* user) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  g_shard.a2a = alltoall; g_shard.a2a_user = user;
+  return MH_OK;
+}
+
+// One transform of 2^log_n points over the registered ranks (ntt_dist.cuh).  forward: d_in = this rank's cyclic slice of the
+// coefficients (C-layout), d_out = its block of the evaluations (M-layout); inverse: the other way round.  n / world elements
+// each; d_in may equal d_out.
+int mh_ntt_dist_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
+  LOCKED_CTX();
+  if (field != hostff::CURVE_ID) return fail(MH_EINVAL, "mh_ntt_dist_dev: unsupported field");
+  if (!d_in || !d_out) return fail(MH_EINVAL, "mh_ntt_dist_dev: null pointer");
+  const int G = g_shard.world, rank = g_shard.rank;
+  if (G == 1) return ntt_device(c, d_in, d_out, log_n, inverse);
+  uint32_t lg = 0;
+  while ((1 << lg) < G) lg++;
+  if ((1 << lg) != G || G > 16) return fail(MH_EINVAL, "mh_ntt_dist_dev: the number of ranks must be a power of two <= 16");
+  if (!g_shard.a2a) return fail(MH_EINVAL, "mh_ntt_dist_dev: no all_to_all callback registered (mh_marlin_set_alltoall)");
+  if (log_n > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "log_n exceeds the two-adicity of Fr");
+  if (log_n < 2 * lg) return fail(MH_EINVAL, "mh_ntt_dist_dev: the transform must have at least world^2 points");
+  const uint32_t log_m = log_n - lg;
+  const uint64_t m = 1ull << log_m, chunk = m >> lg;
+  MH_TRY(c.ntt_dist_buf[0].ensure(m * 32)); MH_TRY(c.ntt_dist_buf[1].ensure(m * 32));
+  Fr* A = (Fr*)c.ntt_dist_buf[0].ptr; Fr* B = (Fr*)c.ntt_dist_buf[1].ptr;
+  // w_n, and the tables of (w_n^(+-rank))^k2 = hi[k2 >> 11] * lo[k2 & 2047], the inverse's lo carrying G^-1
+  HFr wn = hostff::fr_two_adic_root();
+  for (uint32_t i = log_n; i < hostff::FR_TWO_ADICITY_H; i++) wn = wn.sqr();
+  if (inverse) wn = wn.inv();
+  const HFr base = wn.pow_u64((uint64_t)rank);
+  const uint64_t LO = 1ull << poly::COSET_LO_BITS, nhi = (m + LO - 1) / LO;
+  std::vector<uint64_t> tab(4 * (LO + nhi));
+  {
+    HFr a = inverse ? HFr::from_u64((uint64_t)G).inv() : HFr::one();
+    for (uint64_t j = 0; j < LO; j++) { memcpy(&tab[4 * j], a.v, 32); a = a * base; }
+    const HFr bl = base.pow_u64(LO);
+    a = HFr::one();
+    for (uint64_t j = 0; j < nhi; j++) { memcpy(&tab[4 * (LO + j)], a.v, 32); a = a * bl; }
+  }
+  MH_TRY(c.ntt_dist_tw.ensure(tab.size() * 8));
+  MH_HIP(hipMemcpyAsync(c.ntt_dist_tw.ptr, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c.stream));
+  MH_HIP(hipStreamSynchronize(c.stream));            // `tab` is pageable and goes out of scope
+  const Fr* t_lo = (const Fr*)c.ntt_dist_tw.ptr; const Fr* t_hi = t_lo + LO;
+  nttdist::Roots roots;
+  {
+    HFr wg = wn.pow_u64(m), a = HFr::one();          // w_G = w_n^m (the inverse root when `inverse`)
+    for (int e = 0; e < 8; e++) { roots.w[e] = dfr(a); a = a * wg; }
+  }
+  auto gdft = [&](Fr* out, const Fr* in) -> int {
+    ProfScope ps(c, PF_NTT);
+    const dim3 grid((unsigned)((chunk + 255) / 256)), block(256);
+    switch (lg) {
+      case 1: hipLaunchKernelGGL(nttdist::gdft_kernel<1>, grid, block, 0, c.stream, out, in, (u64)chunk, roots); break;
+      case 2: hipLaunchKernelGGL(nttdist::gdft_kernel<2>, grid, block, 0, c.stream, out, in, (u64)chunk, roots); break;
+      case 3: hipLaunchKernelGGL(nttdist::gdft_kernel<3>, grid, block, 0, c.stream, out, in, (u64)chunk, roots); break;
+      default: hipLaunchKernelGGL(nttdist::gdft_kernel<4>, grid, block, 0, c.stream, out, in, (u64)chunk, roots); break;
+    }
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+  };
+  auto twist = [&](Fr* buf) -> int {
+    ProfScope ps(c, PF_GLUE);
+    KLAUNCH(poly::twist_kernel, m, buf, (const Fr*)buf, t_hi, t_lo, (u64)m);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+  };
+  // the exchange sees finished buffers and hands back a finished buffer (the transport may use its own stream)
+  auto exchange = [&](const Fr* send, Fr* recv) -> int {
+    MH_HIP(hipStreamSynchronize(c.stream));
+    if (g_shard.a2a(send, (size_t)chunk * 32, recv, g_shard.a2a_user) != 0) return fail(MH_EHIP, "mh_ntt_dist_dev: all_to_all callback failed");
+    return MH_OK;
+  };
+  if (!inverse) {
+    MH_TRY(ntt_device(c, d_in, A, log_m, 0));        // Y_rank = local transform of the cyclic slice
+    MH_TRY(twist(A));                                // * w_n^(rank k2)
+    MH_TRY(exchange(A, B));                          // chunk q = k2 in block q -> rank q
+    MH_TRY(gdft((Fr*)d_out, B));                     // X[k2 + m k1], k1-major
+  } else {
+    MH_TRY(gdft(A, (const Fr*)d_in));                // G Z_j1[k2] for k2 in this rank's block, j1-major
+    MH_TRY(exchange(A, B));                          // chunk j1 -> rank j1: B = G w^(j1 k2) Y_j1, k2 in order
+    MH_TRY(twist(B));                                // * w_n^(-rank k2) / G
+    MH_TRY(ntt_device(c, B, d_out, log_m, 1));       // local inverse (with m^-1)
+  }
+  return MH_OK;
+}
+
+// MSMs of this rank's CYCLIC slices (ntt_dist.cuh's C-layout: scalar i of job j multiplies base first_index[j] + i * stride
+// of the handle's set, whose window table serves as is) -- the point-sharded MSM of the slice-sharded pipeline.  combine != 0:
+// the partial points of all registered ranks are all-gathered and summed, every rank returns the complete results.
+int mh_msm_batch_sliced_dev(uint64_t bases_handle, size_t njobs, const size_t* first_index, size_t stride, const void* const* d_scalars,
+                            const size_t* ns, int is_mont, int combine, uint64_t* out_xyz) {
+  LOCKED_CTX();
+  if (njobs && (!first_index || !d_scalars || !ns || !out_xyz)) return fail(MH_EINVAL, "mh_msm_batch_sliced_dev: null pointer");
+  auto it = c.bases.find(bases_handle);
+  if (it == c.bases.end()) return fail(MH_EINVAL, "mh_msm_batch_sliced_dev: unknown bases handle");
+  std::vector<uint64_t> part((size_t)XYZ_L * njobs + 1, 0);
+  int rc = msm_batch_strided_device(c, it->second, (int)njobs, first_index, stride, d_scalars, ns, is_mont, part.data());
+  if (!combine || g_shard.world == 1) { MH_TRY(rc); memcpy(out_xyz, part.data(), (size_t)XYZ_L * njobs * 8); return MH_OK; }
+  if (!g_shard.cb) return fail(MH_EINVAL, "mh_msm_batch_sliced_dev: no all_gather callback registered");
+  part[(size_t)XYZ_L * njobs] = rc == MH_OK ? 0 : 1;                 // a failing rank still enters the collective
+  std::vector<uint64_t> all(part.size() * g_shard.world);
+  if (g_shard.cb(part.data(), part.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "mh_msm_batch_sliced_dev: all_gather callback failed");
+  MH_TRY(rc);
+  for (int g = 0; g < g_shard.world; g++)
+    if (all[(size_t)g * part.size() + XYZ_L * njobs] != 0) return fail(MH_EHIP, "mh_msm_batch_sliced_dev: the MSM of another rank failed");
+  for (size_t j = 0; j < njobs; j++) {
+    HG1 acc = HG1::identity();
+    for (int g = 0; g < g_shard.world; g++) acc = acc.add(jac_from(all.data() + (size_t)g * part.size() + XYZ_L * j));
+    uint64_t* o = out_xyz + XYZ_L * j;
+    memcpy(o, acc.X.v, FQ_B); memcpy(o + FQ_L, acc.Y.v, FQ_B); memcpy(o + 2 * FQ_L, acc.Z.v, FQ_B);
+  }
+  return MH_OK;
 }
 
 // mh_msm_batch_dev across the ranks registered with mh_marlin_set_shard: every rank passes the SAME jobs (full scalar

@@ -133,4 +133,81 @@ def enable_simulated_shard(rank, world):
 
 def disable_sharded_prove():
     _lib.check(_lib.load().mh_marlin_set_shard(0, 1, None, None), "mh_marlin_set_shard")
+    _lib.check(_lib.load().mh_marlin_set_alltoall(None, None), "mh_marlin_set_alltoall")
     _keepalive.clear()
+
+
+# ---- slice-sharded building blocks: the all-to-all of the distributed transform (mh_ntt_dist_dev) ----
+_ALLTOALL_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+
+
+def enable_alltoall(dist, device=None):
+    """Registers torch.distributed.all_to_all_single as the exchange of mh_ntt_dist_dev.  The library hands over DEVICE
+    pointers of its own buffers.  RCCL (`device` given): persistent device tensors wrap the exchange, filled and drained with
+    device-to-device copies -- the payload never touches the host.  gloo (CPU tests): staged through host tensors."""
+    import torch
+    world = dist.get_world_size()
+    lib = _lib.load()
+    st = {"n": 0}
+
+    def _cb(d_send, bytes_per_peer, d_recv, _user):
+        try:
+            total = bytes_per_peer * world
+            if st["n"] != total:
+                dev = device if device is not None else "cpu"
+                st["send"] = torch.empty(total, dtype=torch.uint8, device=dev)
+                st["recv"] = torch.empty(total, dtype=torch.uint8, device=dev)
+                st["n"] = total
+            send, recv = st["send"], st["recv"]
+            if device is not None:
+                _lib.check(lib.mh_memcpy_d2d(send.data_ptr(), d_send, total), "d2d")
+                _lib.check(lib.mh_synchronize(), "sync")
+                dist.all_to_all_single(recv, send)
+                torch.cuda.synchronize(device)
+                _lib.check(lib.mh_memcpy_d2d(d_recv, recv.data_ptr(), total), "d2d")
+                _lib.check(lib.mh_synchronize(), "sync")
+            else:
+                _lib.check(lib.mh_memcpy_d2h(send.data_ptr(), d_send, total), "d2h")
+                dist.all_to_all_single(recv, send)
+                _lib.check(lib.mh_memcpy_h2d(d_recv, recv.data_ptr(), total), "h2d")
+            return 0
+        except Exception as e:      # never unwind into C
+            import sys
+            print("all_to_all callback failed:", e, file=sys.stderr)
+            return -1
+    cb = _ALLTOALL_T(_cb)
+    _keepalive["a2a"] = cb
+    _lib.check(lib.mh_marlin_set_alltoall(C.cast(cb, C.c_void_p), None), "mh_marlin_set_alltoall")
+
+
+def c_layout_slice(x, rank, world):
+    """this rank's cyclic slice of a coefficient vector: x[rank + world * j]"""
+    return np.ascontiguousarray(x[rank::world])
+
+
+def m_layout_indices(n, rank, world):
+    """global indices k of the evaluations this rank holds, in local order: local[k1 * (m / G) + t] = X[rank * (m / G) + t + m * k1]"""
+    m = n // world
+    chunk = m // world
+    k1, t = np.divmod(np.arange(m, dtype=np.int64), chunk)
+    return rank * chunk + t + m * k1
+
+
+def ntt_dist_dev(d_in, d_out, log_n, inverse=False):
+    """mh_ntt_dist_dev on DeviceBuffers / device pointers holding n / world elements each."""
+    from .api import DeviceBuffer
+    p = lambda b: b.ptr if isinstance(b, DeviceBuffer) else int(b)
+    _lib.check(_lib.load().mh_ntt_dist_dev(_lib.CURVE_ID, p(d_in), p(d_out), int(log_n), 1 if inverse else 0), "mh_ntt_dist_dev")
+
+
+def msm_batch_sliced_dev(bases, jobs, stride, montgomery=True, combine=True):
+    """jobs: [(first_index, DeviceBuffer or pointer of the LOCAL scalars, n_local)]: scalar i multiplies base first_index + i * stride."""
+    from .api import DeviceBuffer
+    k = len(jobs)
+    first = (C.c_size_t * k)(*[int(j[0]) for j in jobs])
+    ptrs = (C.c_void_p * k)(*[(j[1].ptr if isinstance(j[1], DeviceBuffer) else int(j[1])) for j in jobs])
+    ns = (C.c_size_t * k)(*[int(j[2]) for j in jobs])
+    out = np.zeros((k, 3 * _lib.FQ_LIMBS), dtype=np.uint64)
+    _lib.check(_lib.load().mh_msm_batch_sliced_dev(bases.handle, k, first, int(stride), ptrs, ns, 1 if montgomery else 0,
+                                                   1 if combine else 0, out.ctypes.data), "mh_msm_batch_sliced_dev")
+    return out

@@ -45,6 +45,10 @@ pub struct mh_verifier_key {
 pub type mh_allgather_fn =
     Option<unsafe extern "C" fn(send: *const c_void, bytes: usize, recv: *mut c_void, user: *mut c_void) -> c_int>;
 
+/// `mh_alltoall_fn`: all-to-all on DEVICE buffers (chunk q of `d_send` to rank q, chunk q of `d_recv` from rank q).
+pub type mh_alltoall_fn =
+    Option<unsafe extern "C" fn(d_send: *const c_void, bytes_per_peer: usize, d_recv: *mut c_void, user: *mut c_void) -> c_int>;
+
 extern "C" {
     pub fn mh_curve_info(curve_id: *mut c_int, fr_limbs64: *mut c_int, fq_limbs64: *mut c_int, fr_two_adicity: *mut c_int) -> c_int;
 
@@ -119,6 +123,10 @@ extern "C" {
     pub fn mh_marlin_proof_serialize(flat_proof: *const u8, flat_len: usize, pc: c_int, out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_proof_deserialize(bytes: *const u8, len: usize, pc: c_int, flat_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_set_shard(rank: c_int, world: c_int, allgather: mh_allgather_fn, user: *mut c_void) -> c_int;
+    pub fn mh_marlin_set_alltoall(alltoall: mh_alltoall_fn, user: *mut c_void) -> c_int;
+    pub fn mh_ntt_dist_dev(field: c_int, d_in_local: *const c_void, d_out_local: *mut c_void, log_n: u32, inverse: c_int) -> c_int;
+    pub fn mh_msm_batch_sliced_dev(bases_handle: u64, njobs: usize, first_index: *const usize, stride: usize, d_scalars_local: *const *const c_void,
+                                   ns_local: *const usize, scalars_are_montgomery: c_int, combine: c_int, out_xyz_mont: *mut u64) -> c_int;
     pub fn mh_marlin_test_allgather(send: *const c_void, bytes: usize, recv: *mut c_void) -> c_int;
     pub fn mh_marlin_get_poly(pk: u64, label: *const c_char, out: *mut u64, cap_elems: usize, len_out: *mut usize) -> c_int;
 

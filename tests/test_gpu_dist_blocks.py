@@ -1,0 +1,98 @@
+"""Building blocks of the slice-sharded multi-GPU pipeline, on this box's one GPU with `world` processes and
+a gloo exchange:
+
+* mh_ntt_dist_dev -- one transform over G ranks with ONE all-to-all (4-step NTT): every rank feeds its cyclic slice of the
+  coefficients, the gathered M-layout blocks equal mh_ntt of the whole vector bit for bit; the inverse brings every rank's
+  slice back (src/ahp/prover.rs:351-366,532-535,655-688 are the transforms it distributes);
+* mh_msm_batch_sliced_dev -- the point-sharded MSM of cyclic coefficient slices against the ONE window table (table index
+  first + i * stride), partial points all-gathered and added: equals the MSM of the whole vector.
+"""
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+import marlin_amd as M
+from marlin_amd import dist as MD
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+M.init(0)                                            # every rank shares the box's one GPU
+MD.enable_sharded_prove(dist)
+MD.enable_alltoall(dist)
+rng = np.random.default_rng(11)                      # the same global vectors on every rank
+
+
+def rand_fr(n):
+    x = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    x[:, 3] &= np.uint64((1 << 59) - 1)
+    return x
+
+
+for log_n in %(logs)r:
+    n = 1 << log_n
+    x = rand_fr(n)
+    want = M.ntt(x)                                  # the whole transform on one GPU (mh_ntt)
+    mine = MD.c_layout_slice(x, rank, world)
+    d_in, d_out = M.DeviceBuffer.from_numpy(mine), M.DeviceBuffer(32 * (n // world))
+    MD.ntt_dist_dev(d_in, d_out, log_n)
+    got = d_out.download((n // world, 4))
+    idx = MD.m_layout_indices(n, rank, world)
+    assert np.array_equal(got, want[idx]), "forward 2^%%d: rank %%d's block differs" %% (log_n, rank)
+    # every output index has exactly one owner
+    owners = [None] * world
+    dist.all_gather_object(owners, idx)
+    assert np.array_equal(np.sort(np.concatenate(owners)), np.arange(n))
+    # inverse: M-layout block in, C-layout slice out, in place
+    MD.ntt_dist_dev(d_out, d_out, log_n, inverse=True)
+    assert np.array_equal(d_out.download((n // world, 4)), mine), "inverse 2^%%d: rank %%d" %% (log_n, rank)
+    # an inverse transform of evaluations given in M-layout equals mh_ntt(inverse) of the gathered vector
+    e = rand_fr(n)
+    d_e = M.DeviceBuffer.from_numpy(np.ascontiguousarray(e[idx]))
+    MD.ntt_dist_dev(d_e, d_e, log_n, inverse=True)
+    assert np.array_equal(d_e.download((n // world, 4)), MD.c_layout_slice(M.intt(e), rank, world))
+    for b in (d_in, d_out, d_e):
+        b.free()
+
+# ---- sliced MSM against one window table
+n = 1 << %(msm_log)d
+tau = np.array([0x1234567, 0, 0, 0], dtype=np.uint64)
+B = M.Bases.srs_powers(tau, n + 64)
+B.precompute(%(c)d)
+s1, s2 = rand_fr(n), rand_fr(n - 5)
+d1, d2 = M.DeviceBuffer.from_numpy(s1), M.DeviceBuffer.from_numpy(s2)
+whole = M.msm_batch_dev([(B, 0, d1, n), (B, 37, d2, n - 5), (B, 0, d2, n - 5)])
+l1, l2 = MD.c_layout_slice(s1, rank, world), MD.c_layout_slice(s2, rank, world)
+e1, e2 = M.DeviceBuffer.from_numpy(l1), M.DeviceBuffer.from_numpy(l2)
+fb0, vb0 = M.msm_path_counts()
+got = MD.msm_batch_sliced_dev(B, [(rank, e1, len(l1)), (37 + rank, e2, len(l2)), (rank, e2, len(l2))], world)
+fb1, vb1 = M.msm_path_counts()
+aff = lambda a: [tuple(M.g1_to_affine(r)[0]) for r in a]
+assert aff(got) == aff(whole), "rank %%d: sliced MSM differs" %% rank
+assert vb1 == vb0 and fb1 > fb0
+part = MD.msm_batch_sliced_dev(B, [(rank, e1, len(l1))], world, combine=False)
+parts = [None] * world
+dist.all_gather_object(parts, part[0])
+assert aff([MD.g1_sum(np.stack(parts))]) == aff(whole[:1])
+print("rank %%d ok" %% rank)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,logs", [(2, [2, 3, 10, 16]), (4, [4, 5, 12, 18]), (8, [6, 7, 13, 20])])
+def test_distributed_ntt_and_sliced_msm(gpu, tmp_path, world, logs):
+    script = tmp_path / "dist_blocks_worker.py"
+    script.write_text(WORKER % {"root": ROOT, "logs": logs, "msm_log": 15, "c": 14})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29833 + world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok" % r in so, "rank %d:\n%s\n%s" % (r, so[-1500:], se[-3000:])

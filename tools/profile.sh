@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-seam-route $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # per-dispatch durations of the accumulate kernel: kernel_stats averages over index + warm-up + timed launches, the
@@ -24,16 +24,16 @@ for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
 rows.sort()
 d = [x[1] / 1e6 for x in rows]
 steps = 2
-per_prove = 8            # the 4 MSM groups of a prove (rounds 1-3, openings) run as two sub-batches each
+per_prove = 4            # the 4 MSM groups of a prove (rounds 1-3, openings); 8 with MH_FB_SPLIT=1
 timed = d[-per_prove * steps:]
 json.dump({"kernel": "bucket accumulation (msmfb::accum30_kernel)", "dispatch_ms_in_launch_order": [round(x, 3) for x in d],
            "avg_ms_all_dispatches": round(sum(d) / max(1, len(d)), 3),
            "avg_ms_timed_region": round(sum(timed) / max(1, len(timed)), 3),
-           "note": "timed region = the last 8 x %d dispatches (4 MSM groups per prove -- rounds 1-3 and the openings -- as two sub-batches each); "
+           "note": "timed region = the last 4 x %d dispatches (4 MSM groups per prove: rounds 1-3 and the openings); "
                    "earlier dispatches belong to Marlin::index (larger batches) and the warm-up prove" % steps},
           open(out + "/accum_dispatches.json", "w"), indent=1)
 PY
-CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"
+CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam-route $*"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD1 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $CMD1 > $OUT/pmc_write.log 2>&1
 find $OUT/pmc_fetch -name "*counter_collection.csv" -exec cp {} $OUT/pmc_fetch.csv \;
