@@ -180,6 +180,20 @@ def enable_alltoall(dist, device=None):
     _lib.check(lib.mh_marlin_set_alltoall(C.cast(cb, C.c_void_p), None), "mh_marlin_set_alltoall")
 
 
+def enable_simulated_alltoall(rank, world):
+    """MEASUREMENT ONLY (like enable_simulated_shard): this process acts as rank `rank` of `world` for mh_ntt_dist_dev with
+    the exchange replaced by a device-to-device copy of its own send buffer -- the values are meaningless, the kernels and
+    the bytes each rank would move are the real ones (tools/ntt_dist_bench.py)."""
+    lib = _lib.load()
+
+    def _cb(d_send, bytes_per_peer, d_recv, _user):
+        return lib.mh_memcpy_d2d(d_recv, d_send, bytes_per_peer * world) or lib.mh_synchronize()
+    cb = _ALLTOALL_T(_cb)
+    _keepalive["a2a"] = cb
+    _lib.check(lib.mh_marlin_set_alltoall(C.cast(cb, C.c_void_p), None), "mh_marlin_set_alltoall")
+    enable_simulated_shard(rank, world)
+
+
 def c_layout_slice(x, rank, world):
     """this rank's cyclic slice of a coefficient vector: x[rank + world * j]"""
     return np.ascontiguousarray(x[rank::world])

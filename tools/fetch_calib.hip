@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t mix(uint32_t h) { h ^= h >> 16; h *= 0x7feb3
 __global__ __launch_bounds__(256) void gather128_kernel(const Pt* __restrict__ tab, uint64_t slots, uint64_t n, uint32_t* __restrict__ sink) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint64_t s = (((uint64_t)mix((uint32_t)i) << 20) ^ mix((uint32_t)(i >> 7) + 0x9e3779b9u)) % slots;
+  const uint64_t s = (((uint64_t)mix((uint32_t)i) << 32) | mix((uint32_t)i ^ 0xdeadbeefu)) % slots;     // every lane its own slot
   const uint4* p = reinterpret_cast<const uint4*>(tab + s);
   uint32_t acc = 0;
 #pragma unroll
