@@ -151,9 +151,10 @@ class SeamRoute:
     (PC::trim).  Everything else the Rust prover does on the host between those calls is NOT included: this is a lower
     bound of what the seam route costs per proof, to be read beside the device-resident prover's number."""
 
-    def __init__(self, M, log_n, bases=None, seed=3):
+    def __init__(self, M, log_n, bases=None, seed=3, batched=True):
         from marlin_amd import workload as W, _lib
         self.M, self.lib, self.curve = M, _lib.load(), _lib.CURVE_ID
+        self.batched = batched
         self.N = 1 << log_n
         H, K = self.N, 4 * self.N
         self.ntts = W.ntt_inventory(H, K)
@@ -176,6 +177,14 @@ class SeamRoute:
         self.scal = rand_fr_np(rng, K)
         self.out = np.zeros(18, dtype=np.uint64)
         self.ntt_s = self.msm_s = 0.0
+        # the 15 MSMs by call: round 1 (w, z_a, z_b, mask), round 2 (t, g_1, g_1 shifted, h_1), round 3 (g_2, g_2 shifted, h_2),
+        # opening at beta (witness, shifted witness), opening at gamma (witness, shifted witness); distinct host vectors per
+        # polynomial, the SAME vector for a polynomial and its shifted commitment
+        self.groups = [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10], [11, 12], [13, 14]]
+        same_as = {6: 5, 9: 8}
+        self.vecs = {}
+        for i, (n, _) in enumerate(self.msms):
+            self.vecs[i] = self.vecs[same_as[i]] if i in same_as else self.scal[(i * 4099) % 1024:][:n].copy()
 
     def step(self, dist=None, torch=None):
         t0 = time.perf_counter()
@@ -183,16 +192,30 @@ class SeamRoute:
             rc = self.lib.mh_ntt(self.curve, self.data.ctypes.data, lg, 1 if inverse else 0)
             assert rc == 0
         t1 = time.perf_counter()
-        for (n, _), off in zip(self.msms, self.offsets):
-            rc = self.lib.mh_msm(self.bases.handle, off, self.scal.ctypes.data, 1, n, self.out.ctypes.data)
-            assert rc == 0, self.lib.mh_last_error()
+        if self.batched:
+            # one mh_msm_batch per PC::commit call (lib.rs:172,193,213) -- the labeled polynomials of a round -- and one per
+            # opening point (lib.rs:292); a degree-bounded polynomial passes the same host vector twice
+            import ctypes as C
+            for grp in self.groups:
+                k = len(grp)
+                handles = (C.c_uint64 * k)(*[self.bases.handle] * k)
+                offs = (C.c_size_t * k)(*[self.offsets[i] for i in grp])
+                ptrs = (C.c_void_p * k)(*[self.vecs[i].ctypes.data for i in grp])
+                ns = (C.c_size_t * k)(*[self.msms[i][0] for i in grp])
+                out = np.zeros(18 * k, dtype=np.uint64)
+                rc = self.lib.mh_msm_batch(k, handles, offs, ptrs, ns, 1, out.ctypes.data)
+                assert rc == 0, self.lib.mh_last_error()
+        else:
+            for (n, _), off in zip(self.msms, self.offsets):
+                rc = self.lib.mh_msm(self.bases.handle, off, self.scal.ctypes.data, 1, n, self.out.ctypes.data)
+                assert rc == 0, self.lib.mh_last_error()
         t2 = time.perf_counter()
         self.ntt_s += t1 - t0
         self.msm_s += t2 - t1
 
 
-def seam_route_measure(M, log_n, bases, steps=2):
-    sr = SeamRoute(M, log_n, bases)
+def seam_route_measure(M, log_n, bases, steps=2, batched=True):
+    sr = SeamRoute(M, log_n, bases, batched=batched)
     sr.step()                                        # warm-up: staging buffers, MSM workspace
     sr.ntt_s = sr.msm_s = 0.0
     for _ in range(steps):
@@ -202,8 +225,9 @@ def seam_route_measure(M, log_n, bases, steps=2):
     msm_bytes = sum(32 * n for n, _ in sr.msms)                        # scalars only: the bases are resident
     return {"ms_per_proof": round((sr.ntt_s + sr.msm_s) * 1e3 / steps, 2), "ntt_ms": round(sr.ntt_s * 1e3 / steps, 2),
             "msm_ms": round(sr.msm_s * 1e3 / steps, 2), "steps": steps,
+            "msm_calls": "one mh_msm_batch per PC::commit / opening point (5 calls)" if batched else "15 separate mh_msm calls",
             "pcie_bytes_per_proof": ntt_bytes + msm_bytes,
-            "what": "seam route lower bound: the reference's 30 transforms through mh_ntt and 15 MSMs through mh_msm with "
+            "what": "seam route lower bound: the reference's 30 transforms through mh_ntt and 15 MSMs through mh_msm_batch / mh_msm with "
                     "HOST pointers (pageable, like Vec<Fr>), SRS + window table resident; the Rust host work between the "
                     "calls is not included.  Compare with ms_per_step of the device-resident prover (mh_marlin_prove_dev)",
             "constraints_per_s": round(H / ((sr.ntt_s + sr.msm_s) / steps), 1)}
@@ -533,6 +557,7 @@ def main():
     elif workload == "marlin-prove" and rank == 0 and world == 1 and not args.no_seam_route and not args.simulate_rank:
         try:
             out["seam_route"] = seam_route_measure(M, args.log_constraints, wl.srs.powers_of_g)
+            out["seam_route"]["unbatched_msm_ms"] = seam_route_measure(M, args.log_constraints, wl.srs.powers_of_g, steps=1, batched=False)["msm_ms"]
         except Exception as e:                      # a side measurement must not cost the headline line
             out["seam_route"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -130,6 +130,11 @@ int mh_msm_dev(uint64_t bases_handle, size_t base_offset, const void* d_scalars,
  * out_xyz: njobs x 18 limbs. */
 int mh_msm_batch_dev(size_t njobs, const uint64_t* bases_handles, const size_t* base_offsets, const void* const* d_scalars,
                      const size_t* ns, int scalars_are_montgomery, uint64_t* out_xyz_mont);
+/* The same with the scalar vectors in HOST memory (what a Rust host holds): the polynomials of one PC::commit call go up
+ * back to back and run as one batch; a host vector that appears twice (a degree-bounded polynomial against powers and
+ * shifted powers) is uploaded once. */
+int mh_msm_batch(size_t njobs, const uint64_t* bases_handles, const size_t* base_offsets, const uint64_t* const* scalars,
+                 const size_t* ns, int scalars_are_montgomery, uint64_t* out_xyz_mont);
 /* Jacobian -> affine x||y (Montgomery) + infinity flag, on the host (GroupProjective::into_affine) */
 int mh_g1_to_affine(const uint64_t* xyz_mont, uint64_t* xy_mont_out, int* is_infinity_out);
 

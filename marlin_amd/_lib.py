@@ -48,6 +48,7 @@ SYMBOLS = {
     "mh_msm": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "mh_msm_dev": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "mh_msm_batch_dev": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mh_msm_batch": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mh_msm_batch_sharded_dev": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mh_g1_to_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mh_g1_sum": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),

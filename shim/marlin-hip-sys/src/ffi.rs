@@ -90,6 +90,8 @@ extern "C" {
     pub fn mh_msm_dev(bases_handle: u64, base_offset: usize, d_scalars: *const c_void, scalars_are_montgomery: c_int, n: usize, out_xyz_mont: *mut u64) -> c_int;
     pub fn mh_msm_batch_dev(njobs: usize, bases_handles: *const u64, base_offsets: *const usize, d_scalars: *const *const c_void,
                             ns: *const usize, scalars_are_montgomery: c_int, out_xyz_mont: *mut u64) -> c_int;
+    pub fn mh_msm_batch(njobs: usize, bases_handles: *const u64, base_offsets: *const usize, scalars: *const *const u64,
+                        ns: *const usize, scalars_are_montgomery: c_int, out_xyz_mont: *mut u64) -> c_int;
     pub fn mh_msm_batch_sharded_dev(njobs: usize, bases_handles: *const u64, base_offsets: *const usize, d_scalars: *const *const c_void,
                                     ns: *const usize, scalars_are_montgomery: c_int, out_xyz_mont: *mut u64) -> c_int;
     pub fn mh_g1_to_affine(xyz_mont: *const u64, xy_mont_out: *mut u64, is_infinity_out: *mut c_int) -> c_int;

@@ -160,6 +160,36 @@ pub fn msm_g1(srs: &GpuSrs, offset: usize, coeffs: &[Fr]) -> Result<G1Projective
     Ok(g1_from_jacobian_limbs(&out))
 }
 
+/// Several MSMs in ONE library call (`mh_msm_batch`): the polynomials of one `PC::commit` go up back to back and share one
+/// sort / accumulate / reduce sequence on the device; a coefficient slice that appears twice (a degree-bounded polynomial
+/// against `powers` and against `shifted_powers`) is uploaded once when both jobs name the same SRS handle.  Jobs are
+/// `(srs, offset, coefficients)`; results in job order.
+pub fn msm_g1_batch(jobs: &[(&GpuSrs, usize, &[Fr])]) -> Result<Vec<G1Projective>, HipError> {
+    if jobs.is_empty() {
+        return Ok(Vec::new());
+    }
+    // the library reads Montgomery limbs; `Fr` is `repr(Rust)`, so each vector is marshalled once (convert.rs)
+    let limbs: Vec<Vec<u64>> = jobs.iter().map(|(_, _, c)| fr_slice_to_limbs(c)).collect();
+    let handles: Vec<u64> = jobs.iter().map(|(s, _, _)| s.handle).collect();
+    let offsets: Vec<usize> = jobs.iter().map(|(_, o, _)| *o).collect();
+    let ns: Vec<usize> = jobs.iter().map(|(_, _, c)| c.len()).collect();
+    // same host slice (pointer and length) -> same marshalled buffer, so that the library sees the repeated vector
+    let mut ptrs: Vec<*const u64> = Vec::with_capacity(jobs.len());
+    for (j, (_, _, c)) in jobs.iter().enumerate() {
+        let first = jobs[..j].iter().position(|(_, _, d)| d.as_ptr() == c.as_ptr() && d.len() == c.len());
+        ptrs.push(match first {
+            Some(k) => limbs[k].as_ptr(),
+            None => limbs[j].as_ptr(),
+        });
+    }
+    for (j, (s, o, c)) in jobs.iter().enumerate() {
+        assert!(o + c.len() <= s.len, "MSM {} reads past the uploaded SRS", j);
+    }
+    let mut out = vec![0u64; 18 * jobs.len()];
+    check(unsafe { ffi::mh_msm_batch(jobs.len(), handles.as_ptr(), offsets.as_ptr(), ptrs.as_ptr(), ns.as_ptr(), 1, out.as_mut_ptr()) })?;
+    Ok(out.chunks_exact(18).map(g1_from_jacobian_limbs).collect())
+}
+
 /// Host MSM for the short ones (hiding terms: 3 coefficients on `powers_of_gamma_g`).
 pub(crate) fn msm_host(bases: &[G1Affine], coeffs: &[Fr]) -> G1Projective {
     let repr: Vec<_> = coeffs.iter().map(|c| c.into_repr()).collect();

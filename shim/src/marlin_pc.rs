@@ -15,7 +15,9 @@
 //! UNCOMPILED (see Cargo.toml).
 use crate::kzg::{kzg_commit, kzg_open_with_witness, srs_cache};
 use crate::HipError;
-use ark_bls12_381::{Bls12_381, Fr};
+use ark_bls12_381::{Bls12_381, Fr, G1Affine};
+use ark_ec::ProjectiveCurve;
+use ark_poly_commit::kzg10;
 use ark_ff::{One, Zero};
 use ark_poly::univariate::DensePolynomial;
 use ark_poly::{Polynomial, UVPolynomial};
@@ -100,37 +102,82 @@ impl PolynomialCommitment<Fr, P> for GpuMarlinKZG10 {
     {
         let mut rng = rng;
         let srs = srs_cache().get_or_upload(&ck.powers).map_err(pc_err)?;
-        let mut commitments = Vec::new();
-        let mut randomness = Vec::new();
-        for p in polynomials {
-            let label = p.label();
-            let degree_bound = p.degree_bound();
-            let hiding_bound = p.hiding_bound();
+        let polynomials: Vec<&'a LabeledPolynomial<Fr, P>> = polynomials.into_iter().collect();
+        // Pass 1 -- everything that touches the rng, in the reference's order (per polynomial: the blinding polynomial of the
+        // commitment, then that of the shifted commitment).  The multi-scalar multiplications consume no randomness, so they
+        // can run afterwards, all of them in ONE batched library call (kzg::msm_g1_batch -> mh_msm_batch).
+        struct Plan {
+            rand: kzg10::Randomness<Fr, P>,
+            shifted: Option<(std::sync::Arc<crate::kzg::GpuSrs>, usize, kzg10::Randomness<Fr, P>)>,
+        }
+        let mut plans = Vec::with_capacity(polynomials.len());
+        for p in &polynomials {
             let polynomial: &P = p.polynomial();
             // Error::check_degrees_and_bounds(ck.supported_degree(), ck.max_degree, enforced_degree_bounds, p)
             if polynomial.degree() > ck.powers.len() - 1 {
                 return Err(PCError::TooManyCoefficients { num_coefficients: polynomial.degree() + 1, num_powers: ck.powers.len() });
             }
-            let (comm, rand) = kzg_commit(
-                &srs, &ck.powers, &ck.powers_of_gamma_g, 0, polynomial, hiding_bound,
-                rng.as_mut().map(|r| &mut **r as &mut dyn RngCore),
-            ).map_err(pc_err)?;
-            let (shifted_comm, shifted_rand) = if let Some(d) = degree_bound {
+            let draw = |rng: &mut Option<&mut dyn RngCore>| -> Result<kzg10::Randomness<Fr, P>, PCError> {
+                match p.hiding_bound() {
+                    // Randomness::rand(hiding_bound, false, None, rng): blinding_polynomial = P::rand(hiding_bound + 1, rng)
+                    Some(h) => Ok(kzg10::Randomness::rand(h, false, None, rng.as_mut().ok_or(PCError::MissingRng)?)),
+                    None => Ok(kzg10::Randomness::empty()),
+                }
+            };
+            let rand = draw(&mut rng)?;
+            let shifted = if let Some(d) = p.degree_bound() {
                 let sp = ck.shifted_powers.as_ref().ok_or(PCError::UnsupportedDegreeBound(d))?;
                 let ssrs = srs_cache().get_or_upload(sp).map_err(pc_err)?;
                 // ck.shifted_powers(d) = powers_of_g[max_degree - d ..]; sp starts at max_degree - highest bound
                 let highest = *ck.enforced_degree_bounds.as_ref().and_then(|v| v.last()).ok_or(PCError::UnsupportedDegreeBound(d))?;
-                let off = highest - d;
-                let (sc, sr) = kzg_commit(
-                    &ssrs, sp, &ck.powers_of_gamma_g, off, polynomial, hiding_bound,
-                    rng.as_mut().map(|r| &mut **r as &mut dyn RngCore),
-                ).map_err(pc_err)?;
-                (Some(sc), Some(sr))
+                Some((ssrs, highest - d, draw(&mut rng)?))
             } else {
-                (None, None)
+                None
             };
-            commitments.push(LabeledCommitment::new(label.to_string(), marlin_pc::Commitment { comm, shifted_comm }, degree_bound));
-            randomness.push(marlin_pc::Randomness { rand, shifted_rand });
+            plans.push(Plan { rand, shifted });
+        }
+        // Pass 2 -- the large MSMs of the call as one batch (skip_leading_zeros as kzg10::commit does; short ones on the host)
+        let mut jobs: Vec<(&crate::kzg::GpuSrs, usize, &[Fr])> = Vec::new();
+        let mut slot: Vec<(Option<usize>, Option<usize>)> = Vec::new();
+        for (p, plan) in polynomials.iter().zip(&plans) {
+            let coeffs: &[Fr] = &p.polynomial().coeffs;
+            let lz = coeffs.iter().take_while(|c| c.is_zero()).count();
+            let tail = &coeffs[lz..];
+            let big = tail.len() >= crate::kzg::GPU_MSM_THRESHOLD;
+            let a = if big { jobs.push((&*srs, lz, tail)); Some(jobs.len() - 1) } else { None };
+            let b = match (&plan.shifted, big) {
+                (Some((ssrs, off, _)), true) => { jobs.push((&**ssrs, off + lz, tail)); Some(jobs.len() - 1) }
+                _ => None,
+            };
+            slot.push((a, b));
+        }
+        let sums = crate::kzg::msm_g1_batch(&jobs).map_err(pc_err)?;
+        // Pass 3 -- hiding parts (3 coefficients, host) and normalisation, per polynomial as upstream
+        let mut commitments = Vec::new();
+        let mut randomness = Vec::new();
+        for ((p, plan), (a, b)) in polynomials.iter().zip(plans.into_iter()).zip(slot) {
+            let coeffs: &[Fr] = &p.polynomial().coeffs;
+            let finish = |sum: Option<usize>, host_powers: &[G1Affine], off: usize, rand: &kzg10::Randomness<Fr, P>| {
+                let mut c = match sum {
+                    Some(i) => sums[i],
+                    None => crate::kzg::msm_host(&host_powers[off..off + coeffs.len()], coeffs),
+                };
+                let blind = &rand.blinding_polynomial.coeffs;
+                if !blind.is_empty() {
+                    c.add_assign_mixed(&crate::kzg::msm_host(&ck.powers_of_gamma_g[..blind.len()], blind).into_affine());
+                }
+                kzg10::Commitment(c.into_affine())
+            };
+            let comm = finish(a, &ck.powers, 0, &plan.rand);
+            let (shifted_comm, shifted_rand) = match plan.shifted {
+                Some((_, off, srand)) => {
+                    let sp = ck.shifted_powers.as_ref().unwrap();
+                    (Some(finish(b, sp, off, &srand)), Some(srand))
+                }
+                None => (None, None),
+            };
+            commitments.push(LabeledCommitment::new(p.label().to_string(), marlin_pc::Commitment { comm, shifted_comm }, p.degree_bound()));
+            randomness.push(marlin_pc::Randomness { rand: plan.rand, shifted_rand });
         }
         Ok((commitments, randomness))
     }
