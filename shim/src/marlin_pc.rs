@@ -17,7 +17,6 @@ use crate::kzg::{kzg_commit, kzg_open_with_witness, srs_cache};
 use crate::HipError;
 use ark_bls12_381::{Bls12_381, Fr, G1Affine};
 use ark_ec::ProjectiveCurve;
-use ark_poly_commit::kzg10;
 use ark_ff::{One, Zero};
 use ark_poly::univariate::DensePolynomial;
 use ark_poly::{Polynomial, UVPolynomial};
