@@ -377,6 +377,67 @@ int ref_bases_arith(const u64* a0_canon, const u64* d_canon, size_t n, u64* out_
   return 0;
 }
 
+/* KZG10::setup's powers for a KNOWN tau (test SRS; what `Marlin::universal_setup` -> `kzg10::setup` computes with its
+ * FixedBaseMSM after drawing beta, /root/reference src/lib.rs:79-96): out[i] = [scale * tau^i]G, i < n, affine x||y
+ * Montgomery.  Byte windows over a table T[w][d] = [d 256^w]G; batch-normalised per chunk.  tau, scale: canonical limbs. */
+int ref_srs_powers(const u64* tau_canon, const u64* scale_canon, size_t n, int threads, u64* out_xy) {
+  if (threads < 1) threads = 1;
+  jac_t g; fq_mul(g.x, G1_GX, FQ_R2); fq_mul(g.y, G1_GY, FQ_R2); memcpy(g.z, FQ_ONE, FQB);
+  jac_t* T = (jac_t*)malloc(sizeof(jac_t) * 32 * 256);
+  if (!T) return -2;
+  jac_t base = g;
+  for (int w = 0; w < 32; w++) {
+    jac_set_identity(&T[w * 256]);
+    for (int d = 1; d < 256; d++) jac_add(&T[w * 256 + d], &T[w * 256 + d - 1], &base);
+    jac_add(&base, &T[w * 256 + 255], &base);              /* 256 * base */
+  }
+  u64 tau[4], sc[4];
+  memcpy(tau, tau_canon, 32); memcpy(sc, scale_canon, 32);
+  fr_mul(tau, tau, FR_R2); fr_mul(sc, sc, FR_R2);           /* Montgomery */
+  const size_t CH = 4096;
+  const long nch = (long)((n + CH - 1) / CH);
+  int rc = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic)
+  for (long c = 0; c < nch; c++) {
+    size_t i0 = (size_t)c * CH, i1 = i0 + CH < n ? i0 + CH : n, m = i1 - i0;
+    jac_t* pts = (jac_t*)malloc(sizeof(jac_t) * m);
+    u64* prod = (u64*)malloc(m * FQB);
+    if (!pts || !prod) { rc = -2; free(pts); free(prod); continue; }
+    u64 e[4];
+    fr_pow(e, tau, (u64)i0);
+    fr_mul(e, e, sc);                                       /* scale * tau^i0, Montgomery */
+    u64 acc[FQN]; memcpy(acc, FQ_ONE, FQB);
+    for (size_t k = 0; k < m; k++) {
+      u64 can[4]; memcpy(can, e, 32);
+      ref_fr_from_mont(can, 1);
+      jac_t p; jac_set_identity(&p);
+      for (int w = 0; w < 32; w++) {
+        unsigned d = (unsigned)((can[w / 8] >> (8 * (w % 8))) & 0xff);
+        if (d) jac_add(&p, &p, &T[w * 256 + d]);
+      }
+      pts[k] = p;
+      if (jac_is_identity(&p)) { rc = -3; memcpy(prod + FQN * k, acc, FQB); }   /* scale * tau^i = 0 mod r: not an SRS */
+      else { fq_mul(acc, acc, p.z); memcpy(prod + FQN * k, acc, FQB); }
+      fr_mul(e, e, tau);
+    }
+    if (rc == 0) {
+      u64 inv[FQN]; fq_inv(inv, acc);
+      for (size_t k = m; k-- > 0;) {
+        u64 zi[FQN];
+        if (k) fq_mul(zi, inv, prod + FQN * (k - 1)); else memcpy(zi, inv, FQB);
+        fq_mul(inv, inv, pts[k].z);
+        u64 zi2[FQN], zi3[FQN];
+        fq_mul(zi2, zi, zi); fq_mul(zi3, zi2, zi);
+        fq_mul(out_xy + 2 * FQN * (i0 + k), pts[k].x, zi2);
+        fq_mul(out_xy + 2 * FQN * (i0 + k) + FQN, pts[k].y, zi3);
+      }
+    }
+    free(pts); free(prod);
+  }
+  free(T);
+  return rc;
+}
+
 /* ------------------------------------------------------------------ MSM ------- */
 typedef struct {
   const u64* bases; const u64* scalars; size_t n; unsigned c; unsigned w_start; jac_t result;

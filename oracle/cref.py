@@ -44,6 +44,8 @@ def lib():
         L.ref_fr_div_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.ref_fr_eval.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.ref_fr_add_at.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ref_srs_powers.restype = C.c_int
+        L.ref_srs_powers.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.ref_curve_id.restype = C.c_int
         assert L.ref_curve_id() == {"bls12_381": 0, "bn254": 1}[_F.CURVE]
         _lib = L
@@ -152,3 +154,12 @@ def add_at(dst, off, src):
     assert dst.flags["C_CONTIGUOUS"] and off + len(src) <= len(dst)
     if len(src):
         lib().ref_fr_add_at(dst.ctypes.data, off, src.ctypes.data, len(src))
+
+
+def srs_powers(tau, n, scale=1, threads=1):
+    """[scale * tau^i]G, i < n, as (n, 2 * FQL) uint64 affine Montgomery (KZG10::setup's powers for a known tau)."""
+    out = np.zeros((n, 2 * FQL), dtype=np.uint64)
+    t, s = _limbs(tau % _F.R_MOD, 4), _limbs(scale % _F.R_MOD, 4)
+    rc = lib().ref_srs_powers(t.ctypes.data, s.ctypes.data, n, int(threads), out.ctypes.data)
+    assert rc == 0, rc
+    return out

@@ -9,6 +9,11 @@ Run from the repo root:
     python tests/golden/make_golden.py            # the src/test.rs shapes (marlin_proofs.json, ~1 min)
     python tests/golden/make_golden.py large      # DummyCircuit at 2^10 (BASELINE configs[0]), 2^12, 2^14
                                                   # (marlin_proofs_large.json, ~15 min of pure-Python big-int work)
+    python tests/golden/make_golden.py xl [logs]  # DummyCircuit at 2^16, 2^18 (BASELINE configs[1]) [, 2^20 = configs[2]] with
+                                                  # the oracle's C backend for NTT / MSM / SRS (oracle/accel.py; the AHP
+                                                  # rounds, the PC logic and Fiat-Shamir stay Python): marlin_proofs_xl.json.
+                                                  # Before it writes anything it re-proves the 2^12 case of the pure-Python
+                                                  # file with the backend on and checks the bytes.
 """
 import hashlib
 import json
@@ -47,8 +52,26 @@ def build(kind, nc, nv):
 def main():
     large = len(sys.argv) > 1 and sys.argv[1] == "large"
     cases, fname = (LARGE_CASES, "marlin_proofs_large.json") if large else (CASES, "marlin_proofs.json")
+    if len(sys.argv) > 1 and sys.argv[1] == "xl":
+        from oracle import accel
+        accel.enable()
+        # the backend must reproduce the pure-Python oracle before its output is trusted as a fixture
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "marlin_proofs_large.json")))
+        c12 = [c for c in ref["cases"] if c["num_constraints"] == 1 << 12][0]
+        a, b, cs, pub = build("dummy_circuit", 1 << 12, 10)
+        srs = MR.universal_setup(1 << 12, 1 << 12, 3 << 12, TAU, GAMMA)
+        pk = MR.marlin_index(srs, cs)
+        assert MR.proof_bytes(MR.prove(pk, cs, FS.ChaChaRng(ZK_SEED, 20))).hex() == c12["proof_bytes"], "C backend diverges from the pure-Python oracle"
+        logs = [int(x) for x in sys.argv[2:]] or [16, 18]
+        cases, fname = [("dummy_circuit", 1 << lg, 10) for lg in logs], "marlin_proofs_xl.json"
     out = {"tau": hex(TAU), "gamma": hex(GAMMA), "zk_seed": ZK_SEED.hex(), "zk_rng": "ChaCha20 (rand_chacha ChaChaRng::from_seed)",
            "cases": []}
+    path = os.path.join(ROOT, "tests", "golden", fname)
+    if fname == "marlin_proofs_xl.json":
+        out["producer"] = "oracle/*.py with the C backend of oracle/accel.py for NTT / MSM / SRS powers (self-consistency vectors, not arkworks output)"
+        if os.path.exists(path):                                  # add sizes to an existing file
+            out = json.load(open(path))
+            out["cases"] = [c for c in out["cases"] if (c["kind"], c["num_constraints"], c["num_variables"]) not in cases]
     for kind, nc, nv in cases:
         a, b, cs, pub = build(kind, nc, nv)
         nnz = 3 * max(nc, nv)

@@ -1,7 +1,9 @@
 """Parity pins above the sizes the pure-Python oracle can prove at.
 
 * byte-identical proofs against oracle-generated golden fixtures at 2^10 (BASELINE configs[0]), 2^12 and 2^14
-  (tests/golden/marlin_proofs_large.json, tests/golden/make_golden.py large);
+  (tests/golden/marlin_proofs_large.json, tests/golden/make_golden.py large: the pure-Python oracle) and at 2^16, 2^18
+  (configs[1]) and 2^20 (configs[2]) (tests/golden/marlin_proofs_xl.json, make_golden.py xl: the same oracle with its C
+  backend for NTT / MSM / SRS powers, oracle/accel.py) -- every prover polynomial hashed, the proof compared byte for byte;
 * the device's `DensePolynomial::rand` (rng.cuh: ChaCha blocks in parallel + rejection sampling as stream
   compaction) against the sequential `Fp256::rand` stream at 2^16 / 2^18 (3|H| draws, prover.rs:370-380);
 * at 2^18 (configs[1]), 2^20 (configs[2]), 2^22 (configs[3] on one GPU) and, in the BN254 subprocess, BN254 +
@@ -22,6 +24,11 @@ from marlin_amd import marlin as GM
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LARGE = json.load(open(os.path.join(ROOT, "tests", "golden", "marlin_proofs_large.json")))
+# 2^16, 2^18 (BASELINE configs[1]), 2^20 (configs[2]): whole proofs from the oracle with its C backend for NTT / MSM / SRS
+# (oracle/accel.py: a CPU prover that shares no code with the device; tests/golden/make_golden.py xl)
+_XL_PATH = os.path.join(ROOT, "tests", "golden", "marlin_proofs_xl.json")
+XL = json.load(open(_XL_PATH)) if os.path.exists(_XL_PATH) else {"cases": []}
+assert not XL["cases"] or (XL["tau"], XL["gamma"], XL["zk_seed"]) == (LARGE["tau"], LARGE["gamma"], LARGE["zk_seed"])
 TAU, GAMMA, SEED = int(LARGE["tau"], 16), int(LARGE["gamma"], 16), bytes.fromhex(LARGE["zk_seed"])
 BLS = pytest.mark.skipif(F.CURVE != "bls12_381", reason="fixtures and the C restatement are BLS12-381 / MarlinKZG10")
 
@@ -39,7 +46,7 @@ def _fr_bytes_of(arr):
 
 
 @BLS
-@pytest.mark.parametrize("case", LARGE["cases"], ids=lambda c: "2^%d" % (c["num_constraints"].bit_length() - 1))
+@pytest.mark.parametrize("case", LARGE["cases"] + XL["cases"], ids=lambda c: "2^%d" % (c["num_constraints"].bit_length() - 1))
 def test_proof_bytes_match_golden_large(gpu, case):
     n = case["num_constraints"]
     a, b = int(case["a"], 16), int(case["b"], 16)

@@ -130,3 +130,25 @@ def test_reference_fixture_dimensions():
         idx_h = OP.Domain(cs.num_constraints).size
         nnz = sum(len(set([j for _, j in ra] + [j for _, j in rb] + [j for _, j in rc])) for ra, rb, rc in zip(cs.a, cs.b, cs.c))
         assert (idx_h, OP.Domain(nnz).size) == (H, K)
+
+
+def test_c_backend_of_the_oracle_reproduces_the_pure_python_proof():
+    """oracle/accel.py swaps the oracle's NTT (>= 2^10 points), its KZG10 MSM (>= 2^10 coefficients) and its SRS powers for
+    the C restatement -- the backend behind tests/golden/marlin_proofs_xl.json (2^16 .. 2^20).  At 2^8 constraints (H = 2^8,
+    K = 2^10: transforms of 2^10 and 2^11 points and K-sized MSMs take the C path) index and proof bytes must be the
+    pure-Python oracle's, for both PC schemes."""
+    from oracle import accel
+    a, b, n = 0x1234567, 0x7654321, 1 << 8
+
+    def run(pc):
+        cs = AHP.pad_and_square(AHP.dummy_circuit(a, b, 10, n))
+        srs = MR.universal_setup(n, n, 3 * n, 0x1f3a9c5d7e2b4a6f, 0x5eed5eed)
+        pk = MR.marlin_index(srs, cs, pc)
+        return MR.vk_bytes(pk), MR.proof_bytes(MR.prove(pk, cs, FS.ChaChaRng(bytes(range(32)), 20)))
+    pure = {pc: run(pc) for pc in ("marlin", "sonic")}
+    accel.enable(threads=2)
+    try:
+        fast = {pc: run(pc) for pc in ("marlin", "sonic")}
+    finally:
+        accel.disable()
+    assert fast == pure
