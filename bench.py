@@ -325,6 +325,8 @@ def main():
     ap.add_argument("--log-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["marlin-prove", "hotpath-inventory", "seam-route"], default=None)
+    ap.add_argument("--no-sliced", action="store_true",
+                    help="multi-GPU: keep rounds 2 and 3 replicated on every rank (no distributed transforms / all-to-all)")
     ap.add_argument("--no-seam-route", action="store_true", help="skip the (untimed, ~1 s) seam-route measurement of the default run")
     ap.add_argument("--cpu-baseline-log", type=int, default=18,
                     help="log2 constraints of the CPU baseline's all-core sample (default 18, ~20 s; 20 = the headline size, minutes)")
@@ -393,10 +395,15 @@ def main():
         if world > 1:
             from marlin_amd import dist as MD
             MD.enable_sharded_prove(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
+            if not args.no_sliced:
+                MD.enable_alltoall(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
         elif args.simulate_rank:
             from marlin_amd import dist as MD
             sr, sg = (int(x) for x in args.simulate_rank.split("/"))
-            MD.enable_simulated_shard(sr, sg)
+            if args.no_sliced:
+                MD.enable_simulated_shard(sr, sg)
+            else:
+                MD.enable_simulated_alltoall(sr, sg)
     elif workload == "seam-route":
         wl = SeamRoute(M, args.log_constraints)
     else:
@@ -520,7 +527,9 @@ def main():
                                + "DummyCircuit 2^%d constraints, BLS12-381, MarlinKZG10 (benches/bench.rs shape; SURVEY.md Appendix A)"
                                % args.log_constraints,
                    "constraints": wl.N, "curve": "BLS12-381", "pc": "MarlinKZG10",
-                   "parallelism": "msm sharded by bucket range x%d (one all_gather of partial points per commit round), AHP rounds replicated" % world},
+                   "parallelism": ("msm sharded by bucket range x%d (one all_gather of partial points per commit round), " % world) +
+                                  ("AHP rounds replicated" if world == 1 or args.no_sliced else
+                                   "rounds 2 and 3 on slices (distributed transforms with one all-to-all each, one all-gather of the round's polynomials), round 1 and the openings replicated")},
         "breakdown_ms_per_step": {"ntt": round(ntt_ms / args.steps, 3), "msm": round(msm_ms / args.steps, 3),
                                   "msm_accum": round(acc_ms / args.steps, 3),
                                   "msm_sort_and_reduce_stages": round(stages_ms / args.steps, 3),
@@ -543,6 +552,7 @@ def main():
         args.no_cpu_baseline = True          # the C restatement covers the headline configuration only
     if args.simulate_rank:
         out["simulated_rank"] = args.simulate_rank
+        out["simulated_sliced_rounds"] = not args.no_sliced
         out["value"] = None
         out["note"] = ("simulation of one rank of a multi-GPU run on one GPU (exchange replaced by a local copy): ms_per_step is "
                        "that rank's time without the all_gather; the proofs made are not valid; not a benchmark result")

@@ -50,4 +50,30 @@ __global__ __launch_bounds__(256) void gdft_kernel(Fr* __restrict__ out, const F
   for (int k = 0; k < G; k++) ff_store(out + (u64)k * chunk + t, a[k]);
 }
 
+// ---- moving vectors between the replicated and the sliced world (prover.hip: the sliced sections of rounds 2 and 3) -------
+// C-layout slice of a replicated coefficient vector: dst[j] = src[r + G j]
+__global__ __launch_bounds__(256) void slice_c_kernel(Fr* __restrict__ dst, const Fr* __restrict__ src, u64 nloc, u32 r, u32 G) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nloc) ff_store(dst + j, ff_load(src + r + (u64)G * j));
+}
+// M-layout block of a replicated evaluation vector on a domain of G m points: dst[l] = src[r chunk + (l mod chunk) + m (l / chunk)]
+__global__ __launch_bounds__(256) void gather_m_kernel(Fr* __restrict__ dst, const Fr* __restrict__ src, u64 m, u64 chunk, u32 r) {
+  const u64 l = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < m) ff_store(dst + l, ff_load(src + (u64)r * chunk + (l % chunk) + m * (l / chunk)));
+}
+// the all-to-all used as an all-gather: the same chunk (a's na elements followed by b's nb) for every peer
+__global__ __launch_bounds__(256) void replicate_kernel(Fr* __restrict__ send, const Fr* __restrict__ a, u64 na, const Fr* __restrict__ b,
+                                                        u64 nb, u32 G) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 ch = na + nb;
+  if (i >= ch) return;
+  const Fr v = i < na ? ff_load(a + i) : ff_load(b + (i - na));
+  for (u32 q = 0; q < G; q++) ff_store(send + (u64)q * ch + i, v);
+}
+// back to a replicated coefficient vector from the gathered C-layout slices: full[i] = recv[(i mod G) stride + off + i / G]
+__global__ __launch_bounds__(256) void unslice_c_kernel(Fr* __restrict__ full, const Fr* __restrict__ recv, u64 len, u32 G, u64 stride, u64 off) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) ff_store(full + i, ff_load(recv + (i % G) * stride + off + i / G));
+}
+
 }  // namespace nttdist

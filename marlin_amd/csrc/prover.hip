@@ -90,6 +90,10 @@ struct ProverKey {
   DBuf S[8];
   DBuf small;       // partial sums / carries
   DBuf scal;        // a few device scalars (scan totals)
+  // sliced sections (multi-GPU): this rank's M-layout blocks of the 12 index evaluation vectors and its twist
+  // tables g^(+-(r + G j)), built when the shard geometry is first seen
+  DBuf sl_ev[6], sl_cs[6], sl_gpow_hi, sl_gpow_lo, sl_ginv_hi, sl_ginv_lo;
+  int sl_rank = -1, sl_world = 0;
   std::map<std::string, std::pair<const Fr*, uint64_t>> last_polys;   // prover oracles of the last proof (label -> ptr, len)
   void free_all() {
     DBuf* all[] = {&ev_row, &ev_col, &ev_row_col, &ev_val_a, &ev_val_b, &ev_val_c, &p_row, &p_col, &p_a_val, &p_b_val, &p_c_val,
@@ -98,6 +102,10 @@ struct ProverKey {
                    &z, &za_ev, &zb_ev, &xpoly, &w, &za, &zb, &mask, &t, &g1, &h1, &g2, &h2, &outer, &inner, &small, &scal};
     for (auto* b : all) b->release();
     for (auto& s : S) s.release();
+    for (auto& b : sl_ev) b.release();
+    for (auto& b : sl_cs) b.release();
+    for (DBuf* b : {&sl_gpow_hi, &sl_gpow_lo, &sl_ginv_hi, &sl_ginv_lo}) b->release();
+    sl_rank = -1; sl_world = 0;
   }
 };
 
@@ -288,6 +296,7 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
 struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; mh_alltoall_fn a2a = nullptr; void* a2a_user = nullptr; } g_shard;
 
 HG1 jac_from(const uint64_t* xyz);
+int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, uint32_t log_n, int inverse);
 struct MsmJob { const char* bases; const Fr* scalars; uint64_t n; };
 // all jobs in one launch sequence (msm_batch_device) and ONE all_gather for all partial points.
 // Payload per rank: nj Jacobian points | one error word | nj flag words (1 = this rank's point is its SHARE of the sum,
@@ -606,15 +615,11 @@ int mh_marlin_set_alltoall(mh_alltoall_fn alltoall, void* user) {
   return MH_OK;
 }
 
-// One transform of 2^log_n points over the registered ranks (ntt_dist.cuh).  forward: d_in = this rank's cyclic slice of the
-// coefficients (C-layout), d_out = its block of the evaluations (M-layout); inverse: the other way round.  n / world elements
-// each; d_in may equal d_out.
-int mh_ntt_dist_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
-  LOCKED_CTX();
-  if (field != hostff::CURVE_ID) return fail(MH_EINVAL, "mh_ntt_dist_dev: unsupported field");
-  if (!d_in || !d_out) return fail(MH_EINVAL, "mh_ntt_dist_dev: null pointer");
+}  // extern "C"
+namespace {
+// the transform itself; forward accepts a SHORT slice (in_len <= n / world local coefficients, the rest reads as zero)
+int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, uint32_t log_n, int inverse) {
   const int G = g_shard.world, rank = g_shard.rank;
-  if (G == 1) return ntt_device(c, d_in, d_out, log_n, inverse);
   uint32_t lg = 0;
   while ((1 << lg) < G) lg++;
   if ((1 << lg) != G || G > 16) return fail(MH_EINVAL, "mh_ntt_dist_dev: the number of ranks must be a power of two <= 16");
@@ -673,7 +678,7 @@ int mh_ntt_dist_dev(int field, const void* d_in, void* d_out, uint32_t log_n, in
     return MH_OK;
   };
   if (!inverse) {
-    MH_TRY(ntt_device(c, d_in, A, log_m, 0));        // Y_rank = local transform of the cyclic slice
+    MH_TRY(ntt_device_len(c, d_in, in_len, A, log_m, 0));   // Y_rank = local transform of the cyclic slice (short input: zero-padded)
     MH_TRY(twist(A));                                // * w_n^(rank k2)
     MH_TRY(exchange(A, B));                          // chunk q = k2 in block q -> rank q
     MH_TRY(gdft((Fr*)d_out, B));                     // X[k2 + m k1], k1-major
@@ -684,6 +689,84 @@ int mh_ntt_dist_dev(int field, const void* d_in, void* d_out, uint32_t log_n, in
     MH_TRY(ntt_device(c, B, d_out, log_m, 1));       // local inverse (with m^-1)
   }
   return MH_OK;
+}
+}  // namespace
+namespace {
+// ---- sliced sections of the prover ----------------------------------------------------------------------
+// The 4H- and K-sized transforms of rounds 2 and 3 and the pointwise work between them run on SLICES: every rank takes its
+// cyclic slice of the (replicated) coefficient vectors, the transforms are distributed (one all-to-all each), the pointwise
+// kernels see 1 / G of the domain, and one all-gather per round brings the round's polynomials back to every rank for the
+// bucket-sharded commitments.  Proof bytes are unchanged: field arithmetic is exact whoever does it.
+inline unsigned grid256(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+// this rank's cyclic slice of a replicated coefficient vector of `len` elements; returns its length
+uint64_t slice_c(Context& c, Fr* dst, const Fr* src, uint64_t len) {
+  const uint64_t G = (uint64_t)g_shard.world, r = (uint64_t)g_shard.rank;
+  const uint64_t nloc = len > r ? (len - r + G - 1) / G : 0;
+  if (nloc) hipLaunchKernelGGL(nttdist::slice_c_kernel, dim3(grid256(nloc)), dim3(256), 0, c.stream, dst, src, (u64)nloc, (u32)r, (u32)G);
+  return nloc;
+}
+// all ranks' (a | b) chunks, rank-major: the all-to-all with the same chunk for every peer
+int allgather2(Context& c, const Fr* a, uint64_t na, const Fr* b, uint64_t nb, const Fr** recv_out) {
+  const uint64_t G = (uint64_t)g_shard.world, ch = na + nb;
+  MH_TRY(c.sl_send.ensure(G * ch * 32)); MH_TRY(c.sl_recv.ensure(G * ch * 32));
+  hipLaunchKernelGGL(nttdist::replicate_kernel, dim3(grid256(ch)), dim3(256), 0, c.stream, (Fr*)c.sl_send.ptr, a, (u64)na, b, (u64)nb, (u32)G);
+  MH_HIP(hipGetLastError());
+  MH_HIP(hipStreamSynchronize(c.stream));
+  if (g_shard.a2a(c.sl_send.ptr, (size_t)ch * 32, c.sl_recv.ptr, g_shard.a2a_user) != 0) return fail(MH_EHIP, "sliced prove: all_to_all callback failed");
+  *recv_out = (const Fr*)c.sl_recv.ptr;
+  return MH_OK;
+}
+void unslice_c(Context& c, Fr* full, const Fr* recv, uint64_t len, uint64_t stride, uint64_t off) {
+  hipLaunchKernelGGL(nttdist::unslice_c_kernel, dim3(grid256(len)), dim3(256), 0, c.stream, full, recv, (u64)len, (u32)g_shard.world, (u64)stride, (u64)off);
+}
+
+// per-key, per-geometry data of the sliced sections: M-layout blocks of the index evaluation vectors the third round reads,
+// and the twist tables g^(+-(r + G j)) = lo[j & 2047] * hi[j >> 11]
+int prepare_sliced(Context& c, ProverKey& pk) {
+  const int G = g_shard.world, r = g_shard.rank;
+  if (pk.sl_rank == r && pk.sl_world == G) return MH_OK;
+  const uint64_t K = pk.K, m = K / (uint64_t)G, chunk = m / (uint64_t)G;
+  const DBuf* ev_src[5] = {&pk.ev_row, &pk.ev_col, &pk.ev_val_a, &pk.ev_val_b, &pk.ev_val_c};
+  const DBuf* cs_src[6] = {&pk.cs_val_a, &pk.cs_val_b, &pk.cs_val_c, &pk.cs_row, &pk.cs_col, &pk.cs_row_col};
+  for (int q = 0; q < 5; q++) {
+    MH_TRY(pk.sl_ev[q].alloc(m * 32));
+    hipLaunchKernelGGL(nttdist::gather_m_kernel, dim3(grid256(m)), dim3(256), 0, c.stream, pk.sl_ev[q].fr(), (const Fr*)ev_src[q]->p, (u64)m, (u64)chunk, (u32)r);
+  }
+  for (int q = 0; q < 6; q++) {
+    MH_TRY(pk.sl_cs[q].alloc(m * 32));
+    hipLaunchKernelGGL(nttdist::gather_m_kernel, dim3(grid256(m)), dim3(256), 0, c.stream, pk.sl_cs[q].fr(), (const Fr*)cs_src[q]->p, (u64)m, (u64)chunk, (u32)r);
+  }
+  MH_HIP(hipGetLastError());
+  const uint64_t LO = 1ull << poly::COSET_LO_BITS, nhi = (m + LO - 1) / LO;
+  std::vector<uint64_t> lo(4 * LO), hi(4 * nhi), ilo(4 * LO), ihi(4 * nhi);
+  const HFr g = pk.coset_g, ginv = g.inv();
+  const HFr gG = g.pow_u64((uint64_t)G), giG = ginv.pow_u64((uint64_t)G);
+  HFr a = g.pow_u64((uint64_t)r), b = ginv.pow_u64((uint64_t)r);
+  for (uint64_t j = 0; j < LO; j++) { memcpy(&lo[4 * j], a.v, 32); memcpy(&ilo[4 * j], b.v, 32); a = a * gG; b = b * giG; }
+  const HFr gL = gG.pow_u64(LO), giL = giG.pow_u64(LO);
+  a = HFr::one(); b = HFr::one();
+  for (uint64_t j = 0; j < nhi; j++) { memcpy(&hi[4 * j], a.v, 32); memcpy(&ihi[4 * j], b.v, 32); a = a * gL; b = b * giL; }
+  MH_TRY(pk.sl_gpow_lo.alloc(LO * 32)); MH_TRY(pk.sl_ginv_lo.alloc(LO * 32)); MH_TRY(pk.sl_gpow_hi.alloc(nhi * 32)); MH_TRY(pk.sl_ginv_hi.alloc(nhi * 32));
+  MH_TRY(h2d(c, pk.sl_gpow_lo.p, lo.data(), LO * 32)); MH_TRY(h2d(c, pk.sl_ginv_lo.p, ilo.data(), LO * 32));
+  MH_TRY(h2d(c, pk.sl_gpow_hi.p, hi.data(), nhi * 32)); MH_TRY(h2d(c, pk.sl_ginv_hi.p, ihi.data(), nhi * 32));
+  MH_HIP(hipStreamSynchronize(c.stream));
+  pk.sl_rank = r; pk.sl_world = G;
+  return MH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// One transform of 2^log_n points over the registered ranks (ntt_dist.cuh).  forward: d_in = this rank's cyclic slice of the
+// coefficients (C-layout), d_out = its block of the evaluations (M-layout); inverse: the other way round.  n / world elements
+// each; d_in may equal d_out.
+int mh_ntt_dist_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse) {
+  LOCKED_CTX();
+  if (field != hostff::CURVE_ID) return fail(MH_EINVAL, "mh_ntt_dist_dev: unsupported field");
+  if (!d_in || !d_out) return fail(MH_EINVAL, "mh_ntt_dist_dev: null pointer");
+  if (g_shard.world == 1) return ntt_device(c, d_in, d_out, log_n, inverse);
+  return ntt_dist_device(c, d_in, (1ull << log_n) / (uint64_t)g_shard.world, d_out, log_n, inverse);
 }
 
 // MSMs of this rank's CYCLIC slices (ntt_dist.cuh's C-layout: scalar i of job j multiplies base first_index[j] + i * stride
@@ -1140,6 +1223,12 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   Trace tr(c);
   Fr* S[8]; for (int i = 0; i < 8; i++) S[i] = pk.S[i].fr();
   const Fr* tw = (const Fr*)c.tw;
+  // sliced sections (rounds 2 and 3 on 1 / G of every 4H- and K-sized vector): with an all-to-all registered and a
+  // power-of-two number of ranks; MH_SLICED=0 keeps every rank on the replicated rounds
+  static const bool sliced_env = [] { const char* e = getenv("MH_SLICED"); return !e || atoi(e) != 0; }();
+  const uint64_t Gs = (uint64_t)g_shard.world;
+  const bool sliced = sliced_env && Gs > 1 && g_shard.a2a && (Gs & (Gs - 1)) == 0 && Gs <= 16 && H >= Gs * Gs;
+  if (sliced) MH_TRY(prepare_sliced(c, pk));
 
   // ---------------- prover_init (prover.rs:211-306): z = x || w, z_A = A z, z_B = B z --------------------
   if (inputs_on_device) { MH_TRY(d2d(c, pk.z.fr(), (const Fr*)instance, X)); MH_TRY(d2d(c, pk.z.fr() + X, (const Fr*)witness, nw)); }
@@ -1216,13 +1305,19 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
 
   // ---------------- second round (prover.rs:443-570) ---------------------------------------------------------
   const uint32_t lg4H = lgH + 2; const uint64_t H4 = 4 * H;
+  const uint64_t H4loc = sliced ? H4 / Gs : H4;          // elements of a 4H-vector this rank works on
+  if (sliced) {
+    MH_TRY(ntt_dist_device(c, S[0], slice_c(c, S[0], pk.za.fr(), za_len), S[0], lg4H, 0));
+    MH_TRY(ntt_dist_device(c, S[1], slice_c(c, S[1], pk.zb.fr(), za_len), S[1], lg4H, 0));
+  } else {
   MH_TRY(ntt_device_len(c, pk.za.fr(), za_len, S[0], lg4H, 0));
   MH_TRY(ntt_device_len(c, pk.zb.fr(), za_len, S[1], lg4H, 0));
+  }
   // The reference forms z_c = z_a * z_b (two forward transforms, a pointwise product, one inverse: prover.rs:467),
   // summed_z_m = eta_a z_a + eta_b z_b + eta_c z_c (468-471), and later evaluates summed_z_m on the same 4H domain
   // (533).  deg z_c = 2H + 2 < 4H, so those evaluations ARE eta_c z_a z_b + eta_a z_a + eta_b z_b pointwise: the inverse
   // and the forward transform in between cancel exactly and are not executed.  S[1] <- evaluations of summed_z_m.
-  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::summed_evals_kernel, H4, S[1], (const Fr*)S[0], arg(eta_a), arg(eta_b), arg(eta_c), (u64)H4); }
+  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::summed_evals_kernel, H4loc, S[1], (const Fr*)S[0], arg(eta_a), arg(eta_b), arg(eta_c), (u64)H4loc); }
   // r_alpha_x evals on H (mod.rs:311-318)
   HFr vH_alpha = v_h(alpha);
   { ProfScope ps(c, PF_GLUE);
@@ -1243,6 +1338,28 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   const uint64_t z_len = w_len + X;
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::z_poly_kernel, z_len, S[7], (const Fr*)pk.w.fr(), (u64)w_len, (u64)X, (const Fr*)pk.xpoly.fr(), (u64)X); }
   // q_1 (prover.rs:520-547): forward transforms on the 4H domain (summed_z_m's is known, see above), pointwise, one inverse
+  const uint64_t h1_len = 2 * H;                                                // deg <= 2H + 2*zk_bound - 2 - ... (upper H coefficients are zero)
+  if (sliced) {
+    // the same on this rank's slices: C-layout slices of r_alpha, z, t -> distributed forward transforms -> pointwise on its
+    // M-layout block -> distributed inverse -> q_1, the division by v_H (stride H / G inside a slice) and the remainder, all
+    // local; then ONE all-gather returns h_1 and x g_1 to every rank
+    const uint64_t Hloc = H / Gs;
+    MH_TRY(ntt_dist_device(c, S[0], slice_c(c, S[0], S[5], H), S[0], lg4H, 0));                  // r_alpha
+    MH_TRY(ntt_dist_device(c, S[2], slice_c(c, S[2], S[7], z_len), S[2], lg4H, 0));              // z
+    MH_TRY(ntt_dist_device(c, S[4], slice_c(c, S[4], pk.t.fr(), H), S[4], lg4H, 0));             // t
+    { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_sub_mul_kernel, H4loc, S[0], (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2], (const Fr*)S[4], (u64)H4loc); }
+    MH_TRY(ntt_dist_device(c, S[0], H4loc, S[1], lg4H, 1));                                      // rhs, cyclic slice
+    const uint64_t mask_loc = slice_c(c, S[2], pk.mask.fr(), mask_len);
+    MH_TRY(lincomb(c, S[2], H4loc, {{S[2], mask_loc, HFr::one()}, {S[1], H4loc, HFr::one()}}));  // q_1 slice
+    MH_TRY(div_vanishing(c, S[6], S[2], H4loc, Hloc, S[3]));                                     // h_1 slice (3H / G)
+    MH_TRY(lincomb(c, S[4], Hloc, {{S[2], Hloc, HFr::one()}, {S[6], Hloc, HFr::one()}}));        // slice of the remainder x g_1
+    const Fr* rcv = nullptr;
+    MH_TRY(allgather2(c, S[6], 2 * Hloc, S[4], Hloc, &rcv));
+    { ProfScope ps(c, PF_GLUE);
+      unslice_c(c, pk.h1.fr(), rcv, h1_len, 3 * Hloc, 0);
+      unslice_c(c, S[4], rcv, H, 3 * Hloc, 2 * Hloc); }
+    MH_HIP(hipGetLastError());
+  } else {
   MH_TRY(ntt_device_len(c, S[5], H, S[0], lg4H, 0));                                     // r_alpha
   // summed_z_m: already in S[1]
   MH_TRY(ntt_device_len(c, S[7], z_len, S[2], lg4H, 0));                                 // z
@@ -1252,8 +1369,8 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   MH_TRY(lincomb(c, S[2], H4, {{pk.mask.fr(), mask_len, HFr::one()}, {S[1], H4, HFr::one()}}));      // q_1 = mask + rhs
   // (h_1, x g_1) = q_1 / v_H (prover.rs:550-551)
   MH_TRY(div_vanishing(c, pk.h1.fr(), S[2], H4, H, S[3]));
-  const uint64_t h1_len = 2 * H;                                                // deg <= 2H + 2*zk_bound - 2 - ... (upper H coefficients are zero)
   MH_TRY(lincomb(c, S[4], H, {{S[2], H, HFr::one()}, {pk.h1.fr(), H, HFr::one()}}));   // remainder = x g_1
+  }
   MH_TRY(d2d(c, pk.g1.fr(), S[4] + 1, H - 1));
   const uint64_t g1_len = H - 1;
   tr.mark("AHP::Prover::SecondRound");
@@ -1286,6 +1403,35 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   // < |K|, so it only enters the REMAINDER of the division by v_K, which the reference discards (686-689); the quotient is
   // that of -b f either way.  tests/test_gpu_marlin.py::test_all_zero_matrix_a_poly_zip_quirk pins it.)
   HFr alpha_beta = alpha * beta;
+  if (sliced) {
+    // the third round on this rank's block of K (index evaluations pre-sliced into M-layout, prepare_sliced) and its cyclic
+    // slice of f and h_2; ONE all-gather returns f and h_2 to every rank
+    const uint64_t Kloc = K / Gs;
+    { ProfScope ps(c, PF_GLUE);
+      KLAUNCH(poly::denom_kernel, Kloc, S[1], (const Fr*)pk.sl_ev[0].p, (const Fr*)pk.sl_ev[1].p, arg(alpha), arg(beta), (u64)Kloc); }
+    MH_TRY(batch_inverse(c, S[1], S[3], Kloc, HFr::one(), 0));
+    { ProfScope ps(c, PF_GLUE);
+      KLAUNCH(poly::f_evals_kernel, Kloc, S[3], (const Fr*)S[1], (const Fr*)pk.sl_ev[2].p, (const Fr*)pk.sl_ev[3].p, (const Fr*)pk.sl_ev[4].p, arg(ea), arg(eb), arg(ec), (u64)Kloc); }
+    MH_TRY(ntt_dist_device(c, S[3], Kloc, S[4], lgK, 1));                        // f, cyclic slice
+    { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, Kloc, S[5], (const Fr*)S[4], (const Fr*)pk.sl_gpow_hi.p, (const Fr*)pk.sl_gpow_lo.p, (u64)Kloc); }
+    MH_TRY(ntt_dist_device(c, S[5], Kloc, S[6], lgK, 0));                        // f on g K, this rank's block
+    {
+      HFr vk_inv = (pk.coset_g.pow_u64(K) - HFr::one()).inv();
+      ProfScope ps(c, PF_GLUE);
+      KLAUNCH(poly::h2_coset_kernel, Kloc, S[5], (const Fr*)S[6], (const Fr*)pk.sl_cs[0].p, (const Fr*)pk.sl_cs[1].p, (const Fr*)pk.sl_cs[2].p,
+              (const Fr*)pk.sl_cs[3].p, (const Fr*)pk.sl_cs[4].p, (const Fr*)pk.sl_cs[5].p, arg(ea), arg(eb), arg(ec), arg(alpha), arg(beta),
+              arg(alpha_beta), arg(vk_inv), (u64)Kloc);
+    }
+    MH_TRY(ntt_dist_device(c, S[5], Kloc, S[6], lgK, 1));
+    { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, Kloc, S[7], (const Fr*)S[6], (const Fr*)pk.sl_ginv_hi.p, (const Fr*)pk.sl_ginv_lo.p, (u64)Kloc); }
+    const Fr* rcv = nullptr;
+    MH_TRY(allgather2(c, S[4], Kloc, S[7], Kloc, &rcv));
+    { ProfScope ps(c, PF_GLUE);
+      unslice_c(c, S[4], rcv, K, 2 * Kloc, 0);
+      unslice_c(c, pk.h2.fr(), rcv, K, 2 * Kloc, Kloc); }
+    MH_HIP(hipGetLastError());
+    MH_TRY(d2d(c, pk.g2.fr(), S[4] + 1, K - 1));                                // g_2 = f / X
+  } else {
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::denom_kernel, K, S[1], (const Fr*)pk.ev_row.p, (const Fr*)pk.ev_col.p, arg(alpha), arg(beta), (u64)K);
   }
@@ -1294,7 +1440,6 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     KLAUNCH(poly::f_evals_kernel, K, S[3], (const Fr*)S[1], (const Fr*)pk.ev_val_a.p, (const Fr*)pk.ev_val_b.p, (const Fr*)pk.ev_val_c.p, arg(ea), arg(eb), arg(ec), (u64)K); }
   MH_TRY(ntt_device(c, S[3], S[4], lgK, 1));                                    // f
   MH_TRY(d2d(c, pk.g2.fr(), S[4] + 1, K - 1));                                  // g_2 = f / X
-  const uint64_t g2_len = K - 1;
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, K, S[5], (const Fr*)S[4], (const Fr*)pk.gpow_hi.p, (const Fr*)pk.gpow_lo.p, (u64)K); }
   MH_TRY(ntt_device(c, S[5], S[6], lgK, 0));                                    // f on g K
   {
@@ -1306,6 +1451,8 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   }
   MH_TRY(ntt_device(c, S[5], S[6], lgK, 1));
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, K, pk.h2.fr(), (const Fr*)S[6], (const Fr*)pk.ginv_hi.p, (const Fr*)pk.ginv_lo.p, (u64)K); }
+  }
+  const uint64_t g2_len = K - 1;
   const uint64_t h2_len = K - 1;
   tr.mark("AHP::Prover::ThirdRound");
   std::vector<fsh::Commitment> cm3; std::vector<PolyRand> rd3;

@@ -190,29 +190,38 @@ srs = GM.universal_setup(n, n, 3 * n, %(tau)d, %(gamma)d, pc=%(pc)r)
 nc, ni, mats, inst, wit = GM.dummy_circuit(%(a)d, %(b)d, 10, n)
 pk = GM.index(srs, nc, ni, mats, pc=%(pc)r)
 MD.enable_sharded_prove(dist)
+if %(sliced)d:
+    MD.enable_alltoall(dist)                # rounds 2 and 3 run on slices (distributed transforms, one all-gather per round)
 proof = GM.prove(pk, inst, wit, bytes(range(32)))
-open(os.path.join(%(out)r, "proof%%d.bin" %% rank), "wb").write(proof)
+proof2 = GM.prove(pk, inst, wit, bytes(range(1, 33)))        # the key's sliced tables are reused
+open(os.path.join(%(out)r, "proof%%d.bin" %% rank), "wb").write(proof + proof2)
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,log_n,pc", [(2, 12, "marlin"), (3, 12, "marlin"), (2, 16, "sonic"), (4, 16, "marlin"),
-                                            (8, 12, "marlin"), (8, 16, "marlin")])
-def test_sharded_prove_ranks_equal_single(gpu, tmp_path, world, log_n, pc):
+@pytest.mark.parametrize("world,log_n,pc,sliced", [(2, 12, "marlin", 0), (3, 12, "marlin", 0), (2, 16, "sonic", 0), (4, 16, "marlin", 0),
+                                                   (8, 12, "marlin", 0), (8, 16, "marlin", 0),
+                                                   (2, 12, "marlin", 1), (4, 12, "sonic", 1), (8, 12, "marlin", 1), (4, 16, "marlin", 1),
+                                                   (8, 16, "marlin", 1), (8, 16, "sonic", 1), (3, 12, "marlin", 1)])
+def test_sharded_prove_ranks_equal_single(gpu, tmp_path, world, log_n, pc, sliced):
     """MSM sharding by bucket range across 2, 3, 4 and 8 ranks (gloo exchange, all ranks on the one GPU of this box), both PC
     schemes, yields the very same proof bytes as the unsharded prover.  At 2^12 the window table has 2 partitions (c = 13:
     2^12 buckets), fewer than 3, 4 or 8 ranks: those groups run unsharded on every rank and rank 0's copy counts; at 2^16
-    it has 64 and every rank owns 8 (world = 8, the target of BASELINE configs[3])."""
+    it has 64 and every rank owns 8 (world = 8, the target of BASELINE configs[3]).
+    sliced = 1: an all-to-all is registered as well, so the 4H- and K-sized transforms of rounds 2 and 3 and the pointwise
+    work between them run on each rank's slices (mh_ntt_dist_dev inside the prover, DESIGN.md 8.3) -- same bytes; with 3 ranks
+    (not a power of two) the prover stays on the replicated rounds."""
     import subprocess, sys
     a, b = 0x1234567, 0x7654321
     n = 1 << log_n
     srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc=pc)
     nc, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
     pk = GM.index(srs, nc, ni, mats, pc=pc)
-    want = GM.prove(pk, inst, wit, bytes(range(32)))
+    want = GM.prove(pk, inst, wit, bytes(range(32))) + GM.prove(pk, inst, wit, bytes(range(1, 33)))
     script = tmp_path / "shard_worker.py"
-    script.write_text(SHARD_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "pc": pc})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29613 + world + log_n), WORLD_SIZE=str(world))
+    script.write_text(SHARD_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "pc": pc,
+                                      "sliced": sliced})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29613 + world + log_n + 40 * sliced), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
