@@ -305,7 +305,7 @@ struct MsmJob { const char* bases; const Fr* scalars; uint64_t n; };
 // partitions) can strike on one rank only: the hot digit lives in exactly one partition.  So the combination rule is
 // per job: if any rank reports a whole sum, the lowest such rank's point IS the result (the shares of the others are
 // discarded); otherwise the result is the sum of all shares.
-int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<HG1>& out, int is_mont = 1) {
+int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<HG1>& out, int is_mont = 1, bool already_shares = false) {
   const int nj = (int)jobs.size();
   out.assign(nj, HG1::identity());
   if (nj == 0) return MH_OK;
@@ -315,7 +315,11 @@ int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<H
   const bool sharded = g_shard.world > 1;
   const int sh[2] = {g_shard.rank, g_shard.world};
   std::vector<uint8_t> partial(nj, 0);
-  int rc = msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), is_mont, part.data(), sharded ? sh : nullptr, sharded ? partial.data() : nullptr);
+  // already_shares: the jobs ARE this rank's part of the sums (blocks of the scalar vectors against the matching base
+  // ranges: point sharding) -- computed in full here and flagged as shares for the combination below
+  int rc = msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), is_mont, part.data(), sharded && !already_shares ? sh : nullptr,
+                            sharded ? partial.data() : nullptr);
+  if (sharded && already_shares) std::fill(partial.begin(), partial.end(), (uint8_t)1);
   if (!sharded) { MH_TRY(rc); for (int j = 0; j < nj; j++) out[j] = jac_from(part.data() + XYZ_L * j); return MH_OK; }
   if (!g_shard.cb) return fail(MH_EINVAL, "sharded prove: no all_gather callback registered");
   // a rank whose launch failed still enters the collective (with the error word set) so that the other ranks do not
@@ -1495,12 +1499,19 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   HFr c_za_lc = r_ab * (eta_a + eta_c * zb_beta);
   HFr c_w_lc = (t_beta * vX_beta).neg();
   HFr c_h1_lc = vH_beta.neg();
+  HFr mult = gamma * g2_gamma + t_beta * HFr::from_u64(K).inv();
+  // sliced openings (MarlinKZG10, the usual SRS geometry): every rank builds only ITS block of the linear combinations and of
+  // the witness polynomials (see below), so the full outer / inner polynomials are never formed
+  static const bool sliced_open_env = [] { const char* e = getenv("MH_SLICED_OPEN"); return !e || atoi(e) != 0; }();
+  const bool sliced_open = sliced && sliced_open_env && pk.pc == 0 && pk.srs_max_degree - (K - 2) == 1 &&
+                           std::max(mask_len - 1, pk.srs_max_degree - (H - 2) + (H - 2)) <= pk.S[1].bytes / 32;
+  if (!sliced_open) {
   MH_TRY(lincomb(c, pk.outer.fr(), mask_len, {{pk.mask.fr(), mask_len, HFr::one()}, {pk.za.fr(), za_len, c_za_lc},
                                                {pk.w.fr(), w_len, c_w_lc}, {pk.h1.fr(), h1_len, c_h1_lc}}));
-  HFr mult = gamma * g2_gamma + t_beta * HFr::from_u64(K).inv();
   MH_TRY(lincomb(c, pk.inner.fr(), K, {{pk.p_a_val.fr(), K, ea}, {pk.p_b_val.fr(), K, eb}, {pk.p_c_val.fr(), K, ec},
                                        {pk.p_row.fr(), K, alpha * mult}, {pk.p_col.fr(), K, beta * mult}, {pk.p_row_col.fr(), K, mult.neg()},
                                        {pk.h2.fr(), h2_len, vK_gamma.neg()}}));
+  }
 
   tr.mark("Evaluating linear combinations over query set");
   // ---------------- PC::open_combinations (lib.rs:292) -> batch_open -> MarlinKZG10::open ---------------------
@@ -1532,20 +1543,106 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     { const HG1 two[2] = {wacc, om[1]}; HG1Affine a2[2]; hostff::batch_to_affine(two, 2, a2); w_beta = a2[0]; w_gamma = a2[1]; }
     // nothing hiding at gamma: random_v = None
   } else {
+  const uint64_t off_b = pk.srs_max_degree - (H - 2), off_g = pk.srs_max_degree - (K - 2);
+  const bool fuse_g = off_g == 1;            // see below
+  const uint64_t wb_len = mask_len - 1, swb_len = g1_len - 1, wg_len = K - 1, swg_len = g2_len - 1;
+  const uint64_t mb_len = std::max(wb_len, off_b + swb_len), mg_len = std::max(wg_len, off_g + swg_len);
+  std::vector<HG1> om;                       // [0] witness at beta (+ shifted), [1] witness at gamma (+ shifted)
+  if (sliced_open) {
+    // Point-sharded openings.  The two merged witness vectors (index spaces [0, mb_len) and [0, mg_len) of the SRS) are cut
+    // into G contiguous blocks; rank r builds block r of the combined polynomial straight from the replicated round
+    // polynomials (one lincomb over 1 / G of the range: the 7-term inner combination over K is the dearest glue kernel of a
+    // proof), divides it by (X - z) locally -- the recurrence q_i = p_{i+1} + z q_{i+1} only needs q at the block's upper
+    // end, which is sum_{r' > r} E_{r'} z^(a_{r'} - a_{r+1}) with E_{r'} = the value of block r' at z: ONE all_gather of two
+    // field elements per rank -- and multiplies its block against the matching base range; the partial points are combined
+    // like bucket-range shares.  The shifted witness of g_1 (H - 2 coefficients against shifted_powers) is divided the same
+    // way, its carry taken directly from the replicated g_1.
+    const uint64_t G = Gs, r = (uint64_t)g_shard.rank;
+    auto cut = [&](uint64_t L, uint64_t cap, uint64_t k) { return std::min<uint64_t>(L * k / G, cap); };
+    auto clip = [](const Fr* p, uint64_t len, uint64_t a, uint64_t e, const HFr& coef) { return Term{p + a, len > a ? std::min(len, e) - a : 0, coef}; };
+    // boundaries in the index space of the divided polynomial (length len, quotient length len - 1): a_k, a_G = len
+    auto bounds = [&](uint64_t L, uint64_t qlen, uint64_t len, uint64_t k) { return k >= G ? len : cut(L, qlen, k); };
+    const uint64_t ab = bounds(mb_len, wb_len, mask_len, r), eb_ = bounds(mb_len, wb_len, mask_len, r + 1);     // beta: block [ab, eb_)
+    const uint64_t ag = bounds(mg_len, wg_len, K, r), eg = bounds(mg_len, wg_len, K, r + 1);                    // gamma
+    // blocks of the combined polynomials: beta in S[0], gamma in S[3]
+    MH_TRY(lincomb(c, S[0], eb_ - ab, {clip(pk.g1.fr(), g1_len, ab, eb_, HFr::one()), clip(pk.mask.fr(), mask_len, ab, eb_, xi_pow(2)),
+                                       clip(pk.za.fr(), za_len, ab, eb_, xi_pow(2) * c_za_lc), clip(pk.w.fr(), w_len, ab, eb_, xi_pow(2) * c_w_lc),
+                                       clip(pk.h1.fr(), h1_len, ab, eb_, xi_pow(2) * c_h1_lc), clip(pk.t.fr(), H, ab, eb_, xi_pow(3)),
+                                       clip(pk.zb.fr(), za_len, ab, eb_, xi_pow(4))}));
+    const HFr x2 = xi_pow(2);
+    MH_TRY(lincomb(c, S[3], eg - ag, {clip(pk.g2.fr(), g2_len, ag, eg, HFr::one()), clip(pk.p_a_val.fr(), K, ag, eg, x2 * ea),
+                                      clip(pk.p_b_val.fr(), K, ag, eg, x2 * eb), clip(pk.p_c_val.fr(), K, ag, eg, x2 * ec),
+                                      clip(pk.p_row.fr(), K, ag, eg, x2 * alpha * mult), clip(pk.p_col.fr(), K, ag, eg, x2 * beta * mult),
+                                      clip(pk.p_row_col.fr(), K, ag, eg, x2 * mult.neg()), clip(pk.h2.fr(), h2_len, ag, eg, x2 * vK_gamma.neg())}));
+    // + xi X g_2: F_i += xi g_2[i - 1] for 1 <= i <= g2_len, on this block
+    {
+      const uint64_t lo = std::max<uint64_t>(ag, 1), hi = std::min<uint64_t>(eg, g2_len + 1);
+      if (hi > lo) { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::axpy_shifted_kernel, hi - lo, S[3], (const Fr*)(pk.g2.fr() + (lo - 1)), arg(xi_pow(1)), (u64)(lo - ag), (u64)(hi - lo)); }
+    }
+    // block values at the points, exchanged
+    HFr Eb = HFr::zero(), Eg = HFr::zero();
+    if (eb_ > ab) MH_TRY(eval_poly(c, pk, S[0], eb_ - ab, beta, &Eb));
+    if (eg > ag) MH_TRY(eval_poly(c, pk, S[3], eg - ag, gamma, &Eg));
+    std::vector<uint64_t> snd(8), all_e(8 * G);
+    memcpy(&snd[0], Eb.v, 32); memcpy(&snd[4], Eg.v, 32);
+    if (g_shard.cb(snd.data(), 64, all_e.data(), g_shard.user) != 0) return fail(MH_EHIP, "sliced openings: all_gather callback failed");
+    auto carry = [&](int which, const HFr& z, uint64_t L, uint64_t qlen, uint64_t len) {
+      HFr acc = HFr::zero();
+      const uint64_t top = bounds(L, qlen, len, r + 1);
+      for (uint64_t q = r + 1; q < G; q++) {
+        HFr e; memcpy(e.v, &all_e[8 * q + 4 * which], 32);
+        acc = acc + e * z.pow_u64(bounds(L, qlen, len, q) - top);
+      }
+      return acc;
+    };
+    // quotient blocks: the block extended by the carry (the top rank's block already ends with the leading coefficient)
+    auto divide_block = [&](Fr* q, Fr* blk, uint64_t a, uint64_t e, uint64_t qlen, const HFr& z, const HFr& car) -> int {
+      const uint64_t qb = std::min(e, qlen);                 // quotient indices [a, qb)
+      if (qb <= a) return MH_OK;
+      uint64_t n = e - a;
+      if (r + 1 < G) { MH_TRY(set_fr(c, blk + (qb - a), car)); n = qb - a + 1; }
+      return div_linear(c, q, blk, n, z, S[2]);
+    };
+    const uint64_t lo_b = mb_len * r / G, hi_b = mb_len * (r + 1) / G;     // this rank's block of the merged beta vector
+    MH_HIP(hipMemsetAsync(S[1], 0, (hi_b - lo_b + 1) * 32, c.stream));
+    MH_TRY(divide_block(S[1] + (ab - lo_b), S[0], ab, eb_, wb_len, beta, carry(0, beta, mb_len, wb_len, mask_len)));
+    // shifted witness of g_1 on [lo_b, hi_b) n [off_b, off_b + swb_len): quotient indices [ka, kb) of g_1 / (X - beta)
+    {
+      const uint64_t ka = std::max(lo_b, off_b) - off_b, kb = std::min(std::max(hi_b, off_b), off_b + swb_len) - off_b;
+      if (kb > ka) {
+        HFr car = HFr::zero();
+        MH_TRY(eval_poly(c, pk, pk.g1.fr() + kb, g1_len - kb, beta, &car));                 // sum_{j >= kb} g_1[j] beta^(j - kb)
+        MH_TRY(d2d(c, S[4], pk.g1.fr() + ka, kb - ka));
+        MH_TRY(set_fr(c, S[4] + (kb - ka), car));
+        MH_TRY(div_linear(c, S[6], S[4], kb - ka + 1, beta, S[2]));
+        ProfScope ps(c, PF_GLUE);
+        KLAUNCH(poly::axpy_shifted_kernel, kb - ka, S[1], (const Fr*)S[6], arg(xi_pow(1)), (u64)(off_b + ka - lo_b), (u64)(kb - ka));
+      }
+    }
+    MH_TRY(divide_block(S[5], S[3], ag, eg, wg_len, gamma, carry(1, gamma, mg_len, wg_len, K)));
+    if (r == 0) hipLaunchKernelGGL(poly::add_const_kernel, dim3(1), dim3(64), 0, c.stream, S[5], arg((xi_pow(1) * g2_gamma).neg()));
+    MH_HIP(hipGetLastError());
+    const uint64_t qg_end = std::min(eg, wg_len);
+    std::vector<MsmJob> jobs;
+    jobs.push_back({srs_pts + lo_b * PT_B, S[1], hi_b - lo_b});
+    jobs.push_back({srs_pts + ag * PT_B, S[5], qg_end > ag ? qg_end - ag : 0});
+    std::vector<HG1> res;
+    MH_TRY(sharded_msm_batch(c, jobs, res, 1, true));
+    om = {res[0], res[1]};
+  }
   // The MSMs of the two opening proofs (witness + shifted witness at beta and at gamma, merged below) run as one batch.
   // --- at beta: labels g_1, outer_sumcheck, t, z_b  -> challenges xi^0 (g_1), xi^1 (g_1 shifted), xi^2, xi^3, xi^4
+  if (!sliced_open) {
   MH_TRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(2)},
                                      {pk.t.fr(), H, xi_pow(3)}, {pk.zb.fr(), za_len, xi_pow(4)}}));
   MH_TRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));                         // witness of the combined polynomial
   MH_TRY(div_linear(c, S[3], pk.g1.fr(), g1_len, beta, S[2]));                     // degree-bounded g_1: shifted witness
   MH_TRY(lincomb(c, S[4], g1_len - 1, {{S[3], g1_len - 1, xi_pow(1)}}));
   // --- at gamma: labels g_2, inner_sumcheck -> challenges xi^0 (g_2), xi^1 (g_2 shifted), xi^2
-  const uint64_t off_b = pk.srs_max_degree - (H - 2), off_g = pk.srs_max_degree - (K - 2);
   // When shifted_powers(K - 2) starts at SRS index 1 (max_degree = K - 1, the usual case) the witness plus the shifted
   // witness moved up by one coefficient is the quotient of ONE polynomial: with C = g_2 + xi^2 inner,
   //   (C - C(gamma)) / (X - gamma) + X xi (g_2 - g_2(gamma)) / (X - gamma) = quotient(C + xi X g_2) - xi g_2(gamma),
   // so a single division serves both (the general offset keeps two divisions and adds the vectors).
-  const bool fuse_g = off_g == 1;
   MH_TRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(2)}}));
   if (fuse_g) {
     { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::axpy_shifted_kernel, g2_len, S[0], (const Fr*)pk.g2.fr(), arg(xi_pow(1)), (u64)1, (u64)g2_len); }
@@ -1555,6 +1652,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
     MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
     MH_TRY(lincomb(c, S[6], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
+  }
   }
   // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b); its witness and the shifted
   // one are multiplied on host threads while the device runs the batch
@@ -1575,16 +1673,14 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   // max_degree - d, so the sum is ONE multi-scalar multiplication with the shifted witness's coefficients added at
   // that offset: at gamma the offset is max_degree - (K - 2) (1 for this circuit: the two 4M-point MSMs collapse into
   // one), at beta the ranges do not overlap but one job replaces two.
-  const uint64_t wb_len = mask_len - 1, swb_len = g1_len - 1, wg_len = K - 1, swg_len = g2_len - 1;
-  const uint64_t mb_len = std::max(wb_len, off_b + swb_len), mg_len = std::max(wg_len, off_g + swg_len);
   // (an SRS much larger than this index needs puts the shifted range beyond the scratch vectors: then the two stay apart)
   const bool merge_b = mb_len <= pk.S[1].bytes / 32, merge_g = fuse_g || mg_len <= pk.S[5].bytes / 32;
+  if (!sliced_open) {
   if (merge_b) MH_TRY(zero_tail(c, S[1], wb_len, mb_len));
   if (merge_g && !fuse_g) MH_TRY(zero_tail(c, S[5], wg_len, mg_len));
   { ProfScope ps(c, PF_GLUE);
     if (merge_b) KLAUNCH(poly::add_shifted_kernel, swb_len, S[1], (const Fr*)S[4], (u64)off_b, (u64)swb_len);
     if (merge_g && !fuse_g) KLAUNCH(poly::add_shifted_kernel, swg_len, S[5], (const Fr*)S[6], (u64)off_g, (u64)swg_len); }
-  std::vector<HG1> om;                       // [0] witness at beta (+ shifted), [1] witness at gamma (+ shifted)
   {
     std::vector<MsmJob> jobs;
     jobs.push_back({srs_pts, S[1], merge_b ? mb_len : wb_len});
@@ -1598,6 +1694,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     size_t nx = 2;
     if (!merge_b) om[0] = om[0].add(res[nx++]);
     if (!merge_g) om[1] = om[1].add(res[nx++]);
+  }
   }
   HG1 w_beta_jac;
   {

@@ -181,13 +181,26 @@ def enable_alltoall(dist, device=None):
 
 
 def enable_simulated_alltoall(rank, world):
-    """MEASUREMENT ONLY (like enable_simulated_shard): this process acts as rank `rank` of `world` for mh_ntt_dist_dev with
-    the exchange replaced by a device-to-device copy of its own send buffer -- the values are meaningless, the kernels and
-    the bytes each rank would move are the real ones (tools/ntt_dist_bench.py)."""
+    """MEASUREMENT ONLY (like enable_simulated_shard): this process acts as rank `rank` of `world` for mh_ntt_dist_dev and the
+    sliced rounds of the prover without any peers.  The exchange copies this rank's own chunk into its slot; the slots of the
+    absent peers hold pseudo-random field elements, written once per receive buffer -- so that what the prover then feeds to
+    its MSMs looks like coefficient vectors (copies of the own slice in every slot would make every digit repeat `world`
+    times and unbalance the bucket accumulation, which is not what a real run sees).  The values are meaningless and the
+    proofs invalid; the kernels and the bytes each rank would move are the real ones (tools/ntt_dist_bench.py,
+    bench.py --simulate-rank)."""
     lib = _lib.load()
+    filled = {}
 
     def _cb(d_send, bytes_per_peer, d_recv, _user):
-        return lib.mh_memcpy_d2d(d_recv, d_send, bytes_per_peer * world) or lib.mh_synchronize()
+        total = bytes_per_peer * world
+        if filled.get(d_recv, 0) < total:                     # once per receive buffer (and again only if a larger exchange uses it)
+            rnd = np.random.default_rng(bytes_per_peer & 0xffff).integers(0, 1 << 63, size=(total // 32, 4), dtype=np.uint64)
+            rnd[:, 3] &= np.uint64((1 << 60) - 1)
+            if lib.mh_memcpy_h2d(d_recv, rnd.ctypes.data, total):
+                return -1
+            filled[d_recv] = total
+        off = rank * bytes_per_peer
+        return lib.mh_memcpy_d2d(d_recv + off, d_send + off, bytes_per_peer) or lib.mh_synchronize()
     cb = _ALLTOALL_T(_cb)
     _keepalive["a2a"] = cb
     _lib.check(lib.mh_marlin_set_alltoall(C.cast(cb, C.c_void_p), None), "mh_marlin_set_alltoall")
