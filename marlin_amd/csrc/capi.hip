@@ -574,7 +574,21 @@ struct FbRun {
       ProfScope pa(c, PF_MSM_ACCUM, s);
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
       // resident waves per SIMD of the accumulate kernel (register budget 512 / waves): MH_ACC_WAVES = 3 | 4
-      static const int acc_waves = [] { const char* e = getenv("MH_ACC_WAVES"); int w = e ? atoi(e) : 3; return w == 4 ? 4 : (w == 2 ? 2 : 3); }();
+      // 2, 3 and 4 resident waves run the kernel at the same rate when the chip is full (it is bound by VALU issue), so the
+      // count is chosen to DIVIDE the waves a SIMD gets: a bucket-range shard of 8 ranks leaves ~4 equally long waves per SIMD
+      // and launch, and at 3 resident waves the fourth runs alone, at little more than half the issue rate (+25 % measured on
+      // a simulated rank of 8).  With many waves per SIMD (one GPU: ~32) the choice does not matter and stays 3.
+      static const int env_waves = [] { const char* e = getenv("MH_ACC_WAVES"); int w = e ? atoi(e) : 0; return (w >= 2 && w <= 4) ? w : 0; }();
+      int acc_waves = env_waves ? env_waves : 3;
+      if (!env_waves) {
+        const u64 active = (u64)nj * nbown;                                   // buckets that do work on this rank
+        const u64 per_simd = (active / 64 + (u64)c.num_simds - 1) / (u64)c.num_simds;
+        if (per_simd <= 12) {
+          int best = 3; u64 best_idle = (per_simd + 2) / 3 * 3 - per_simd;
+          for (int k : {4, 2}) { const u64 idle = (per_simd + k - 1) / k * k - per_simd; if (idle < best_idle) { best_idle = idle; best = k; } }
+          acc_waves = best;
+        }
+      }
       if (acc_waves == 2)
         hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
@@ -1136,6 +1150,7 @@ int mh_init(int device_id) {
   MH_HIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
   for (auto& e : c.fb_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   c.device = device_id;
+  c.num_simds = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
   c.inited = true;
   return MH_OK;
 }

@@ -74,6 +74,7 @@ struct ProfRec { int family; hipEvent_t a, b; };
 struct Context {
   bool inited = false;
   int device = -1;
+  int num_simds = 1024;      // 4 per CU
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::recursive_mutex mu;
