@@ -574,20 +574,19 @@ struct FbRun {
       ProfScope pa(c, PF_MSM_ACCUM, s);
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
       // resident waves per SIMD of the accumulate kernel (register budget 512 / waves): MH_ACC_WAVES = 3 | 4
-      // 2, 3 and 4 resident waves run the kernel at the same rate when the chip is full (it is bound by VALU issue), so the
-      // count is chosen to DIVIDE the waves a SIMD gets: a bucket-range shard of 8 ranks leaves ~4 equally long waves per SIMD
-      // and launch, and at 3 resident waves the fourth runs alone, at little more than half the issue rate (+25 % measured on
-      // a simulated rank of 8).  With many waves per SIMD (one GPU: ~32) the choice does not matter and stays 3.
+      // Resident waves per SIMD.  With the chip full (one GPU: ~32 equally long waves per SIMD and launch) 2 and 3 run the
+      // kernel at the same rate -- it is bound by VALU issue -- and 3 is the default.  A bucket-range shard of 8 ranks leaves
+      // only ~4 waves per SIMD: at 3 resident the fourth runs ALONE, and one wave issues at ~2/3 of the rate two or three
+      // reach together; at 4 resident (128 VGPRs, 224 B of scratch) every wave pays for its spills.  Measured on a simulated
+      // rank of 8 (profiles/r03j_sim_*): 8.2 / 9.1 / 10.5 ms of accumulation per proof at 2 / 3 / 4 waves at 2^20, 32.5 / 36.6 /
+      // 41.5 ms at 2^22; rank of 4 (8 waves per SIMD): 14.9 / 14.5 / 16.9.  So: 3, unless that leaves a lone last wave and 2
+      // does not.  MH_ACC_WAVES = 2 | 3 | 4 overrides.
       static const int env_waves = [] { const char* e = getenv("MH_ACC_WAVES"); int w = e ? atoi(e) : 0; return (w >= 2 && w <= 4) ? w : 0; }();
       int acc_waves = env_waves ? env_waves : 3;
       if (!env_waves) {
         const u64 active = (u64)nj * nbown;                                   // buckets that do work on this rank
         const u64 per_simd = (active / 64 + (u64)c.num_simds - 1) / (u64)c.num_simds;
-        if (per_simd <= 12) {
-          int best = 3; u64 best_idle = (per_simd + 2) / 3 * 3 - per_simd;
-          for (int k : {4, 2}) { const u64 idle = (per_simd + k - 1) / k * k - per_simd; if (idle < best_idle) { best_idle = idle; best = k; } }
-          acc_waves = best;
-        }
+        if (per_simd <= 16 && per_simd % 3 == 1 && per_simd % 2 == 0) acc_waves = 2;
       }
       if (acc_waves == 2)
         hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
