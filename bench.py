@@ -395,8 +395,25 @@ def main():
         if world > 1:
             from marlin_amd import dist as MD
             MD.enable_sharded_prove(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
-            if not args.no_sliced:
+            sliced_rounds = False
+            if not args.no_sliced and (world & (world - 1)) == 0:
                 MD.enable_alltoall(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
+                # the sliced rounds depend on the all-to-all: check one distributed transform against the local one on every
+                # rank, and fall back to the replicated rounds everywhere unless all of them agree
+                try:
+                    ok = MD.selftest_alltoall(dist)
+                except Exception as e:
+                    print("bench.py: all-to-all self-test raised on rank %d: %s" % (rank, e), file=sys.stderr)
+                    ok = False
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                sliced_rounds = bool(int(flag.item()))
+                if not sliced_rounds:
+                    from marlin_amd import _lib as _ML
+                    _ML.check(_ML.load().mh_marlin_set_alltoall(None, None), "mh_marlin_set_alltoall")
+                    if rank == 0:
+                        print("bench.py: all-to-all self-test failed; rounds 2 and 3 stay replicated", file=sys.stderr)
+            args.no_sliced = not sliced_rounds
         elif args.simulate_rank:
             from marlin_amd import dist as MD
             sr, sg = (int(x) for x in args.simulate_rank.split("/"))

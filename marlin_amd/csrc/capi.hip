@@ -579,14 +579,15 @@ struct FbRun {
       // only ~4 waves per SIMD: at 3 resident the fourth runs ALONE, and one wave issues at ~2/3 of the rate two or three
       // reach together; at 4 resident (128 VGPRs, 224 B of scratch) every wave pays for its spills.  Measured on a simulated
       // rank of 8 (profiles/r03j_sim_*): 8.2 / 9.1 / 10.5 ms of accumulation per proof at 2 / 3 / 4 waves at 2^20, 32.5 / 36.6 /
-      // 41.5 ms at 2^22; rank of 4 (8 waves per SIMD): 14.9 / 14.5 / 16.9.  So: 3, unless that leaves a lone last wave and 2
-      // does not.  MH_ACC_WAVES = 2 | 3 | 4 overrides.
+      // 41.5 ms at 2^22 -- 2 also wins where 3 would leave no lone wave (round 3: 3 waves per SIMD), so part of it is the 3-wave
+      // build's 28 B of scratch, which a full chip hides and a thin launch does not --; rank of 4 (8 waves per SIMD): 14.9 /
+      // 14.5 / 16.9.  So: 2 when a launch has at most 6 waves per SIMD, else 3.  MH_ACC_WAVES = 2 | 3 | 4 overrides.
       static const int env_waves = [] { const char* e = getenv("MH_ACC_WAVES"); int w = e ? atoi(e) : 0; return (w >= 2 && w <= 4) ? w : 0; }();
       int acc_waves = env_waves ? env_waves : 3;
       if (!env_waves) {
         const u64 active = (u64)nj * nbown;                                   // buckets that do work on this rank
         const u64 per_simd = (active / 64 + (u64)c.num_simds - 1) / (u64)c.num_simds;
-        if (per_simd <= 16 && per_simd % 3 == 1 && per_simd % 2 == 0) acc_waves = 2;
+        if (per_simd <= 6) acc_waves = 2;
       }
       if (acc_waves == 2)
         hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,

@@ -207,6 +207,25 @@ def enable_simulated_alltoall(rank, world):
     enable_simulated_shard(rank, world)
 
 
+def selftest_alltoall(dist, log_n=12):
+    """One distributed transform of 2^log_n points checked against the same transform on this GPU alone (mh_ntt): True when
+    this rank's block is bit-identical.  bench.py runs it once after registering the exchange, so that a transport problem
+    turns the sliced rounds off (the replicated rounds need no all-to-all) instead of producing a wrong proof."""
+    from .api import DeviceBuffer, ntt as _ntt
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = 1 << log_n
+    rng = np.random.default_rng(2024)
+    x = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    x[:, 3] &= np.uint64((1 << 59) - 1)
+    d = DeviceBuffer.from_numpy(c_layout_slice(x, rank, world))
+    try:
+        ntt_dist_dev(d, d, log_n)
+        got = d.download((n // world, 4))
+    finally:
+        d.free()
+    return bool(np.array_equal(got, _ntt(x)[m_layout_indices(n, rank, world)]))
+
+
 def c_layout_slice(x, rank, world):
     """this rank's cyclic slice of a coefficient vector: x[rank + world * j]"""
     return np.ascontiguousarray(x[rank::world])
