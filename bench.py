@@ -396,7 +396,7 @@ def main():
             from marlin_amd import dist as MD
             MD.enable_sharded_prove(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
             sliced_rounds = False
-            if not args.no_sliced and (world & (world - 1)) == 0:
+            if not args.no_sliced and (world & (world - 1)) == 0 and world >= 4:     # 2 ranks: the exchanges cost more than they save
                 MD.enable_alltoall(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
                 # the sliced rounds depend on the all-to-all: check one distributed transform against the local one on every
                 # rank, and fall back to the replicated rounds everywhere unless all of them agree
@@ -417,6 +417,8 @@ def main():
         elif args.simulate_rank:
             from marlin_amd import dist as MD
             sr, sg = (int(x) for x in args.simulate_rank.split("/"))
+            if sg < 4:
+                args.no_sliced = True               # the library keeps the rounds replicated below 4 ranks
             if args.no_sliced:
                 MD.enable_simulated_shard(sr, sg)
             else:

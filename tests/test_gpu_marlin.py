@@ -222,6 +222,8 @@ def test_sharded_prove_ranks_equal_single(gpu, tmp_path, world, log_n, pc, slice
     script.write_text(SHARD_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "pc": pc,
                                       "sliced": sliced})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29613 + world + log_n + 40 * sliced), WORLD_SIZE=str(world))
+    if sliced:
+        env["MH_SLICED"] = "2"               # also with 2 ranks, where the library would keep the rounds replicated (not worth the bytes)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
