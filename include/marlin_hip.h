@@ -260,11 +260,11 @@ int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv);   /* r
  * "M-layout"; a point of a subdomain has the same owner in the larger domain).
  * mh_ntt_dist_dev: one transform of 2^log_n points with ONE all-to-all of 32 n / G^2 bytes per peer (4-step NTT):
  * forward takes the C-layout slice (n / G elements) and returns the M-layout block, inverse the other way round; results
- * equal mh_ntt on the gathered vector.  world must be a power of two <= 16, n >= world^2.  The all-to-all works on DEVICE
+ * equal mh_ntt on the gathered vector.  world must be a power of two <= 8, n >= world^2.  The all-to-all works on DEVICE
  * buffers: chunk q (bytes_per_peer bytes) of d_send goes to rank q, chunk q of d_recv comes from rank q; it must return
  * with d_recv complete (torch.distributed.all_to_all_single over RCCL in marlin_amd/dist.py). */
 typedef int (*mh_alltoall_fn)(const void* d_send, size_t bytes_per_peer, void* d_recv, void* user);
-/* Registering an all-to-all (next to mh_marlin_set_shard's all_gather; world a power of two in [4, 16], |H| >= world^2) also
+/* Registering an all-to-all (next to mh_marlin_set_shard's all_gather; world = 4 or 8, |H| >= world^2) also
  * switches mh_marlin_prove to its SLICED sections: the 4H- and K-sized transforms of rounds 2 and 3 run distributed, the
  * pointwise work between them and the opening polynomials on 1 / world of each vector, with two all-gathers (this callback
  * with the same chunk for every peer) per proof -- same proof bytes.  NULL unregisters. */

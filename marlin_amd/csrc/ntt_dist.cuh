@@ -18,7 +18,7 @@
 
 namespace nttdist {
 
-struct Roots { Fr w[8]; };      // powers 0 .. G / 2 - 1 of the G-th root (inverse root for the inverse transform), G <= 16
+struct Roots { Fr w[8]; };      // powers 0 .. G / 2 - 1 of the G-th root (inverse root for the inverse transform), G <= 8
 
 // thread per t < chunk: G-point transform across the G chunks of `in` (chunk j1 at in + j1 * chunk), out chunk k1
 template <int LOGG>

@@ -626,7 +626,7 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
   const int G = g_shard.world, rank = g_shard.rank;
   uint32_t lg = 0;
   while ((1 << lg) < G) lg++;
-  if ((1 << lg) != G || G > 16) return fail(MH_EINVAL, "mh_ntt_dist_dev: the number of ranks must be a power of two <= 16");
+  if ((1 << lg) != G || G > 8) return fail(MH_EINVAL, "mh_ntt_dist_dev: the number of ranks must be a power of two <= 8 (one node)");
   if (!g_shard.a2a) return fail(MH_EINVAL, "mh_ntt_dist_dev: no all_to_all callback registered (mh_marlin_set_alltoall)");
   if (log_n > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "log_n exceeds the two-adicity of Fr");
   if (log_n < 2 * lg) return fail(MH_EINVAL, "mh_ntt_dist_dev: the transform must have at least world^2 points");
@@ -663,8 +663,7 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
     switch (lg) {
       case 1: hipLaunchKernelGGL(nttdist::gdft_kernel<1>, grid, block, 0, c.stream, out, in, (u64)chunk, roots); break;
       case 2: hipLaunchKernelGGL(nttdist::gdft_kernel<2>, grid, block, 0, c.stream, out, in, (u64)chunk, roots); break;
-      case 3: hipLaunchKernelGGL(nttdist::gdft_kernel<3>, grid, block, 0, c.stream, out, in, (u64)chunk, roots); break;
-      default: hipLaunchKernelGGL(nttdist::gdft_kernel<4>, grid, block, 0, c.stream, out, in, (u64)chunk, roots); break;
+      default: hipLaunchKernelGGL(nttdist::gdft_kernel<3>, grid, block, 0, c.stream, out, in, (u64)chunk, roots); break;
     }
     MH_HIP(hipGetLastError());
     return MH_OK;
@@ -1234,7 +1233,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   // (from 4 ranks on: with 2 ranks each exchange moves a quarter of the vector to the one peer -- ~10 ms of xGMI time per proof
   // at 2^20 for 2.4 ms of saved kernels; MH_SLICED=2 forces it for tests)
   static const bool sliced_force = [] { const char* e = getenv("MH_SLICED"); return e && atoi(e) == 2; }();
-  const bool sliced = sliced_env && (Gs >= 4 || (sliced_force && Gs > 1)) && g_shard.a2a && (Gs & (Gs - 1)) == 0 && Gs <= 16 && H >= Gs * Gs;
+  const bool sliced = sliced_env && (Gs >= 4 || (sliced_force && Gs > 1)) && g_shard.a2a && (Gs & (Gs - 1)) == 0 && Gs <= 8 && H >= Gs * Gs;
   if (sliced) MH_TRY(prepare_sliced(c, pk));
 
   // ---------------- prover_init (prover.rs:211-306): z = x || w, z_A = A z, z_B = B z --------------------
