@@ -1607,7 +1607,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     };
     const uint64_t lo_b = mb_len * r / G, hi_b = mb_len * (r + 1) / G;     // this rank's block of the merged beta vector
     MH_HIP(hipMemsetAsync(S[1], 0, (hi_b - lo_b + 1) * 32, c.stream));
-    MH_TRY(divide_block(S[1] + (ab - lo_b), S[0], ab, eb_, wb_len, beta, carry(0, beta, mb_len, wb_len, mask_len)));
+    if (ab >= lo_b) MH_TRY(divide_block(S[1] + (ab - lo_b), S[0], ab, eb_, wb_len, beta, carry(0, beta, mb_len, wb_len, mask_len)));   // else: no main-witness index in this block
     // shifted witness of g_1 on [lo_b, hi_b) n [off_b, off_b + swb_len): quotient indices [ka, kb) of g_1 / (X - beta)
     {
       const uint64_t ka = std::max(lo_b, off_b) - off_b, kb = std::min(std::max(hi_b, off_b), off_b + swb_len) - off_b;

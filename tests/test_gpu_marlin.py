@@ -513,6 +513,21 @@ def test_prove_with_caller_supplied_zk_draws(gpu, pc):
         GM.prove_draws(pk, inst, wit, bad)
 
 
+def test_bench_gpus_4_runs_the_sliced_rounds(gpu):
+    """`python bench.py --gpus 4` (four ranks on this box's one GPU, gloo exchange): the all-to-all self-test passes on every
+    rank, rounds 2 and 3 and the openings run on slices, and the line says so."""
+    import json, subprocess, sys
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1",
+                          "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 4 and rec["value"] > 0 and "slices" in rec["config"]["parallelism"], rec["config"]
+    assert len(rec["ranks_seen"]) == 4 and rec["distinct_devices"] == 1          # four ranks, one physical GPU on this box
+
+
 RCCL_WORKER = r'''
 import os, sys, ctypes as C
 sys.path.insert(0, %(root)r)
