@@ -1181,6 +1181,9 @@ int mh_shutdown(void) {
   for (auto& kv : c.g2_bases) if (kv.second.d_points) (void)hipFree(kv.second.d_points);
   c.g2_bases.clear();
   c.fbws[0].release_all(); c.fbws[1].release_all();
+  for (auto& kv : c.ntt_dist_tabs) kv.second.release();
+  c.ntt_dist_tabs.clear();
+  c.ntt_dist_buf[0].release(); c.ntt_dist_buf[1].release(); c.sl_send.release(); c.sl_recv.release();
   if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
   for (auto& e : c.fb_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }

@@ -84,7 +84,8 @@ struct Context {
   void* tw30 = nullptr;      // the same table as 9 x 30-bit limbs of w R' mod r (ntt30.cuh), 36 B per entry
   uint32_t tw_log = 0;
   Scratch ntt_tmp[2];
-  Scratch ntt_dist_buf[2], ntt_dist_tw, sl_send, sl_recv;   // distributed transform (ntt_dist.cuh): exchange buffers, twiddle hi / lo tables
+  Scratch ntt_dist_buf[2], sl_send, sl_recv;
+  std::map<uint64_t, Scratch> ntt_dist_tabs;   // twiddle hi / lo tables of the distributed transform, per (size, direction, rank, ranks)   // distributed transform (ntt_dist.cuh): exchange buffers, twiddle hi / lo tables
   Scratch io;                // staging for host-pointer entry points
 
   // MSM

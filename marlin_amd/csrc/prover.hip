@@ -638,20 +638,22 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
   HFr wn = hostff::fr_two_adic_root();
   for (uint32_t i = log_n; i < hostff::FR_TWO_ADICITY_H; i++) wn = wn.sqr();
   if (inverse) wn = wn.inv();
-  const HFr base = wn.pow_u64((uint64_t)rank);
   const uint64_t LO = 1ull << poly::COSET_LO_BITS, nhi = (m + LO - 1) / LO;
-  std::vector<uint64_t> tab(4 * (LO + nhi));
-  {
+  const uint64_t tab_key = ((uint64_t)log_n << 16) | ((uint64_t)(inverse ? 1 : 0) << 15) | ((uint64_t)G << 8) | (uint64_t)rank;
+  Scratch& tabs = c.ntt_dist_tabs[tab_key];
+  if (!tabs.ptr) {                                  // built once per (size, direction, geometry): ~2300 host multiplications
+    const HFr base = wn.pow_u64((uint64_t)rank);
+    std::vector<uint64_t> tab(4 * (LO + nhi));
     HFr a = inverse ? HFr::from_u64((uint64_t)G).inv() : HFr::one();
     for (uint64_t j = 0; j < LO; j++) { memcpy(&tab[4 * j], a.v, 32); a = a * base; }
     const HFr bl = base.pow_u64(LO);
     a = HFr::one();
     for (uint64_t j = 0; j < nhi; j++) { memcpy(&tab[4 * (LO + j)], a.v, 32); a = a * bl; }
+    MH_TRY(tabs.ensure(tab.size() * 8));
+    MH_HIP(hipMemcpyAsync(tabs.ptr, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c.stream));
+    MH_HIP(hipStreamSynchronize(c.stream));          // `tab` is pageable and goes out of scope
   }
-  MH_TRY(c.ntt_dist_tw.ensure(tab.size() * 8));
-  MH_HIP(hipMemcpyAsync(c.ntt_dist_tw.ptr, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c.stream));
-  MH_HIP(hipStreamSynchronize(c.stream));            // `tab` is pageable and goes out of scope
-  const Fr* t_lo = (const Fr*)c.ntt_dist_tw.ptr; const Fr* t_hi = t_lo + LO;
+  const Fr* t_lo = (const Fr*)tabs.ptr; const Fr* t_hi = t_lo + LO;
   nttdist::Roots roots;
   {
     HFr wg = wn.pow_u64(m), a = HFr::one();          // w_G = w_n^m (the inverse root when `inverse`)
