@@ -416,7 +416,7 @@ struct FbRun {
   msmfb::FbJobs jobs; std::vector<int> alias;
   u64 ent = 0, pco = 0, tile = 0, max_tiles_total = 0; u32 max_blk = 0, seg = 0, nseg = 0, chunks = 1;
   std::vector<msmfb::FbWin> desc; std::vector<msmfb::FbBlk> blk; std::vector<u32> ptot;
-  bool skewed = false;
+  bool skewed = false, quad1 = false, quad2 = false;
   FbRun(Context& c_, const BaseSet& bs_, Context::FbWs& ws_) : c(c_), bs(bs_), ws(ws_) {}
 
   int prepare(int is_mont_, const int* shard) {
@@ -469,9 +469,22 @@ struct FbRun {
     // segment length of the bucket reduction: >= 49152 threads per launch (measured best: 31.2 ms vs 36.1 ms with SEG fixed,
     // 32.7 ms at 65536, per 3 proofs), at most SEG buckets each; MH_FB_SEG_THREADS overrides
     seg = msm::SEG;
-    static const u64 seg_threads = [] { const char* e = getenv("MH_FB_SEG_THREADS"); return e ? (u64)atoll(e) : 49152ull; }();
+    static const u64 seg_threads_env = [] { const char* e = getenv("MH_FB_SEG_THREADS"); return e ? (u64)atoll(e) : 0ull; }();
+    // One point per quad of lanes (msm_fb_quad.cuh): an addition is 4 dependent multiplications instead of 14 (2,807
+    // instructions instead of 7,099), but a lone wave then has no second multiplication to interleave and issues an
+    // instruction every ~11 cycles instead of every ~6: 13 us per addition against 17 us.  Measured (profiles/r03p_*): the
+    // tree stage (reduce2, a pure chain) of a bucket-range shard of 8 gains 0.5 ms per proof (6.39 -> 5.88 ms of sort +
+    // reduce stages), on one GPU it loses 0.2 ms; the segment stage loses everywhere (its chains get longer at the same
+    // lane count: +0.6 ms on a rank of 8, +5 ms on one GPU).  So: reduce2 only, and only for the small launches of a
+    // shard.  MH_FB_QUAD = 0 (off) | 1 (reduce2) | 2 (both stages) overrides.
+    static const int quad_env = [] { const char* e = getenv("MH_FB_QUAD"); return e ? atoi(e) : -1; }();
+    static const u64 quad_max = [] { const char* e = getenv("MH_FB_QUAD_MAX"); return e ? (u64)atoll(e) : (1ull << 19); }();
+    quad2 = quad_env < 0 ? (partial && (u64)nj * nbown <= quad_max) : quad_env >= 1;
+    quad1 = quad_env >= 2;
+    const u64 seg_threads = seg_threads_env ? seg_threads_env : (quad1 ? 65536ull : 49152ull);
+    const u64 lanes = quad1 ? 4 : 1;
     if (seg > nb) seg = nb;                                              // a segment stays inside one partition
-    while (seg > 4 && (u64)nj * (nbown / seg) < seg_threads) seg >>= 1;
+    while (seg > 4 && (u64)nj * (nbown / seg) * lanes < seg_threads) seg >>= 1;
     nseg = nbown / seg;
     chunks = nseg >= 4096 ? nseg / 256 : 1;                              // reduce2 in two launches when nseg is large
     MH_TRY(ws.seg.ensure((size_t)nj * (nseg + chunks) * sizeof(F::G1Xyzz30)));
@@ -615,16 +628,21 @@ struct FbRun {
     namespace F = msmfb;
     ProfScope ps(c, PF_MSM_STAGES, s);
     F::G1Xyzz30* seg30 = (F::G1Xyzz30*)ws.seg.ptr;
-    hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
-                       seg30, nbt, nseg, (u32)nj, seg, nb, own);
-    const size_t r2lds = 256 * sizeof(F::G1Xyzz30);
+    if (quad1)
+      hipLaunchKernelGGL(F::reduce1_q_kernel, dim3((unsigned)(((u64)nj * nseg * 4 + 255) / 256)), dim3(256), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
+                         seg30, nbt, nseg, (u32)nj, seg, nb, own);
+    else
+      hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
+                         seg30, nbt, nseg, (u32)nj, seg, nb, own);
+    const size_t r2lds = (quad2 ? 64 : 256) * sizeof(F::G1Xyzz30);
+    auto r2 = quad2 ? F::reduce2_q_kernel : F::reduce2_30_kernel;
     if (chunks > 1) {
       F::G1Xyzz30* mid = seg30 + (size_t)nj * nseg;
-      hipLaunchKernelGGL(F::reduce2_30_kernel, dim3(chunks, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, mid, (G1Xyzz*)nullptr, nseg, 0);
-      hipLaunchKernelGGL(F::reduce2_30_kernel, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)mid, (F::G1Xyzz30*)nullptr,
+      hipLaunchKernelGGL(r2, dim3(chunks, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, mid, (G1Xyzz*)nullptr, nseg, 0);
+      hipLaunchKernelGGL(r2, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)mid, (F::G1Xyzz30*)nullptr,
                          (G1Xyzz*)ws.win.ptr, chunks, 1);
     } else {
-      hipLaunchKernelGGL(F::reduce2_30_kernel, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, (F::G1Xyzz30*)nullptr,
+      hipLaunchKernelGGL(r2, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, (F::G1Xyzz30*)nullptr,
                          (G1Xyzz*)ws.win.ptr, nseg, 1);
     }
     MH_HIP(hipGetLastError());
@@ -1692,6 +1710,8 @@ int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out) {
   MH_HIP(hipMemcpyAsync(c.io.ptr, h.data(), h.size() * 4, hipMemcpyHostToDevice, c.stream));
   MH_HIP(hipMemsetAsync(d_bad, 0, 4, c.stream));
   hipLaunchKernelGGL(msmfb::selftest30_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c.stream, (const Fq*)c.io.ptr, (u64)n, d_bad);
+  // the one-point-per-quad group law of the bucket reduction against the one-lane form (msm_fb_quad.cuh)
+  hipLaunchKernelGGL(msmfb::selftest30_quad_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, (const Fq*)c.io.ptr, (u64)n, d_bad);
   MH_HIP(hipGetLastError());
   u32 bad = 0;
   MH_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c.stream));

@@ -730,3 +730,5 @@ __global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ 
 }
 
 }  // namespace msmfb
+
+#include "msm_fb_quad.cuh"

@@ -210,28 +210,11 @@ def divide_by_vanishing_poly(c, domain_size):
     n = domain_size
     if len(c) < n:
         return [], c
-    q = list(c[n:])
-    for i in range(1, len(c) // n):
-        for j in range(len(q)):
-            if j + n * i < len(q):
-                pass
-    # q_i = sum_{j>=1} p_{i + j n}
+    # q_i = sum_{j>=1} p_{i + j n}: a suffix sum along every residue class mod n (q_i = p_{i+n} + q_{i+n}); r_i = p_i + q_i
     q = [0] * (len(c) - n)
-    for i in range(len(q)):
-        s = 0
-        k = i + n
-        while k < len(c):
-            s += c[k]
-            k += n
-        q[i] = s % R
-    r = [0] * n
-    for i in range(n):
-        s = 0
-        k = i
-        while k < len(c):
-            s += c[k]
-            k += n
-        r[i] = s % R
+    for i in range(len(q) - 1, -1, -1):
+        q[i] = (c[i + n] + (q[i + n] if i + n < len(q) else 0)) % R
+    r = [(c[i] + (q[i] if i < len(q) else 0)) % R for i in range(n)]
     return trim(q), trim(r)
 
 

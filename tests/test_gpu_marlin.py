@@ -157,12 +157,14 @@ sys.stdout.write(pk.vk_bytes().hex() + " " + GM.prove(pk, inst, wit, bytes(range
 
 
 @pytest.mark.parametrize("env,pc", [({"MH_FB": "0"}, "marlin"), ({"MH_FB": "0"}, "sonic"), ({"MH_NTT": "32"}, "marlin"),
-                                    ({"MH_FB_ALIAS": "0"}, "marlin"), ({"MH_FB_SEG_THREADS": "8192"}, "marlin")],
+                                    ({"MH_FB_ALIAS": "0"}, "marlin"), ({"MH_FB_SEG_THREADS": "8192"}, "marlin"),
+                                    ({"MH_FB_QUAD": "2"}, "marlin"), ({"MH_FB_QUAD": "2"}, "sonic"), ({"MH_FB_QUAD": "0"}, "marlin")],
                          ids=lambda v: v if isinstance(v, str) else ",".join("%s=%s" % kv for kv in v.items()))
 def test_alternative_paths_give_the_same_bytes(gpu, env, pc):
     """The paths the library keeps behind switches -- variable-base MSM for every commitment (what serves a key whose window
     table does not fit), the 32-bit-limb NTT kernel, separate sorts for jobs that share a scalar vector, another
-    segmentation of the bucket reduction -- produce the same index commitments and the same proof, byte for byte."""
+    segmentation of the bucket reduction, the bucket reduction with one point per quad of lanes in both stages or in
+    neither -- produce the same index commitments and the same proof, byte for byte."""
     import subprocess, sys
     a, b, log_n = 0x1234567, 0x7654321, 13
     n = 1 << log_n
