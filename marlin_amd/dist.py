@@ -143,16 +143,47 @@ _ALLTOALL_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_
 
 def enable_alltoall(dist, device=None):
     """Registers torch.distributed.all_to_all_single as the exchange of mh_ntt_dist_dev.  The library hands over DEVICE
-    pointers of its own buffers.  RCCL (`device` given): persistent device tensors wrap the exchange, filled and drained with
-    device-to-device copies -- the payload never touches the host.  gloo (CPU tests): staged through host tensors."""
+    pointers of its own buffers.  RCCL (`device` given): torch wraps those buffers without a copy (__cuda_array_interface__) and
+    the collective runs on them directly; if the wrap is refused, persistent device tensors are filled and drained with
+    device-to-device copies -- either way the payload never touches the host.  gloo (CPU tests): staged through host tensors."""
     import torch
     world = dist.get_world_size()
     lib = _lib.load()
-    st = {"n": 0}
+    st = {"n": 0, "zero_copy": device is not None, "views": {}}
+
+    class _DevMem:          # the library's device buffer as a __cuda_array_interface__ object: torch wraps it without a copy
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+    def _view(ptr, nbytes):
+        key = (int(ptr), int(nbytes))
+        t = st["views"].get(key)
+        if t is None:
+            if len(st["views"]) > 64:
+                st["views"].clear()
+            t = torch.as_tensor(_DevMem(ptr, nbytes), device=device)
+            if t.data_ptr() != int(ptr) or t.numel() != nbytes:
+                raise RuntimeError("device view is not zero-copy")
+            st["views"][key] = t
+        return t
 
     def _cb(d_send, bytes_per_peer, d_recv, _user):
         try:
             total = bytes_per_peer * world
+            if device is not None and st["zero_copy"]:
+                # RCCL straight on the library's buffers: no staging copies; the library's stream is drained before the
+                # collective reads, the collective before the library's next kernel
+                try:
+                    send, recv = _view(d_send, total), _view(d_recv, total)
+                except Exception as e:
+                    import sys
+                    print("all_to_all: zero-copy views unavailable (%s); staging through torch tensors" % e, file=sys.stderr)
+                    st["zero_copy"] = False
+                else:
+                    _lib.check(lib.mh_synchronize(), "sync")
+                    dist.all_to_all_single(recv, send)
+                    torch.cuda.synchronize(device)
+                    return 0
             if st["n"] != total:
                 dev = device if device is not None else "cpu"
                 st["send"] = torch.empty(total, dtype=torch.uint8, device=dev)
@@ -177,6 +208,7 @@ def enable_alltoall(dist, device=None):
             return -1
     cb = _ALLTOALL_T(_cb)
     _keepalive["a2a"] = cb
+    _keepalive["a2a_state"] = st
     _lib.check(lib.mh_marlin_set_alltoall(C.cast(cb, C.c_void_p), None), "mh_marlin_set_alltoall")
 
 

@@ -549,6 +549,16 @@ for _ in range(3):                                       # persistent staging bu
     _lib.check(_lib.load().mh_marlin_test_allgather(send.ctypes.data, send.nbytes, recv.ctypes.data), "test_allgather")
     assert np.array_equal(send, recv)
 t = torch.ones(8, device="cuda"); dist.all_reduce(t); assert float(t.sum()) == 8.0
+# the all-to-all of the distributed transforms: the registered callback on two of the library's own device buffers
+# (zero-copy views of them go straight into RCCL), twice so that the cached views are reused
+MD.enable_alltoall(dist, device=torch.device("cuda", 0))
+x = np.random.default_rng(5).integers(0, 1 << 62, size=(1 << 14, 4), dtype=np.uint64)
+a, b = M.DeviceBuffer.from_numpy(x), M.DeviceBuffer(x.nbytes)
+for _ in range(2):
+    assert MD._keepalive["a2a"](a.ptr, x.nbytes, b.ptr, None) == 0
+    assert np.array_equal(b.download(x.shape), x)
+    b.upload(np.zeros_like(x))
+assert MD._keepalive["a2a_state"]["zero_copy"], "RCCL ran on staging tensors, not on the library's buffers"
 print("rccl world=1 ok:", torch.cuda.get_device_name(0))
 dist.destroy_process_group()
 '''
