@@ -173,7 +173,10 @@ __global__ __launch_bounds__(128) void table_level_kernel(const G1Affine* __rest
 // every scalar but keeps only the digits that fall into its partitions.  Interleaved, not contiguous, because the
 // buckets are not equally loaded: the windows narrower than c bits (and the top window) only reach the low buckets.
 struct Own { u32 first, stride; };
-__device__ __forceinline__ bool owns(const Own& o, u32 v) { return v % o.stride == o.first; }
+// (rank counts are powers of two except in tests: the mask form spares the recoding passes a 32-bit division per digit)
+__device__ __forceinline__ bool owns(const Own& o, u32 v) {
+  return (o.stride & (o.stride - 1)) == 0 ? (v & (o.stride - 1)) == o.first : v % o.stride == o.first;
+}
 __global__ __launch_bounds__(TPB) void count_kernel(FbJobs jobs, u32* __restrict__ pc, u32 W, Windows win, int is_mont, u32 nparts,
                                                     u32 pshift, u32 S, Own own) {
   __shared__ u32 cnt[MAX_PARTS];

@@ -68,6 +68,32 @@ class UniversalSRS:
                 np.ascontiguousarray(h_xy_mont, dtype=np.uint64).reshape(-1), g2_power(self.tau)] + sp
 
 
+_Q_MOD = {"bls12_381": 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+          "bn254": 21888242871839275222246405745257275088696311157297823662689037894645226208583}[_lib.CURVE]
+# the standard generators of G2 (BLS12-381: the one ark-bls12-381 0.3 and the IETF draft use; BN254: EIP-197's), x.c0, x.c1, y.c0, y.c1
+_G2_GENERATOR = {
+    "bls12_381": (0x024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8,
+                  0x13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e,
+                  0x0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801,
+                  0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be),
+    "bn254": (10857046999023057135944570762232829481370756359578518086990519993285655852781,
+              11559732032986387107991004021392285783925812861821192530917403151452391805634,
+              8495653923123431417604973247489272438418190587263600148770280649306958101930,
+              4082367875863433681332203403145435568316851327593401208105741076214120093531),
+}[_lib.CURVE]
+
+
+def g2_generator_mont():
+    """The G2 generator as the (4 * FQ_LIMBS,) uint64 Montgomery limbs `UniversalSRS.verifier_key` and the mh_g2_* entry points
+    take -- an `h` for a test / bench SRS (kzg10::setup draws h at random; any point of G2 serves)."""
+    nl = 6 if _lib.CURVE == "bls12_381" else 4
+    out = []
+    for c in _G2_GENERATOR:
+        v = c * (1 << (64 * nl)) % _Q_MOD
+        out += [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nl)]
+    return np.array(out, dtype=np.uint64)
+
+
 def universal_setup(num_constraints, num_variables, num_non_zero, tau, gamma, pc="marlin"):
     """Marlin::universal_setup (src/lib.rs:79-96) with a caller-chosen tau (test/bench SRS)."""
     return UniversalSRS(max_degree(num_constraints, num_variables, num_non_zero), tau, gamma, full_gamma=(pc == "sonic"))

@@ -487,6 +487,29 @@ def test_bench_gpus_2_runs_two_sharded_ranks(gpu):
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["constraints"] == 1 << 14
+    # the line carries what was produced: both ranks hold the same proof, the product's verifier accepts it, and it is the
+    # proof one GPU makes from the same inputs and seed
+    assert rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True, rec["proof"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--log-constraints", "14",
+                          "--no-cpu-baseline", "--no-seam-route"], env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    rec1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec1["proof"]["verified"] is True and rec1["proof"]["sha256_32"] == rec["proof"]["sha256_32"]
+
+
+@pytest.mark.skipif(F.CURVE != "bls12_381", reason="the golden proofs are BLS12-381 + MarlinKZG10")
+def test_bench_line_says_its_proof_is_the_oracles_golden_proof(gpu):
+    """bench.py proves the inputs of tests/golden/marlin_proofs_xl.json (same trapdoors, witness values and zk seed): at a size
+    that file holds, the line it prints states that its last proof is byte-identical to the CPU oracle's and verifies."""
+    import json, subprocess, sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--log-constraints", "16",
+                          "--no-cpu-baseline", "--no-seam-route"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["proof"]["verified"] is True and rec["proof"]["oracle_golden"]["byte_identical"] is True, rec["proof"]
 
 
 @pytest.mark.parametrize("pc", ["marlin", "sonic"])
@@ -528,6 +551,7 @@ def test_bench_gpus_4_runs_the_sliced_rounds(gpu):
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 4 and rec["value"] > 0 and "slices" in rec["config"]["parallelism"], rec["config"]
     assert len(rec["ranks_seen"]) == 4 and rec["distinct_devices"] == 1          # four ranks, one physical GPU on this box
+    assert rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True, rec["proof"]
 
 
 RCCL_WORKER = r'''

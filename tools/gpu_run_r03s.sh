@@ -1,0 +1,17 @@
+set -x
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/r03s; mkdir -p $O
+export TMPDIR=/tmp
+( timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log ); tail -14 $O/pytest.log
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; tail -c 1500 $O/bench_default.json
+timeout 1200 bash tools/profile.sh r03s > $O/profile.log 2>&1; tail -3 $O/profile.log
+B="timeout 300 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-seam-route"
+$B --simulate-rank 5/8 > $O/sim_5_8.json 2>/dev/null
+$B --log-constraints 22 --simulate-rank 3/8 > $O/sim_3_8_2p22.json 2>/dev/null
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r03s/sim*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], d['ms_per_step'], d['breakdown_ms_per_step'])
+    except Exception as e: print(f,'ERR',e)
+PY
