@@ -3,6 +3,7 @@ cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r03s; mkdir -p $O
 export TMPDIR=/tmp
 ( timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log ); tail -14 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -1
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; tail -c 1500 $O/bench_default.json
 timeout 1200 bash tools/profile.sh r03s > $O/profile.log 2>&1; tail -3 $O/profile.log
 B="timeout 300 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-seam-route"
