@@ -11,6 +11,11 @@
 // as x30_add / x30_dbl (EFD add-2008-s, dbl-2008-s-1), so every coordinate is limb-for-limb what the one-lane form
 // computes (mh_selftest_fq30 checks that on the device).
 //
+// Measured (profiles/r03p_*): 2,807 instructions per addition instead of 7,099, but 13 us instead of 17 us,
+// not 7 -- a lone wave with one multiplication in flight cannot interleave anything with a dependent v_mad_u64_u32.  The
+// tree stage (reduce2_q_kernel) of a bucket-range shard gains 0.5 ms per proof and is what FbRun::reduce uses there; the
+// segment stage (reduce1_q_kernel) loses at every size and runs only under MH_FB_QUAD=2 (tests keep it honest).
+//
 //   lane role        0        1          2        3
 //   level 1 (add)    U1       U2         S1       S2            P = U2 - U1 (lanes 0, 1), R = S2 - S1 (lanes 2, 3)
 //   level 2          PP       ZZ1 ZZ2    RR       ZZZ1 ZZZ2
