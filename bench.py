@@ -122,6 +122,12 @@ class MarlinProve:
         # the witness values, SRS trapdoors and zk seed of tests/golden/marlin_proofs_xl.json (the first two draws of the
         # reference's test_rng): at the sizes that file holds, the proof this bench makes IS the oracle's golden proof
         a, b = 0x674e1d7463d34c49f9c9f388646067d796542ccbf66f38d3ab574d0ee422c588, 0x5fb51e0ee491c6f26f2fd3ab01162c4d3ad3aff73fc213510ebbf34faa74c07e
+        try:        # the other curve draws other values from the same rng: take them from that configuration's golden file
+            from marlin_amd import _lib as _L0
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "marlin_proofs_xl_%s_%s.json" % (_L0.CURVE, pc))))
+            a, b = int(g["cases"][0]["a"], 16), int(g["cases"][0]["b"], 16)
+        except (OSError, KeyError, IndexError, ValueError):
+            pass
         self.a, self.b = a, b
         t0 = time.time()
         self.tau, self.gamma = tau, gamma
@@ -489,12 +495,16 @@ def main():
             # a committed fixture, not oracle code: the CPU oracle's whole proof for these very inputs (BLS12-381 + MarlinKZG10)
             try:
                 from marlin_amd import _lib as _L0
-                gold = json.load(open(os.path.join(ROOT, "tests", "golden", "marlin_proofs_xl.json")))
-                same_inputs = (int(gold["tau"], 16), int(gold["gamma"], 16), bytes.fromhex(gold["zk_seed"])) == (wl.tau, wl.gamma, wl.seed)
+                gname = ("marlin_proofs_xl.json" if (_L0.CURVE, args.pc) == ("bls12_381", "marlin")
+                         else "marlin_proofs_xl_%s_%s.json" % (_L0.CURVE, args.pc))
+                gpath = os.path.join(ROOT, "tests", "golden", gname)
+                gold = json.load(open(gpath)) if os.path.exists(gpath) else {"cases": []}
+                same_inputs = bool(gold["cases"]) and (int(gold["tau"], 16), int(gold["gamma"], 16), bytes.fromhex(gold["zk_seed"])) == (wl.tau, wl.gamma, wl.seed) \
+                    and (gold.get("curve", "bls12_381"), gold.get("pc", "marlin")) == (_L0.CURVE, args.pc)
                 for case in gold["cases"]:
-                    if (same_inputs and _L0.CURVE == "bls12_381" and args.pc == "marlin" and case["num_constraints"] == wl.N
+                    if (same_inputs and case["num_constraints"] == wl.N
                             and case["num_variables"] == 10 and (int(case["a"], 16), int(case["b"], 16)) == (wl.a, wl.b)):
-                        proof_info["oracle_golden"] = {"file": "tests/golden/marlin_proofs_xl.json", "producer": gold.get("producer"),
+                        proof_info["oracle_golden"] = {"file": "tests/golden/" + gname, "producer": gold.get("producer"),
                                                        "byte_identical": pb.hex() == case["proof_bytes"]}
             except Exception as e:
                 proof_info["oracle_golden"] = {"error": str(e)[:200]}

@@ -14,6 +14,9 @@ Run from the repo root:
                                                   # rounds, the PC logic and Fiat-Shamir stay Python): marlin_proofs_xl.json.
                                                   # Before it writes anything it re-proves the 2^12 case of the pure-Python
                                                   # file with the backend on and checks the bytes.
+    [ORACLE_CURVE=bn254] python tests/golden/make_golden.py xl-cfg <marlin|sonic> <logs>
+                                                  # the same for another PC scheme / the other curve:
+                                                  # marlin_proofs_xl_<curve>_<pc>.json (BASELINE configs[4], benches/bench.rs's shape)
 """
 import hashlib
 import json
@@ -64,10 +67,27 @@ def main():
         assert MR.proof_bytes(MR.prove(pk, cs, FS.ChaChaRng(ZK_SEED, 20))).hex() == c12["proof_bytes"], "C backend diverges from the pure-Python oracle"
         logs = [int(x) for x in sys.argv[2:]] or [16, 18]
         cases, fname = [("dummy_circuit", 1 << lg, 10) for lg in logs], "marlin_proofs_xl.json"
+    pc = "marlin"
+    if len(sys.argv) > 1 and sys.argv[1] == "xl-cfg":
+        # another PC scheme and / or (ORACLE_CURVE=bn254) the other curve: BASELINE configs[4] and benches/bench.rs's own shape.
+        # No pure-Python fixture of these configurations exists at 2^12, so the backend is first checked against the
+        # pure-Python oracle on a 2^9 proof of the same configuration.
+        from oracle import accel
+        pc = sys.argv[2]
+        a, b, cs, pub = build("dummy_circuit", 1 << 9, 10)
+        srs = MR.universal_setup(1 << 9, 1 << 9, 3 << 9, TAU, GAMMA)
+        want = MR.proof_bytes(MR.prove(MR.marlin_index(srs, cs, pc=pc), cs, FS.ChaChaRng(ZK_SEED, 20)))
+        accel.enable()
+        srs = MR.universal_setup(1 << 9, 1 << 9, 3 << 9, TAU, GAMMA)
+        got = MR.proof_bytes(MR.prove(MR.marlin_index(srs, cs, pc=pc), cs, FS.ChaChaRng(ZK_SEED, 20)))
+        assert got == want, "C backend diverges from the pure-Python oracle"
+        logs = [int(x) for x in sys.argv[3:]]
+        cases, fname = [("dummy_circuit", 1 << lg, 10) for lg in logs], "marlin_proofs_xl_%s_%s.json" % (F.CURVE, pc)
     out = {"tau": hex(TAU), "gamma": hex(GAMMA), "zk_seed": ZK_SEED.hex(), "zk_rng": "ChaCha20 (rand_chacha ChaChaRng::from_seed)",
            "cases": []}
     path = os.path.join(ROOT, "tests", "golden", fname)
-    if fname == "marlin_proofs_xl.json":
+    if fname.startswith("marlin_proofs_xl"):
+        out["curve"], out["pc"] = F.CURVE, pc
         out["producer"] = "oracle/*.py with the C backend of oracle/accel.py for NTT / MSM / SRS powers (self-consistency vectors, not arkworks output)"
         if os.path.exists(path):                                  # add sizes to an existing file
             out = json.load(open(path))
@@ -76,7 +96,7 @@ def main():
         a, b, cs, pub = build(kind, nc, nv)
         nnz = 3 * max(nc, nv)
         srs = MR.universal_setup(max(nc, nv), max(nc, nv), nnz, TAU, GAMMA)
-        pk = MR.marlin_index(srs, cs)
+        pk = MR.marlin_index(srs, cs, pc=pc)
         pr = MR.prove(pk, cs, FS.ChaChaRng(ZK_SEED, 20))
         assert MR.verify(pk, pub, pr) and not MR.verify(pk, [a] * len(pub), pr)
         pb = MR.proof_bytes(pr)

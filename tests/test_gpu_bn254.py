@@ -36,3 +36,13 @@ def test_bn254_sonic_2p20_whole_proof_pinned():
     proof recomputed on the CPU (tests/cpu_open.py over libref_hotpath_bn254.so)."""
     out = _run(["tests/test_gpu_parity_pins.py"], extra=["-k", "bn254_sonic"])
     assert "1 passed" in out
+
+
+def test_bn254_whole_golden_proofs_of_the_cpu_oracle():
+    """BN254 + SonicKZG10 at 2^16 and 2^20 (BASELINE configs[4]) and BN254 + MarlinKZG10 at 2^20: the device's proofs are
+    byte for byte the CPU oracle's golden proofs (tests/golden/marlin_proofs_xl_bn254_*.json, make_golden.py xl-cfg)."""
+    import glob
+    if not glob.glob(os.path.join(ROOT, "tests", "golden", "marlin_proofs_xl_bn254_*.json")):
+        pytest.skip("no BN254 golden file")
+    out = _run(["tests/test_gpu_parity_pins.py"], extra=["-k", "golden_xl_cfg"])
+    assert " passed" in out

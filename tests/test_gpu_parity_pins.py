@@ -63,6 +63,35 @@ def test_proof_bytes_match_golden_large(gpu, case):
     assert proof.hex() == case["proof_bytes"]
 
 
+# the other configurations (make_golden.py xl-cfg): this process's curve with SonicKZG10 (benches/bench.rs's own shape at 2^16;
+# 2^20 = BASELINE configs[4] on BN254) and, on BN254, MarlinKZG10.  The BN254 files run in tests/test_gpu_bn254.py's subprocess.
+def _cfg_cases():
+    out = []
+    for pc in ("sonic", "marlin"):
+        path = os.path.join(ROOT, "tests", "golden", "marlin_proofs_xl_%s_%s.json" % (F.CURVE, pc))
+        if os.path.exists(path):
+            g = json.load(open(path))
+            assert (g["curve"], g["pc"], g["tau"], g["gamma"], g["zk_seed"]) == (F.CURVE, pc, LARGE["tau"], LARGE["gamma"], LARGE["zk_seed"])
+            out += [(pc, c) for c in g["cases"]]
+    return out
+
+
+@pytest.mark.parametrize("pc,case", _cfg_cases(), ids=lambda v: v if isinstance(v, str) else "2^%d" % (v["num_constraints"].bit_length() - 1))
+def test_proof_bytes_match_golden_xl_cfg(gpu, pc, case):
+    """Whole proofs of the CPU oracle (C backend for NTT / MSM / SRS) for the other PC scheme / the other curve, every prover
+    polynomial hashed: the device's proof is the same bytes."""
+    n = case["num_constraints"]
+    a, b = int(case["a"], 16), int(case["b"], 16)
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc=pc)
+    assert srs.max_degree == case["srs_max_degree"]
+    ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, case["num_variables"], n)
+    pk = GM.index(srs, ncp, ni, mats, pc=pc)
+    assert (pk.H, pk.K) == (case["H"], case["K"])
+    assert hashlib.blake2s(pk.vk_bytes()).hexdigest() == case["vk_bytes_blake2s"]
+    proof = GM.prove(pk, inst, wit, SEED)
+    assert proof.hex() == case["proof_bytes"]
+
+
 @BLS
 @pytest.mark.parametrize("log_n", [16, 18])
 def test_device_mask_polynomial_equals_sequential_stream(gpu, log_n):
