@@ -408,7 +408,13 @@ def main():
             MD.enable_sharded_prove(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
             sliced_rounds = False
             if not args.no_sliced and (world & (world - 1)) == 0 and world >= 4:     # 2 ranks: the exchanges cost more than they save
-                MD.enable_alltoall(dist, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
+                if backend == "nccl":
+                    # the library runs on a stream torch knows, so that the all-to-alls are ordered with its kernels on the
+                    # device instead of through two host synchronisations each
+                    dev = torch.device("cuda", local_rank)
+                    MD.enable_alltoall(dist, device=dev, stream=MD.use_torch_stream(dev))
+                else:
+                    MD.enable_alltoall(dist, device=None)
                 # the sliced rounds depend on the all-to-all: check one distributed transform against the local one on every
                 # rank, and fall back to the replicated rounds everywhere unless all of them agree
                 try:

@@ -141,15 +141,27 @@ def disable_sharded_prove():
 _ALLTOALL_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
 
 
-def enable_alltoall(dist, device=None):
+def use_torch_stream(device):
+    """Makes the library run on a stream torch knows (mh_set_stream): collectives issued under `torch.cuda.stream(s)` are then
+    ordered with the library's kernels on the device, without host synchronisation.  Returns the stream (kept alive here)."""
+    import torch
+    s = torch.cuda.Stream(device=device)
+    _lib.check(_lib.load().mh_set_stream(C.c_void_p(s.cuda_stream)), "mh_set_stream")
+    _keepalive["stream"] = s
+    return s
+
+
+def enable_alltoall(dist, device=None, stream=None):
     """Registers torch.distributed.all_to_all_single as the exchange of mh_ntt_dist_dev.  The library hands over DEVICE
     pointers of its own buffers.  RCCL (`device` given): torch wraps those buffers without a copy (__cuda_array_interface__) and
     the collective runs on them directly; if the wrap is refused, persistent device tensors are filled and drained with
-    device-to-device copies -- either way the payload never touches the host.  gloo (CPU tests): staged through host tensors."""
+    device-to-device copies -- either way the payload never touches the host.  With `stream` = the stream the library runs on
+    (use_torch_stream) the collective is stream-ordered: RCCL's stream waits for the library's kernels and the library's
+    next kernel waits for RCCL, the host waits for neither.  gloo (CPU tests): staged through host tensors."""
     import torch
     world = dist.get_world_size()
     lib = _lib.load()
-    st = {"n": 0, "zero_copy": device is not None, "views": {}}
+    st = {"n": 0, "zero_copy": device is not None, "views": {}, "stream_ordered": device is not None and stream is not None, "calls": 0}
 
     class _DevMem:          # the library's device buffer as a __cuda_array_interface__ object: torch wraps it without a copy
         def __init__(self, ptr, nbytes):
@@ -180,6 +192,16 @@ def enable_alltoall(dist, device=None):
                     print("all_to_all: zero-copy views unavailable (%s); staging through torch tensors" % e, file=sys.stderr)
                     st["zero_copy"] = False
                 else:
+                    st["calls"] += 1
+                    if st["stream_ordered"]:
+                        try:
+                            with torch.cuda.stream(stream):
+                                dist.all_to_all_single(recv, send, async_op=True).wait()     # wait() = the stream waits, not the host
+                            return 0
+                        except Exception as e:
+                            import sys
+                            print("all_to_all: stream-ordered collective refused (%s); synchronising around it" % e, file=sys.stderr)
+                            st["stream_ordered"] = False
                     _lib.check(lib.mh_synchronize(), "sync")
                     dist.all_to_all_single(recv, send)
                     torch.cuda.synchronize(device)

@@ -583,6 +583,23 @@ for _ in range(2):
     assert np.array_equal(b.download(x.shape), x)
     b.upload(np.zeros_like(x))
 assert MD._keepalive["a2a_state"]["zero_copy"], "RCCL ran on staging tensors, not on the library's buffers"
+# stream-ordered: the library on a torch stream, the collective enqueued under it, no host synchronisation inside the callback;
+# the download that follows is ordered behind it on the same stream.  A proof made on that stream is the same proof.
+from marlin_amd import marlin as GM
+n = 1 << 12
+srs = GM.universal_setup(n, n, 3 * n, 0x1234567, 0x7654321)
+ncp, ni, mats, inst, wit = GM.dummy_circuit(3, 5, 10, n)
+pk = GM.index(srs, ncp, ni, mats)
+want = GM.prove(pk, inst, wit, bytes(range(32)))
+ts = MD.use_torch_stream(torch.device("cuda", 0))
+MD.enable_alltoall(dist, device=torch.device("cuda", 0), stream=ts)
+for _ in range(3):
+    b.upload(np.zeros_like(x))
+    assert MD._keepalive["a2a"](a.ptr, x.nbytes, b.ptr, None) == 0
+    assert np.array_equal(b.download(x.shape), x)
+st = MD._keepalive["a2a_state"]
+assert st["zero_copy"] and st["stream_ordered"] and st["calls"] == 3, st
+assert GM.prove(pk, inst, wit, bytes(range(32))) == want
 print("rccl world=1 ok:", torch.cuda.get_device_name(0))
 dist.destroy_process_group()
 '''
