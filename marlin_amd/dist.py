@@ -77,15 +77,25 @@ def enable_sharded_prove(dist, device=None):
     st = {"n": 0}
 
     def _buffers(nbytes):
-        if st["n"] != nbytes:
+        # grow-only: the four exchanges of a proof carry different job counts, and a pinned allocation per size change would
+        # cost more than the exchange; the calls use views of the size they need
+        if st["n"] < nbytes:
+            cap = max(nbytes, 4096)
             pin = device is not None
-            st["send_h"] = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pin)
-            st["recv_h"] = torch.empty(nbytes * world, dtype=torch.uint8, pin_memory=pin)
+            st["send_H"] = torch.empty(cap, dtype=torch.uint8, pin_memory=pin)
+            st["recv_H"] = torch.empty(cap * world, dtype=torch.uint8, pin_memory=pin)
             if device is not None:
-                st["send_d"] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-                st["recv_d"] = torch.empty(nbytes * world, dtype=torch.uint8, device=device)
-            st["n"] = nbytes
-        return st
+                st["send_D"] = torch.empty(cap, dtype=torch.uint8, device=device)
+                st["recv_D"] = torch.empty(cap * world, dtype=torch.uint8, device=device)
+            st["n"] = cap
+            st["views"] = {}
+        v = st["views"].get(nbytes)
+        if v is None:
+            v = {"send_h": st["send_H"][:nbytes], "recv_h": st["recv_H"][:nbytes * world]}
+            if device is not None:
+                v["send_d"], v["recv_d"] = st["send_D"][:nbytes], st["recv_D"][:nbytes * world]
+            st["views"][nbytes] = v
+        return v
 
     def _gather(dst, src):
         try:
@@ -206,12 +216,12 @@ def enable_alltoall(dist, device=None, stream=None):
                     dist.all_to_all_single(recv, send)
                     torch.cuda.synchronize(device)
                     return 0
-            if st["n"] != total:
+            if st["n"] < total:                         # grow-only staging (exchanges of different sizes alternate)
                 dev = device if device is not None else "cpu"
                 st["send"] = torch.empty(total, dtype=torch.uint8, device=dev)
                 st["recv"] = torch.empty(total, dtype=torch.uint8, device=dev)
                 st["n"] = total
-            send, recv = st["send"], st["recv"]
+            send, recv = st["send"][:total], st["recv"][:total]
             if device is not None:
                 _lib.check(lib.mh_memcpy_d2d(send.data_ptr(), d_send, total), "d2d")
                 _lib.check(lib.mh_synchronize(), "sync")
