@@ -50,6 +50,14 @@ rc = _lib.load().mh_marlin_test_allgather(send.ctypes.data, send.nbytes, recv.ct
 assert rc == 0
 for g in range(world):
     assert (recv[18 * g: 18 * (g + 1)] == np.arange(18, dtype=np.uint64) + 1000 * g).all()
+# payloads of different sizes alternate inside a proof (4, 4, 3, 2 jobs per exchange): the staging buffers only grow and every
+# call works on views of the size it needs
+for words in (74, 38, 74, 20, 600, 38, 74):
+    send = np.arange(words, dtype=np.uint64) * 3 + 1000 * rank
+    recv = np.zeros(words * world, dtype=np.uint64)
+    assert _lib.load().mh_marlin_test_allgather(send.ctypes.data, send.nbytes, recv.ctypes.data) == 0
+    for g in range(world):
+        assert (recv[words * g: words * (g + 1)] == np.arange(words, dtype=np.uint64) * 3 + 1000 * g).all()
 D.disable_sharded_prove()
 dist.barrier(); dist.destroy_process_group()
 '''
