@@ -284,7 +284,10 @@ int mh_marlin_get_poly(uint64_t pk, const char* label, uint64_t* out, size_t cap
 
 /* ---- profiling: accumulated HIP-event time per kernel family on the library stream ----
  * family: 0 = ntt passes, 1 = msm (wall time of the MSM groups, all stages), 2 = msm accum only, 3 = glue, 4 = the msm sort and
- * bucket-reduction stages by themselves (they run beside the accumulation of the group's other half, on a second stream).  */
+ * bucket-reduction stages by themselves (they run beside the accumulation of the group's other half, on a second stream).
+ * mh_prof_enable(on): 0 = off, 1 = every family, any other value = a mask with bit (f + 1) set for each family f to record
+ * (8 = the accumulate kernel only).  An event pair per scope is not free: ~90 scopes per proof cost ~1 ms of launch gaps, so a
+ * timed run records the one family it needs (bench.py) and takes the full breakdown from untimed proofs.  */
 int mh_prof_enable(int on);
 int mh_prof_reset(void);
 int mh_prof_get(int family, double* total_ms_out, uint64_t* launches_out);

@@ -300,8 +300,10 @@ def g1_to_affine(xyz):
     return out, bool(inf.value)
 
 
-def prof_enable(on=True):
-    _lib.check(_L().mh_prof_enable(1 if on else 0), "mh_prof_enable")
+def prof_enable(on=True, families=None):
+    """HIP-event timing per kernel family (mh_prof_enable); families = the ones to record (None = all)."""
+    v = 0 if not on else (1 if families is None else sum(1 << (int(f) + 1) for f in families))
+    _lib.check(_L().mh_prof_enable(v), "mh_prof_enable")
 
 
 def prof_reset():

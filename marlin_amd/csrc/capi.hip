@@ -1668,6 +1668,7 @@ int mh_g2_msm(uint64_t handle, size_t base_offset, const uint64_t* scalars, int 
 int mh_prof_enable(int on) {
   LOCKED_CTX();
   c.prof_on = on != 0;
+  c.prof_mask = (on == 0 || on == 1) ? ~0u : ((unsigned)on >> 1);
   return MH_OK;
 }
 static int prof_drain(Context& c) {

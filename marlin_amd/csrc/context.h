@@ -1,6 +1,7 @@
 // Process-wide device context of libmarlin_hip.so: one GPU, one stream, cached
 // twiddle table, scratch buffers, uploaded base sets, HIP-event profiling.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -106,6 +107,7 @@ struct Context {
 
   // profiling
   bool prof_on = false;
+  unsigned prof_mask = ~0u;            // families whose scopes record events (mh_prof_enable)
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   double prof_ms[PF_COUNT] = {0, 0, 0, 0, 0};
@@ -120,7 +122,7 @@ struct ProfScope {
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t st;
   ProfScope(Context& c_, int fam_, hipStream_t s_ = nullptr) : c(c_), fam(fam_), st(s_ ? s_ : c_.stream) {
-    if (!c.prof_on) return;
+    if (!c.prof_on || !((c.prof_mask >> fam) & 1u)) return;
     auto get = [&]() { hipEvent_t e; if (!c.ev_pool.empty()) { e = c.ev_pool.back(); c.ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
     a = get(); b = get();
     (void)hipEventRecord(a, st);

@@ -1,0 +1,20 @@
+"""Idle time between consecutive dispatches of the LAST prove in a rocprofv3 --kernel-trace CSV of bench.py:
+python tools/gap_analysis.py <kernel_trace.csv>.  A prove starts at the first poly::spmv_kernel of its pair."""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if "spmv" in r["Kernel_Name"]]
+pr = rows[starts[-2]:]
+gaps = []
+for a, b in zip(pr, pr[1:]):
+    g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3      # us
+    gaps.append((max(g, 0.0), a["Kernel_Name"].split("(")[0][-40:], b["Kernel_Name"].split("(")[0][-40:]))
+tot = sum(g for g, _, _ in gaps)
+span = (int(pr[-1]["End_Timestamp"]) - int(pr[0]["Start_Timestamp"])) / 1e3
+print("dispatches %d, span %.1f us, idle between dispatches %.1f us" % (len(pr), span, tot))
+for lo, hi in ((0, 5), (5, 15), (15, 40), (40, 100), (100, 1e9)):
+    sel = [g for g, _, _ in gaps if lo <= g < hi]
+    print("  gaps in [%g, %g) us: %4d, sum %.1f us" % (lo, hi, len(sel), sum(sel)))
+print("largest gaps (us, after kernel -> before kernel):")
+for g, a, b in sorted(gaps, reverse=True)[:25]:
+    print("  %8.1f  %s -> %s" % (g, a, b))

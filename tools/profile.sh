@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-seam-route $*"
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-seam-route --full-prof $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # per-dispatch durations of the accumulate kernel: kernel_stats averages over index + warm-up + timed launches, the
@@ -33,7 +33,7 @@ json.dump({"kernel": "bucket accumulation (msmfb::accum30_kernel)", "dispatch_ms
                    "earlier dispatches belong to Marlin::index (larger batches) and the warm-up prove" % steps},
           open(out + "/accum_dispatches.json", "w"), indent=1)
 PY
-CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam-route $*"
+CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam-route --full-prof $*"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD1 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $CMD1 > $OUT/pmc_write.log 2>&1
 find $OUT/pmc_fetch -name "*counter_collection.csv" -exec cp {} $OUT/pmc_fetch.csv \;
