@@ -269,6 +269,10 @@ typedef int (*mh_alltoall_fn)(const void* d_send, size_t bytes_per_peer, void* d
  * pointwise work between them and the opening polynomials on 1 / world of each vector, with two all-gathers (this callback
  * with the same chunk for every peer) per proof -- same proof bytes.  NULL unregisters. */
 int mh_marlin_set_alltoall(mh_alltoall_fn alltoall, void* user);
+/* stream_ordered != 0: the registered all-to-all orders itself against the library's stream on the device (it enqueues on the
+ * stream given to mh_set_stream, or makes that stream wait), so the library does not synchronise the stream before calling it and
+ * the callback must not assume finished buffers on the host side.  mh_marlin_set_alltoall resets the mode to 0. */
+int mh_marlin_set_alltoall_mode(int stream_ordered);
 int mh_ntt_dist_dev(int field, const void* d_in_local, void* d_out_local, uint32_t log_n, int inverse);
 /* MSMs of C-layout slices: scalar i of job j multiplies base first_index[j] + i * stride of the handle's set (first_index =
  * rank + offset of the polynomial's base range, stride = world); needs the set's window table, which serves every rank's

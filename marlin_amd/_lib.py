@@ -70,6 +70,7 @@ SYMBOLS = {
     "mh_marlin_proof_deserialize": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mh_marlin_set_shard": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mh_marlin_set_alltoall": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mh_marlin_set_alltoall_mode": (C.c_int, [C.c_int]),
     "mh_ntt_dist_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_msm_batch_sliced_dev": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mh_marlin_test_allgather": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),

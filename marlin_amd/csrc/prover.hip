@@ -293,7 +293,7 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
 // exchanges the 144-byte partial points and every rank adds them, so all ranks see identical commitments.  Unlike a
 // split of the points, this shrinks the sort, the accumulation AND the bucket reduction by the number of ranks and keeps
 // the window width of the one-GPU table.
-struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; mh_alltoall_fn a2a = nullptr; void* a2a_user = nullptr; } g_shard;
+struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; mh_alltoall_fn a2a = nullptr; void* a2a_user = nullptr; bool a2a_ordered = false; } g_shard;
 
 HG1 jac_from(const uint64_t* xyz);
 int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, uint32_t log_n, int inverse);
@@ -615,7 +615,15 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
 int mh_marlin_set_alltoall(mh_alltoall_fn alltoall, void* user) {
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
-  g_shard.a2a = alltoall; g_shard.a2a_user = user;
+  g_shard.a2a = alltoall; g_shard.a2a_user = user; g_shard.a2a_ordered = false;
+  return MH_OK;
+}
+// stream_ordered != 0: the registered all-to-all enqueues its work on the library's stream (mh_set_stream: the caller's stream) or
+// orders itself against it on the device, so the library does not drain the stream before calling it.  Reset by mh_marlin_set_alltoall.
+int mh_marlin_set_alltoall_mode(int stream_ordered) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  g_shard.a2a_ordered = stream_ordered != 0;
   return MH_OK;
 }
 
@@ -678,7 +686,7 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
   };
   // the exchange sees finished buffers and hands back a finished buffer (the transport may use its own stream)
   auto exchange = [&](const Fr* send, Fr* recv) -> int {
-    MH_HIP(hipStreamSynchronize(c.stream));
+    if (!g_shard.a2a_ordered) MH_HIP(hipStreamSynchronize(c.stream));
     if (g_shard.a2a(send, (size_t)chunk * 32, recv, g_shard.a2a_user) != 0) return fail(MH_EHIP, "mh_ntt_dist_dev: all_to_all callback failed");
     return MH_OK;
   };
@@ -717,7 +725,7 @@ int allgather2(Context& c, const Fr* a, uint64_t na, const Fr* b, uint64_t nb, c
   MH_TRY(c.sl_send.ensure(G * ch * 32)); MH_TRY(c.sl_recv.ensure(G * ch * 32));
   hipLaunchKernelGGL(nttdist::replicate_kernel, dim3(grid256(ch)), dim3(256), 0, c.stream, (Fr*)c.sl_send.ptr, a, (u64)na, b, (u64)nb, (u32)G);
   MH_HIP(hipGetLastError());
-  MH_HIP(hipStreamSynchronize(c.stream));
+  if (!g_shard.a2a_ordered) MH_HIP(hipStreamSynchronize(c.stream));
   if (g_shard.a2a(c.sl_send.ptr, (size_t)ch * 32, c.sl_recv.ptr, g_shard.a2a_user) != 0) return fail(MH_EHIP, "sliced prove: all_to_all callback failed");
   *recv_out = (const Fr*)c.sl_recv.ptr;
   return MH_OK;

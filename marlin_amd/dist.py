@@ -201,6 +201,8 @@ def enable_alltoall(dist, device=None, stream=None):
                     import sys
                     print("all_to_all: zero-copy views unavailable (%s); staging through torch tensors" % e, file=sys.stderr)
                     st["zero_copy"] = False
+                    st["stream_ordered"] = False
+                    lib.mh_marlin_set_alltoall_mode(0)
                 else:
                     st["calls"] += 1
                     if st["stream_ordered"]:
@@ -212,6 +214,7 @@ def enable_alltoall(dist, device=None, stream=None):
                             import sys
                             print("all_to_all: stream-ordered collective refused (%s); synchronising around it" % e, file=sys.stderr)
                             st["stream_ordered"] = False
+                            lib.mh_marlin_set_alltoall_mode(0)
                     _lib.check(lib.mh_synchronize(), "sync")
                     dist.all_to_all_single(recv, send)
                     torch.cuda.synchronize(device)
@@ -242,6 +245,8 @@ def enable_alltoall(dist, device=None, stream=None):
     _keepalive["a2a"] = cb
     _keepalive["a2a_state"] = st
     _lib.check(lib.mh_marlin_set_alltoall(C.cast(cb, C.c_void_p), None), "mh_marlin_set_alltoall")
+    if st["stream_ordered"]:        # the library then calls the exchange without draining its stream first
+        _lib.check(lib.mh_marlin_set_alltoall_mode(1), "mh_marlin_set_alltoall_mode")
 
 
 def enable_simulated_alltoall(rank, world):

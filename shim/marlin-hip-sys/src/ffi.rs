@@ -126,6 +126,7 @@ extern "C" {
     pub fn mh_marlin_proof_deserialize(bytes: *const u8, len: usize, pc: c_int, flat_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_set_shard(rank: c_int, world: c_int, allgather: mh_allgather_fn, user: *mut c_void) -> c_int;
     pub fn mh_marlin_set_alltoall(alltoall: mh_alltoall_fn, user: *mut c_void) -> c_int;
+    pub fn mh_marlin_set_alltoall_mode(stream_ordered: c_int) -> c_int;
     pub fn mh_ntt_dist_dev(field: c_int, d_in_local: *const c_void, d_out_local: *mut c_void, log_n: u32, inverse: c_int) -> c_int;
     pub fn mh_msm_batch_sliced_dev(bases_handle: u64, njobs: usize, first_index: *const usize, stride: usize, d_scalars_local: *const *const c_void,
                                    ns_local: *const usize, scalars_are_montgomery: c_int, combine: c_int, out_xyz_mont: *mut u64) -> c_int;
