@@ -442,7 +442,7 @@ def main():
             if args.no_sliced:
                 MD.enable_simulated_shard(sr, sg)
             else:
-                MD.enable_simulated_alltoall(sr, sg)
+                MD.enable_simulated_alltoall(sr, sg, stream_ordered=not os.environ.get("BENCH_SIM_SYNC_EXCHANGE"))
     elif workload == "seam-route":
         wl = SeamRoute(M, args.log_constraints)
     else:

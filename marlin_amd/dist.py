@@ -249,7 +249,7 @@ def enable_alltoall(dist, device=None, stream=None):
         _lib.check(lib.mh_marlin_set_alltoall_mode(1), "mh_marlin_set_alltoall_mode")
 
 
-def enable_simulated_alltoall(rank, world):
+def enable_simulated_alltoall(rank, world, stream_ordered=True):
     """MEASUREMENT ONLY (like enable_simulated_shard): this process acts as rank `rank` of `world` for mh_ntt_dist_dev and the
     sliced rounds of the prover without any peers.  The exchange copies this rank's own chunk into its slot; the slots of the
     absent peers hold pseudo-random field elements, written once per receive buffer -- so that what the prover then feeds to
@@ -269,10 +269,14 @@ def enable_simulated_alltoall(rank, world):
                 return -1
             filled[d_recv] = total
         off = rank * bytes_per_peer
-        return lib.mh_memcpy_d2d(d_recv + off, d_send + off, bytes_per_peer) or lib.mh_synchronize()
+        # the copy is enqueued on the library's stream: like the RCCL transport of enable_alltoall(stream=...) it is ordered with
+        # the library's kernels on the device, and (stream_ordered) nobody synchronises the host around it
+        return lib.mh_memcpy_d2d(d_recv + off, d_send + off, bytes_per_peer) or (0 if stream_ordered else lib.mh_synchronize())
     cb = _ALLTOALL_T(_cb)
     _keepalive["a2a"] = cb
     _lib.check(lib.mh_marlin_set_alltoall(C.cast(cb, C.c_void_p), None), "mh_marlin_set_alltoall")
+    if stream_ordered:
+        _lib.check(lib.mh_marlin_set_alltoall_mode(1), "mh_marlin_set_alltoall_mode")
     enable_simulated_shard(rank, world)
 
 
