@@ -417,6 +417,7 @@ struct FbRun {
   u64 ent = 0, pco = 0, tile = 0, max_tiles_total = 0; u32 max_blk = 0, seg = 0, nseg = 0, chunks = 1;
   std::vector<msmfb::FbWin> desc; std::vector<msmfb::FbBlk> blk; std::vector<u32> ptot;
   bool skewed = false, quad1 = false, quad2 = false;
+  u32 skew_limit = 0xffffffffu;
   FbRun(Context& c_, const BaseSet& bs_, Context::FbWs& ws_) : c(c_), bs(bs_), ws(ws_) {}
 
   int prepare(int is_mont_, const int* shard) {
@@ -496,8 +497,9 @@ struct FbRun {
     return MH_OK;
   }
 
-  // count / split / hist / scatter + the size order of the buckets; two host round trips on `s` (partition totals for the
-  // descriptors, largest bucket for the skew decision).  skewed = true: the caller takes the variable-base path instead.
+  // count / split / hist / scatter + the size order of the buckets; one host round trip on `s` (partition totals for the
+  // descriptors).  The skew decision travels with the results (finish): skewed = true there means the caller takes the
+  // variable-base path instead.
   int sort(hipStream_t s) {
     namespace F = msmfb;
     ProfScope ps(c, PF_MSM_STAGES, s);
@@ -570,12 +572,11 @@ struct FbRun {
     hipLaunchKernelGGL(F::size_scan_kernel, dim3(1), dim3(1024), 0, s, d_szh);
     hipLaunchKernelGGL(F::size_perm_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, s, (const u32*)ws.tot.ptr, (u64)WB, d_szh,
                        (u32*)ws.perm.ptr);
-    u32 mx = 0;
-    MH_HIP(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    // The skew decision (largest bucket > max(4096, 32 x average)) is taken on the device by the accumulate kernel and read
+    // by the host together with the results (finish): no host round trip between the sort and the accumulation.
     const u64 avg = ent / WB + 1;
-    skewed = mx > 4096 && (u64)mx > 32 * avg;
-    for (size_t st : strides) if (st != 1) skewed = false;     // a strided slice has no variable-base fallback: the buckets are accumulated as they are
+    skew_limit = (u32)std::min<u64>(std::max<u64>(4096, 32 * avg), 0xffffffffull);
+    for (size_t st : strides) if (st != 1) skew_limit = 0xffffffffu;   // a strided slice has no variable-base fallback: the buckets are accumulated as they are
     return MH_OK;
   }
 
@@ -605,15 +606,15 @@ struct FbRun {
       if (acc_waves == 2)
         hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
-                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
       else if (acc_waves == 4)
         hipLaunchKernelGGL(F::accum30_kernel<4>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
-                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
       else
         hipLaunchKernelGGL(F::accum30_kernel<3>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
-                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own);
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
     }
     ProfScope ps(c, PF_MSM_STAGES, s);
     hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw,
@@ -652,8 +653,12 @@ struct FbRun {
   // the nj sums to the host (synchronises `s`)
   int finish(hipStream_t s, HG1* out) {
     std::vector<uint64_t> sums((size_t)nj * XYZZ_L);
+    u32 mx = 0;
     MH_HIP(hipMemcpyAsync(sums.data(), ws.win.ptr, sums.size() * 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipMemcpyAsync(&mx, ws.sums.ptr, 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
+    skewed = mx > skew_limit;                      // the kernels returned at once: `out` is not a result
+    if (skewed) return MH_OK;
     for (int k = 0; k < nj; k++) {
       const uint64_t* p = sums.data() + (size_t)k * XYZZ_L;
       HFq X, Y, ZZ, ZZZ;
@@ -729,9 +734,10 @@ static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* 
   partial = A.partial;
   if (idxB.empty()) {
     MH_TRY(A.sort(s0));
-    if (A.skewed) { skewed = true; partial = false; return MH_OK; }
     MH_TRY(A.accum(s0)); MH_TRY(A.reduce(s0));
-    return A.finish(s0, out);
+    MH_TRY(A.finish(s0, out));
+    if (A.skewed) { skewed = true; partial = false; }
+    return MH_OK;
   }
   MH_TRY(B.prepare(is_mont, shard));
   hipEvent_t* ev = c.fb_ev;
@@ -740,11 +746,9 @@ static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* 
   auto bail = [&](int rc) { (void)hipStreamSynchronize(s1); (void)hipStreamSynchronize(s0); return rc; };
   int rc = A.sort(s0);
   if (rc != MH_OK) return bail(rc);
-  if (A.skewed) { skewed = true; partial = false; return bail(MH_OK); }
   if ((rc = A.accum(s0)) != MH_OK) return bail(rc);
   MH_HIP(hipEventRecord(ev[1], s0));                                   // accum(A) done
   if ((rc = B.sort(s1)) != MH_OK) return bail(rc);                     // beside accum(A)
-  if (B.skewed) { skewed = true; partial = false; return bail(MH_OK); }
   MH_HIP(hipEventRecord(ev[2], s1)); MH_HIP(hipStreamWaitEvent(s0, ev[2], 0));
   if ((rc = B.accum(s0)) != MH_OK) return bail(rc);
   MH_HIP(hipStreamWaitEvent(s1, ev[1], 0));
@@ -755,6 +759,7 @@ static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* 
   std::vector<HG1> ra(idxA.size()), rb(idxB.size());
   if ((rc = A.finish(s0, ra.data())) != MH_OK) return bail(rc);
   if ((rc = B.finish(s0, rb.data())) != MH_OK) return bail(rc);
+  if (A.skewed || B.skewed) { skewed = true; partial = false; return bail(MH_OK); }
   for (size_t i = 0; i < idxA.size(); i++) out[idxA[i]] = ra[i];
   for (size_t i = 0; i < idxB.size(); i++) out[idxB[i]] = rb[i];
   return MH_OK;

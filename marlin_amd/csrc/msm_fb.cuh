@@ -527,9 +527,13 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
                                                                const u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                                const u32* __restrict__ tot, const u32* __restrict__ perm,
                                                                G1Xyzz30* __restrict__ buckets, u32* __restrict__ pend,
-                                                               u32* __restrict__ n_deferred, u32 nb, u64 WB, u32 nparts, Own own) {
+                                                               u32* __restrict__ n_deferred, u32 nb, u64 WB, u32 nparts, Own own,
+                                                               const u32* __restrict__ largest, u32 skew_limit) {
   const u64 slot = (u64)blockIdx.x * msm::ACC_TPB + threadIdx.x;
   if (slot >= WB) return;
+  // a batch whose largest bucket exceeds the limit leaves this path (the host sees the same number with the results and takes
+  // the variable-base path): return at once instead of walking a list of millions in one thread
+  if (*largest > skew_limit) return;
   const u64 gid = perm[slot];
   const FbWin d = fbw[gid / nb];
   const u32* lst = sorted_all + d.off + base[gid];
