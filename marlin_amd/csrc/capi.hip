@@ -510,8 +510,10 @@ struct FbRun {
     hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
     hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)ws.pc.ptr,
                        (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S, own);
-    MH_HIP(hipMemcpyAsync(ptot.data(), ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
+    MH_TRY(ws.h_ptot.ensure((size_t)WT * 4));
+    MH_HIP(hipMemcpyAsync(ws.h_ptot.ptr, ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
+    memcpy(ptot.data(), ws.h_ptot.ptr, (size_t)WT * 4);
     // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count.  The XCD of
     // a window is its rank among the windows that HAVE entries, mod 8: with the MSM sharded over G ranks a rank owns the
     // partitions v = g (mod G), and numbering by gw would put all of them on one XCD for G = 8
@@ -542,8 +544,14 @@ struct FbRun {
       for (size_t li = x; li < live.size(); li += 8)
         for (u32 t = 0; t < desc[live[li]].ntiles; t++) blk[(k++ << 3) | x] = F::FbBlk{live[li], t};
     }
-    MH_HIP(hipMemcpyAsync(ws.desc.ptr, desc.data(), (size_t)WT * sizeof(msmfb::FbWin), hipMemcpyHostToDevice, s));
-    if (grid_tiles) MH_HIP(hipMemcpyAsync(ws.blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
+    // the pinned copies are reused by the next group only after this group's finish() has synchronised the stream
+    MH_TRY(ws.h_desc.ensure((size_t)WT * sizeof(msmfb::FbWin))); MH_TRY(ws.h_blk.ensure(blk.size() * sizeof(F::FbBlk) + 8));
+    memcpy(ws.h_desc.ptr, desc.data(), (size_t)WT * sizeof(msmfb::FbWin));
+    MH_HIP(hipMemcpyAsync(ws.desc.ptr, ws.h_desc.ptr, (size_t)WT * sizeof(msmfb::FbWin), hipMemcpyHostToDevice, s));
+    if (grid_tiles) {
+      memcpy(ws.h_blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk));
+      MH_HIP(hipMemcpyAsync(ws.blk.ptr, ws.h_blk.ptr, blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
+    }
     const msmfb::FbWin* fbw = (const msmfb::FbWin*)ws.desc.ptr;
     const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;
     const size_t lds = (size_t)nb * 4;
@@ -652,11 +660,14 @@ struct FbRun {
 
   // the nj sums to the host (synchronises `s`)
   int finish(hipStream_t s, HG1* out) {
-    std::vector<uint64_t> sums((size_t)nj * XYZZ_L);
-    u32 mx = 0;
-    MH_HIP(hipMemcpyAsync(sums.data(), ws.win.ptr, sums.size() * 8, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipMemcpyAsync(&mx, ws.sums.ptr, 4, hipMemcpyDeviceToHost, s));
+    const size_t sums_n = (size_t)nj * XYZZ_L;
+    MH_TRY(ws.h_out.ensure(sums_n * 8 + 8));
+    uint64_t* sums_h = (uint64_t*)ws.h_out.ptr;
+    MH_HIP(hipMemcpyAsync(sums_h, ws.win.ptr, sums_n * 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipMemcpyAsync(sums_h + sums_n, ws.sums.ptr, 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
+    const u32 mx = *(const u32*)(sums_h + sums_n);
+    std::vector<uint64_t> sums(sums_h, sums_h + sums_n);
     skewed = mx > skew_limit;                      // the kernels returned at once: `out` is not a result
     if (skewed) return MH_OK;
     for (int k = 0; k < nj; k++) {

@@ -55,6 +55,21 @@ struct Scratch {
   void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
+// page-locked host staging for the small copies in a hot path (asynchronous for real, no bounce through the runtime's buffer)
+struct Pinned {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return MH_OK;
+    if (ptr) { (void)hipHostFree(ptr); ptr = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&ptr, want, hipHostMallocDefault) != hipSuccess) { ptr = nullptr; return fail(MH_ENOMEM, "hipHostMalloc staging failed"); }
+    cap = want;
+    return MH_OK;
+  }
+  void release() { if (ptr) (void)hipHostFree(ptr); ptr = nullptr; cap = 0; }
+};
+
 struct BaseSet {
   void* d_points = nullptr;  // G1Affine[n]
   size_t n = 0;
@@ -98,7 +113,11 @@ struct Context {
   // reduction overlap the other's accumulation on a second stream (capi.hip: msm_fb_pipeline)
   struct FbWs {
     Scratch dig, val, sorted, pc, ptot, desc, blk, bh, tot, base, pend, buckets, seg, win, sums, perm;
-    void release_all() { for (Scratch* b : {&dig, &val, &sorted, &pc, &ptot, &desc, &blk, &bh, &tot, &base, &pend, &buckets, &seg, &win, &sums, &perm}) b->release(); }
+    Pinned h_ptot, h_desc, h_blk, h_out;      // host side of the partition totals, the descriptors, the block list, the results
+    void release_all() {
+      for (Scratch* b : {&dig, &val, &sorted, &pc, &ptot, &desc, &blk, &bh, &tot, &base, &pend, &buckets, &seg, &win, &sums, &perm}) b->release();
+      for (Pinned* b : {&h_ptot, &h_desc, &h_blk, &h_out}) b->release();
+    }
   } fbws[2];
   hipStream_t stream2 = nullptr;     // library-owned side stream of the fixed-base pipeline
   hipEvent_t fb_ev[4] = {nullptr, nullptr, nullptr, nullptr};
