@@ -512,6 +512,24 @@ def test_bench_line_says_its_proof_is_the_oracles_golden_proof(gpu):
     assert rec["proof"]["verified"] is True and rec["proof"]["oracle_golden"]["byte_identical"] is True, rec["proof"]
 
 
+@pytest.mark.skipif(F.CURVE != "bls12_381", reason="the golden proofs are BLS12-381 + MarlinKZG10")
+@pytest.mark.parametrize("env", [{"MH_FB_SPLIT": "1"}, {"MH_ACC_WAVES": "2"}, {"MH_ACC_WAVES": "4"}, {"MH_FB_QUAD": "2"}, {"MH_NTT_NS": "1"}],
+                         ids=lambda v: ",".join("%s=%s" % kv for kv in v.items()))
+def test_tuning_switches_leave_the_golden_proof_alone_at_2p18(gpu, env):
+    """The experiments kept behind switches -- the two-stream sub-batch pipeline, the accumulate kernel at 2 / 4 resident waves,
+    the quad-lane bucket reduction in both stages, one NTT stage per register round -- at a size where they really engage
+    (2^18: the round-1 batch has 20 M entries): `bench.py` under the switch still prints the oracle's golden proof."""
+    import json, subprocess, sys
+    e = dict(os.environ, **env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--log-constraints", "18",
+                          "--no-cpu-baseline", "--no-seam-route"], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["proof"]["verified"] is True and rec["proof"]["oracle_golden"]["byte_identical"] is True, rec["proof"]
+
+
 @pytest.mark.parametrize("pc", ["marlin", "sonic"])
 def test_prove_with_caller_supplied_zk_draws(gpu, pc):
     """`Marlin::prove` is generic over `R: RngCore` (src/lib.rs:151-155).  mh_marlin_prove_draws takes the field elements
