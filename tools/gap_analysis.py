@@ -1,10 +1,13 @@
 """Idle time between consecutive dispatches of the LAST prove in a rocprofv3 --kernel-trace CSV of bench.py:
-python tools/gap_analysis.py <kernel_trace.csv>.  A prove starts at the first poly::spmv_kernel of its pair."""
+python tools/gap_analysis.py <kernel_trace.csv> [k].  A prove starts at the first poly::spmv_kernel of its pair; k = 1 (default)
+analyses the last prove, k = 3 the third from the end (bench.py appends `breakdown_steps` proofs with events around every kernel
+family after the timed ones: with --steps 2 the timed proofs are k = 3 and 4)."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "spmv" in r["Kernel_Name"]]
-pr = rows[starts[-2]:]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+pr = rows[starts[-2 * k]:(starts[-2 * (k - 1)] if k > 1 else len(rows))]
 gaps = []
 for a, b in zip(pr, pr[1:]):
     g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3      # us
