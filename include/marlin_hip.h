@@ -273,6 +273,38 @@ int mh_marlin_set_alltoall(mh_alltoall_fn alltoall, void* user);
  * stream given to mh_set_stream, or makes that stream wait), so the library does not synchronise the stream before calling it and
  * the callback must not assume finished buffers on the host side.  mh_marlin_set_alltoall resets the mode to 0. */
 int mh_marlin_set_alltoall_mode(int stream_ordered);
+/* Optional, after mh_marlin_set_alltoall: a real all-gather of DEVICE buffers (`bytes` from every rank into d_recv, rank-major)
+ * for the round polynomials of the sliced sections; without it they travel through the all-to-all, every rank sending `world`
+ * copies of its chunk.  It follows the all-to-all's mode (stream-ordered or not).  NULL unregisters. */
+typedef int (*mh_allgather_dev_fn)(const void* d_send, size_t bytes, void* d_recv, void* user);
+int mh_marlin_set_allgather_dev(mh_allgather_dev_fn allgather_dev, void* user);
+/* Runs a registered device exchange once on the caller's device buffers and waits for it: which = 0 the all-to-all (bytes per
+ * peer), 1 the device all-gather.  For a transport's self-test before the first proof. */
+int mh_marlin_test_exchange_dev(int which, const void* d_send, size_t bytes, void* d_recv);
+
+/* ---- native transport: RCCL called by the library itself (marlin_amd/csrc/rccl_native.h) --------------------------------
+ * The three collectives of a sharded proof -- all-gather of partial points (src/lib.rs:172,193,213: one per PC::commit),
+ * all-to-all of the distributed transforms and all-gather of round polynomials (src/ahp/prover.rs:532-535,655-688) -- issued
+ * from C++ as ncclAllGather / ncclAllToAll on the library's stream: stream-ordered with the kernels around them, no
+ * interpreter and no callback in the path.  librccl.so.1 is resolved with dlopen at the first call (the copy the process has
+ * already mapped, if any), so a one-GPU caller never needs it.
+ *   rank 0:      mh_rccl_unique_id(id)            -- ncclGetUniqueId, 128 opaque bytes
+ *   the caller:  hands `id` to every rank (bench.py: one torch.distributed broadcast; a C caller: its own bootstrap)
+ *   every rank:  mh_marlin_set_rccl(rank, world, id)   -- COLLECTIVE (ncclCommInitRank); afterwards mh_marlin_prove shards its MSMs
+ *                by bucket range and runs rounds 2, 3 and the openings on slices when world is 4 or 8
+ * mh_marlin_rccl_sliced(0) keeps the AHP rounds replicated (MSM sharding only); mh_marlin_set_shard / _set_alltoall with a
+ * callback replace the native transport again; mh_marlin_rccl_destroy (also run by mh_shutdown) frees the communicator.
+ * A failure on one rank inside a sharded mh_marlin_prove leaves the peers waiting in the next collective: the caller must
+ * tear the job down (torch.distributed.run does when a rank exits non-zero). */
+int mh_rccl_unique_id(uint8_t* id128_out);
+int mh_marlin_set_rccl(int rank, int world, const uint8_t* id128);
+int mh_marlin_rccl_sliced(int sliced);
+int mh_marlin_rccl_destroy(void);
+/* returns 1 when the native transport is active, 0 otherwise.  info4 (may be NULL): host-payload all-gathers, all-to-alls, device
+ * all-gathers, bytes this rank sent to peers since mh_marlin_set_rccl; lib_path (may be NULL): the librccl the symbols came from */
+int mh_marlin_rccl_info(uint64_t* info4, char* lib_path, size_t cap);
+/* exchanges (any transport) since the last reset: how many, and the host's wall-clock milliseconds spent inside them */
+int mh_marlin_exchange_stats(uint64_t* calls_out, double* host_ms_out, int reset);
 int mh_ntt_dist_dev(int field, const void* d_in_local, void* d_out_local, uint32_t log_n, int inverse);
 /* MSMs of C-layout slices: scalar i of job j multiplies base first_index[j] + i * stride of the handle's set (first_index =
  * rank + offset of the polynomial's base range, stride = world); needs the set's window table, which serves every rank's
@@ -288,7 +320,8 @@ int mh_marlin_get_poly(uint64_t pk, const char* label, uint64_t* out, size_t cap
 
 /* ---- profiling: accumulated HIP-event time per kernel family on the library stream ----
  * family: 0 = ntt passes, 1 = msm (wall time of the MSM groups, all stages), 2 = msm accum only, 3 = glue, 4 = the msm sort and
- * bucket-reduction stages by themselves (they run beside the accumulation of the group's other half, on a second stream).
+ * bucket-reduction stages by themselves, 5 = the exchanges of a sharded proof (events on the library's stream around each
+ * collective; with a host-synchronising callback transport the host's wait is in mh_marlin_exchange_stats instead).
  * mh_prof_enable(on): 0 = off, 1 = every family, any other value = a mask with bit (f + 1) set for each family f to record
  * (8 = the accumulate kernel only).  An event pair per scope is not free: ~90 scopes per proof cost ~1 ms of launch gaps, so a
  * timed run records the one family it needs (bench.py) and takes the full breakdown from untimed proofs.  */

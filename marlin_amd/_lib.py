@@ -71,6 +71,14 @@ SYMBOLS = {
     "mh_marlin_set_shard": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mh_marlin_set_alltoall": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mh_marlin_set_alltoall_mode": (C.c_int, [C.c_int]),
+    "mh_marlin_set_allgather_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mh_marlin_test_exchange_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mh_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "mh_marlin_set_rccl": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "mh_marlin_rccl_sliced": (C.c_int, [C.c_int]),
+    "mh_marlin_rccl_destroy": (C.c_int, []),
+    "mh_marlin_rccl_info": (C.c_int, [_u64p, C.c_char_p, C.c_size_t]),
+    "mh_marlin_exchange_stats": (C.c_int, [_u64p, C.POINTER(C.c_double), C.c_int]),
     "mh_ntt_dist_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_msm_batch_sliced_dev": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mh_marlin_test_allgather": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),

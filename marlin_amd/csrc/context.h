@@ -83,7 +83,9 @@ struct G2Set { void* d_points = nullptr; size_t n = 0; };   // G2Affine[n] (x.c0
 
 // PF_MSM: wall time of the MSM groups on the main stream (accumulation included); PF_MSM_STAGES: the sort and bucket-reduction
 // stages by themselves, on whichever stream they ran (they overlap the accumulation of the other sub-batch)
-enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_MSM_STAGES = 4, PF_COUNT = 5 };
+// PF_EXCHANGE: the collectives of a sharded proof (all-gather of partial points, all-to-all of the distributed transforms, all-gather of
+// round polynomials), events on the library's stream around each
+enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_MSM_STAGES = 4, PF_EXCHANGE = 5, PF_COUNT = 6 };
 
 struct ProfRec { int family; hipEvent_t a, b; };
 
@@ -129,8 +131,8 @@ struct Context {
   unsigned prof_mask = ~0u;            // families whose scopes record events (mh_prof_enable)
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
-  double prof_ms[PF_COUNT] = {0, 0, 0, 0, 0};
-  uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0, 0};
+  double prof_ms[PF_COUNT] = {0, 0, 0, 0, 0, 0};
+  uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 
 Context& ctx();

@@ -27,6 +27,7 @@
 #include "rng.cuh"
 #include "wire_host.h"
 #include "verify_host.h"
+#include "rccl_native.h"
 #include <chrono>
 #include <cstdlib>
 
@@ -298,7 +299,19 @@ int div_linear(Context& c, Fr* q, const Fr* p, uint64_t len, const HFr& z, Fr* s
 // exchanges the 144-byte partial points and every rank adds them, so all ranks see identical commitments.  Unlike a
 // split of the points, this shrinks the sort, the accumulation AND the bucket reduction by the number of ranks and keeps
 // the window width of the one-GPU table.
-struct Shard { int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; mh_alltoall_fn a2a = nullptr; void* a2a_user = nullptr; bool a2a_ordered = false; } g_shard;
+// ag_dev: all-gather of DEVICE buffers (mh_marlin_set_allgather_dev; the native RCCL transport registers ncclAllGather); without it the
+// round polynomials travel through the all-to-all with the same chunk for every peer
+struct Shard {
+  int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; mh_alltoall_fn a2a = nullptr; void* a2a_user = nullptr;
+  bool a2a_ordered = false; mh_allgather_dev_fn ag_dev = nullptr; void* ag_dev_user = nullptr; bool native = false;
+  double host_ms = 0; uint64_t calls = 0;              // wall time the host spent inside exchanges (mh_marlin_exchange_stats)
+} g_shard;
+// one exchange: HIP events on the library's stream (family PF_EXCHANGE) and the host's wall clock around it
+struct ExchangeScope {
+  ProfScope ps; std::chrono::steady_clock::time_point t0;
+  explicit ExchangeScope(Context& c) : ps(c, PF_EXCHANGE), t0(std::chrono::steady_clock::now()) {}
+  ~ExchangeScope() { g_shard.host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g_shard.calls++; }
+};
 
 HG1 jac_from(const uint64_t* xyz);
 int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, uint32_t log_n, int inverse);
@@ -337,7 +350,10 @@ int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<H
   } else {
     send[npts] = 1;
   }
-  if (g_shard.cb(send.data(), send.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather callback failed");
+  {
+    ExchangeScope xs(c);
+    if (g_shard.cb(send.data(), send.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather failed: " + g_err);
+  }
   MH_TRY(rc);
   for (int g = 0; g < g_shard.world; g++)
     if (all[(size_t)g * stride + npts] != 0) return fail(MH_EHIP, "sharded prove: the MSM of another rank failed");
@@ -643,6 +659,8 @@ extern "C" {
 int mh_marlin_release_all(void) {
   for (auto& kv : g_pks) kv.second->free_all();
   g_pks.clear();
+  if (g_shard.native) g_shard = Shard();
+  (void)rcclnative::destroy();
   return MH_OK;
 }
 
@@ -652,7 +670,64 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);     // g_shard is read by a running mh_marlin_prove under this lock
   g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
+  g_shard.ag_dev = nullptr; g_shard.native = false;   // a callback transport replaces the native one (mh_marlin_set_rccl)
   return MH_OK;                                 // the window table does not depend on the number of ranks (bucket-range sharding)
+}
+
+// ---- native transport: RCCL called by the library on its own stream (rccl_native.h) --------------------------------------
+int mh_rccl_unique_id(uint8_t* id128_out) {
+  if (!id128_out) return fail(MH_EINVAL, "mh_rccl_unique_id: null output");
+  return rcclnative::unique_id(id128_out);
+}
+// Collective: every rank of the node calls it with the same id.  Registers the all-gather of partial points, the all-to-all of
+// the distributed transforms and the device all-gather of round polynomials in one step (what mh_marlin_set_shard +
+// mh_marlin_set_alltoall + mh_marlin_set_alltoall_mode(1) do for a callback transport).
+int mh_marlin_set_rccl(int rank, int world, const uint8_t* id128) {
+  if (world < 1 || rank < 0 || rank >= world || !id128) return fail(MH_EINVAL, "mh_marlin_set_rccl: bad rank / world / id");
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (!c.inited) return fail(MH_ENOINIT, "mh_init has not been called");
+  MH_HIP(hipStreamSynchronize(c.stream));
+  MH_TRY(rcclnative::init(c, rank, world, id128));
+  g_shard.rank = rank; g_shard.world = world; g_shard.cb = rcclnative::allgather_host; g_shard.user = nullptr;
+  g_shard.a2a = rcclnative::alltoall_dev; g_shard.a2a_user = nullptr; g_shard.a2a_ordered = true;
+  g_shard.ag_dev = rcclnative::allgather_dev; g_shard.ag_dev_user = nullptr; g_shard.native = true;
+  return MH_OK;
+}
+// sliced != 0 (default after mh_marlin_set_rccl): rounds 2 and 3 and the openings run on slices when the geometry allows it;
+// 0 keeps the AHP rounds replicated (only the MSMs are sharded) -- what a callback transport gets without an all-to-all
+int mh_marlin_rccl_sliced(int sliced) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (!g_shard.native) return fail(MH_EINVAL, "mh_marlin_rccl_sliced: the native transport is not active");
+  g_shard.a2a = sliced ? rcclnative::alltoall_dev : nullptr;
+  g_shard.a2a_ordered = sliced != 0;
+  g_shard.ag_dev = sliced ? rcclnative::allgather_dev : nullptr; g_shard.ag_dev_user = nullptr;
+  return MH_OK;
+}
+int mh_marlin_rccl_destroy(void) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (c.inited && c.stream) (void)hipStreamSynchronize(c.stream);
+  if (g_shard.native) { g_shard = Shard(); }
+  return rcclnative::destroy();
+}
+// info4: all-gathers of host payloads, all-to-alls, device all-gathers, bytes this rank sent to peers -- since mh_marlin_set_rccl;
+// lib_path (may be NULL): which librccl the symbols came from
+int mh_marlin_rccl_info(uint64_t* info4, char* lib_path, size_t cap) {
+  const rcclnative::State& s = rcclnative::state();
+  if (info4) { info4[0] = s.n_allgather_host; info4[1] = s.n_alltoall; info4[2] = s.n_allgather_dev; info4[3] = s.bytes_moved; }
+  if (lib_path && cap) snprintf(lib_path, cap, "%s", s.api.path.c_str());
+  return g_shard.native ? 1 : 0;
+}
+// exchanges since the last reset, whatever the transport: count and the host's wall-clock milliseconds inside them
+int mh_marlin_exchange_stats(uint64_t* calls_out, double* host_ms_out, int reset) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (calls_out) *calls_out = g_shard.calls;
+  if (host_ms_out) *host_ms_out = g_shard.host_ms;
+  if (reset) { g_shard.calls = 0; g_shard.host_ms = 0; }
+  return MH_OK;
 }
 
 // ---- distributed building blocks (the slice-sharded pipeline) ---------------------------------------------
@@ -660,6 +735,15 @@ int mh_marlin_set_alltoall(mh_alltoall_fn alltoall, void* user) {
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
   g_shard.a2a = alltoall; g_shard.a2a_user = user; g_shard.a2a_ordered = false;
+  g_shard.ag_dev = nullptr; g_shard.ag_dev_user = nullptr;
+  return MH_OK;
+}
+// optional, after mh_marlin_set_alltoall: a real all-gather of device buffers for the round polynomials of the sliced sections
+// (otherwise they go through the all-to-all, every rank sending `world` copies of its chunk); follows the all-to-all's mode
+int mh_marlin_set_allgather_dev(mh_allgather_dev_fn allgather_dev, void* user) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  g_shard.ag_dev = allgather_dev; g_shard.ag_dev_user = user;
   return MH_OK;
 }
 // stream_ordered != 0: the registered all-to-all enqueues its work on the library's stream (mh_set_stream: the caller's stream) or
@@ -731,7 +815,8 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
   // the exchange sees finished buffers and hands back a finished buffer (the transport may use its own stream)
   auto exchange = [&](const Fr* send, Fr* recv) -> int {
     if (!g_shard.a2a_ordered) MH_HIP(hipStreamSynchronize(c.stream));
-    if (g_shard.a2a(send, (size_t)chunk * 32, recv, g_shard.a2a_user) != 0) return fail(MH_EHIP, "mh_ntt_dist_dev: all_to_all callback failed");
+    ExchangeScope xs(c);
+    if (g_shard.a2a(send, (size_t)chunk * 32, recv, g_shard.a2a_user) != 0) return fail(MH_EHIP, "mh_ntt_dist_dev: all_to_all failed: " + g_err);
     return MH_OK;
   };
   if (!inverse) {
@@ -766,11 +851,19 @@ uint64_t slice_c(Context& c, Fr* dst, const Fr* src, uint64_t len) {
 // all ranks' (a | b) chunks, rank-major: the all-to-all with the same chunk for every peer
 int allgather2(Context& c, const Fr* a, uint64_t na, const Fr* b, uint64_t nb, const Fr** recv_out) {
   const uint64_t G = (uint64_t)g_shard.world, ch = na + nb;
-  MH_TRY(c.sl_send.ensure(G * ch * 32)); MH_TRY(c.sl_recv.ensure(G * ch * 32));
-  hipLaunchKernelGGL(nttdist::replicate_kernel, dim3(grid256(ch)), dim3(256), 0, c.stream, (Fr*)c.sl_send.ptr, a, (u64)na, b, (u64)nb, (u32)G);
+  const uint64_t copies = g_shard.ag_dev ? 1 : G;        // a real all-gather sends its chunk once
+  MH_TRY(c.sl_send.ensure(copies * ch * 32)); MH_TRY(c.sl_recv.ensure(G * ch * 32));
+  hipLaunchKernelGGL(nttdist::replicate_kernel, dim3(grid256(ch)), dim3(256), 0, c.stream, (Fr*)c.sl_send.ptr, a, (u64)na, b, (u64)nb, (u32)copies);
   MH_HIP(hipGetLastError());
   if (!g_shard.a2a_ordered) MH_HIP(hipStreamSynchronize(c.stream));
-  if (g_shard.a2a(c.sl_send.ptr, (size_t)ch * 32, c.sl_recv.ptr, g_shard.a2a_user) != 0) return fail(MH_EHIP, "sliced prove: all_to_all callback failed");
+  {
+    ExchangeScope xs(c);
+    if (g_shard.ag_dev) {
+      if (g_shard.ag_dev(c.sl_send.ptr, (size_t)ch * 32, c.sl_recv.ptr, g_shard.ag_dev_user) != 0) return fail(MH_EHIP, "sliced prove: all_gather failed: " + g_err);
+    } else if (g_shard.a2a(c.sl_send.ptr, (size_t)ch * 32, c.sl_recv.ptr, g_shard.a2a_user) != 0) {
+      return fail(MH_EHIP, "sliced prove: all_to_all failed: " + g_err);
+    }
+  }
   *recv_out = (const Fr*)c.sl_recv.ptr;
   return MH_OK;
 }
@@ -841,7 +934,10 @@ int mh_msm_batch_sliced_dev(uint64_t bases_handle, size_t njobs, const size_t* f
   if (!g_shard.cb) return fail(MH_EINVAL, "mh_msm_batch_sliced_dev: no all_gather callback registered");
   part[(size_t)XYZ_L * njobs] = rc == MH_OK ? 0 : 1;                 // a failing rank still enters the collective
   std::vector<uint64_t> all(part.size() * g_shard.world);
-  if (g_shard.cb(part.data(), part.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "mh_msm_batch_sliced_dev: all_gather callback failed");
+  {
+    ExchangeScope xs(c);
+    if (g_shard.cb(part.data(), part.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "mh_msm_batch_sliced_dev: all_gather failed: " + g_err);
+  }
   MH_TRY(rc);
   for (int g = 0; g < g_shard.world; g++)
     if (all[(size_t)g * part.size() + XYZ_L * njobs] != 0) return fail(MH_EHIP, "mh_msm_batch_sliced_dev: the MSM of another rank failed");
@@ -951,6 +1047,25 @@ int mh_marlin_proof_deserialize(const uint8_t* bytes, size_t len, int pc, uint8_
 int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv) {
   if (!g_shard.cb) return fail(MH_EINVAL, "no all_gather callback registered");
   return g_shard.cb(send, bytes, recv, g_shard.user);
+}
+// the registered device exchanges, run once on the caller's device buffers and drained (self-tests of a transport: what the
+// sliced sections would call, without a proof around it).  which = 0: all-to-all (bytes = per peer), 1: device all-gather
+int mh_marlin_test_exchange_dev(int which, const void* d_send, size_t bytes, void* d_recv) {
+  LOCKED_CTX();
+  if (!d_send || !d_recv) return fail(MH_EINVAL, "mh_marlin_test_exchange_dev: null pointer");
+  if (which == 0) {
+    if (!g_shard.a2a) return fail(MH_EINVAL, "no all_to_all registered");
+    if (!g_shard.a2a_ordered) MH_HIP(hipStreamSynchronize(c.stream));
+    ExchangeScope xs(c);
+    if (g_shard.a2a(d_send, bytes, d_recv, g_shard.a2a_user) != 0) return fail(MH_EHIP, "all_to_all failed: " + g_err);
+  } else {
+    if (!g_shard.ag_dev) return fail(MH_EINVAL, "no device all_gather registered");
+    if (!g_shard.a2a_ordered) MH_HIP(hipStreamSynchronize(c.stream));
+    ExchangeScope xs(c);
+    if (g_shard.ag_dev(d_send, bytes, d_recv, g_shard.ag_dev_user) != 0) return fail(MH_EHIP, "device all_gather failed: " + g_err);
+  }
+  MH_HIP(hipStreamSynchronize(c.stream));
+  return MH_OK;
 }
 
 int mh_marlin_pk_free(uint64_t pk_handle) {
@@ -1641,7 +1756,10 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     if (eg > ag) MH_TRY(eval_poly(c, pk, S[3], eg - ag, gamma, &Eg));
     std::vector<uint64_t> snd(8), all_e(8 * G);
     memcpy(&snd[0], Eb.v, 32); memcpy(&snd[4], Eg.v, 32);
-    if (g_shard.cb(snd.data(), 64, all_e.data(), g_shard.user) != 0) return fail(MH_EHIP, "sliced openings: all_gather callback failed");
+    {
+      ExchangeScope xs(c);
+      if (g_shard.cb(snd.data(), 64, all_e.data(), g_shard.user) != 0) return fail(MH_EHIP, "sliced openings: all_gather failed: " + g_err);
+    }
     auto carry = [&](int which, const HFr& z, uint64_t L, uint64_t qlen, uint64_t len) {
       HFr acc = HFr::zero();
       const uint64_t top = bounds(L, qlen, len, r + 1);

@@ -97,12 +97,15 @@ def enable_sharded_prove(dist, device=None):
             st["views"][nbytes] = v
         return v
 
+    # the flat variant is probed ONCE, here, by capability (gloo and RCCL both have it in this torch) -- a RuntimeError inside the
+    # callback is then a transport failure and returns -1 instead of being retried as a second collective the peers do not issue
+    flat = hasattr(dist, "all_gather_into_tensor")
+
     def _gather(dst, src):
-        try:
+        if flat:
             dist.all_gather_into_tensor(dst, src)
-        except (RuntimeError, NotImplementedError, AttributeError):      # a backend without the flat variant
-            parts = list(dst.view(world, -1).unbind(0))
-            dist.all_gather(parts, src)
+        else:
+            dist.all_gather(list(dst.view(world, -1).unbind(0)), src)
 
     def _cb(send, nbytes, recv, _user):
         try:
@@ -125,6 +128,65 @@ def enable_sharded_prove(dist, device=None):
     _lib.check(_lib.load().mh_marlin_set_shard(rank, world, C.cast(cb, C.c_void_p), None), "mh_marlin_set_shard")
 
 
+def enable_native_rccl(dist=None, sliced=True):
+    """The native transport (marlin_amd/csrc/rccl_native.h): the library creates its OWN RCCL communicator and issues the
+    all-gathers / all-to-alls of a sharded proof from C++ on its own stream -- no Python in the exchange path.  `dist` (an
+    initialised torch.distributed, any backend) is used ONCE, to hand rank 0's ncclUniqueId to the other ranks; dist = None
+    makes a communicator of one rank (tests on a one-GPU box).  Every rank first probes that it can reach librccl at all and the
+    ranks agree on the outcome before anyone enters the collective ncclCommInitRank, so a box without RCCL makes this return
+    False everywhere instead of hanging.  Returns True when the native transport is active on every rank."""
+    import torch
+    lib = _lib.load()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    ident = np.zeros(128, dtype=np.uint8)
+    ok = lib.mh_rccl_unique_id(ident.ctypes.data) == 0            # every rank draws one (the probe); rank 0's is the one used
+    if dist is not None and world > 1:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(int(flag.item()))
+        if ok:
+            t = torch.from_numpy(ident).to(dev)
+            dist.broadcast(t, src=0)
+            ident = np.ascontiguousarray(t.cpu().numpy())
+    if not ok:
+        return False
+    _lib.check(lib.mh_marlin_set_rccl(rank, world, ident.ctypes.data), "mh_marlin_set_rccl")
+    if not sliced:
+        _lib.check(lib.mh_marlin_rccl_sliced(0), "mh_marlin_rccl_sliced")
+    return True
+
+
+def native_rccl_info():
+    """{"active", "allgather_host", "alltoall", "allgather_dev", "bytes_sent", "librccl"} of the native transport."""
+    lib = _lib.load()
+    info = (C.c_uint64 * 4)()
+    path = C.create_string_buffer(512)
+    active = lib.mh_marlin_rccl_info(info, path, 512)
+    return {"active": bool(active), "allgather_host": int(info[0]), "alltoall": int(info[1]), "allgather_dev": int(info[2]),
+            "bytes_sent": int(info[3]), "librccl": path.value.decode()}
+
+
+def exchange_stats(reset=False):
+    """(number of exchanges, host wall-clock ms inside them) since the last reset, whatever the transport."""
+    calls, ms = C.c_uint64(), C.c_double()
+    _lib.check(_lib.load().mh_marlin_exchange_stats(C.byref(calls), C.byref(ms), 1 if reset else 0), "mh_marlin_exchange_stats")
+    return int(calls.value), float(ms.value)
+
+
+def selftest_allgather(dist=None):
+    """One all-gather of a rank-dependent payload through whatever transport is registered, checked on every rank."""
+    lib = _lib.load()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    n = 600
+    send = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(rank + 1)).view(np.uint8)
+    recv = np.zeros(send.size * world, dtype=np.uint8)
+    if lib.mh_marlin_test_allgather(send.ctypes.data, send.size, recv.ctypes.data) != 0:
+        return False
+    want = np.concatenate([(np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(g + 1)).view(np.uint8) for g in range(world)])
+    return bool(np.array_equal(recv, want))
+
+
 def enable_simulated_shard(rank, world):
     """MEASUREMENT ONLY: make this process behave like rank `rank` of `world` without any peers -- the exchange is
     replaced by a local copy of this rank's own partial points into every slot, so the proof bytes are NOT valid, but
@@ -142,6 +204,7 @@ def enable_simulated_shard(rank, world):
 
 
 def disable_sharded_prove():
+    _lib.check(_lib.load().mh_marlin_rccl_destroy(), "mh_marlin_rccl_destroy")
     _lib.check(_lib.load().mh_marlin_set_shard(0, 1, None, None), "mh_marlin_set_shard")
     _lib.check(_lib.load().mh_marlin_set_alltoall(None, None), "mh_marlin_set_alltoall")
     _keepalive.clear()
@@ -161,7 +224,7 @@ def use_torch_stream(device):
     return s
 
 
-def enable_alltoall(dist, device=None, stream=None):
+def enable_alltoall(dist, device=None, stream=None, allgather_dev=True):
     """Registers torch.distributed.all_to_all_single as the exchange of mh_ntt_dist_dev.  The library hands over DEVICE
     pointers of its own buffers.  RCCL (`device` given): torch wraps those buffers without a copy (__cuda_array_interface__) and
     the collective runs on them directly; if the wrap is refused, persistent device tensors are filled and drained with
@@ -241,10 +304,52 @@ def enable_alltoall(dist, device=None, stream=None):
             import sys
             print("all_to_all callback failed:", e, file=sys.stderr)
             return -1
+    def _ag(d_send, nbytes, d_recv, _user):
+        """mh_allgather_dev_fn: the round polynomials of the sliced sections as ONE all_gather_into_tensor (each rank sends its
+        chunk once; through the all-to-all it would send `world` copies)."""
+        try:
+            total = nbytes * world
+            if device is not None and st["zero_copy"]:
+                send, recv = _view(d_send, nbytes), _view(d_recv, total)
+                st["calls"] += 1
+                if st["stream_ordered"]:
+                    with torch.cuda.stream(stream):
+                        dist.all_gather_into_tensor(recv, send, async_op=True).wait()
+                    return 0
+                _lib.check(lib.mh_synchronize(), "sync")
+                dist.all_gather_into_tensor(recv, send)
+                torch.cuda.synchronize(device)
+                return 0
+            dev = device if device is not None else "cpu"
+            if st.get("ag_n", 0) < total:
+                st["ag_send"] = torch.empty(total, dtype=torch.uint8, device=dev)
+                st["ag_recv"] = torch.empty(total, dtype=torch.uint8, device=dev)
+                st["ag_n"] = total
+            send, recv = st["ag_send"][:nbytes], st["ag_recv"][:total]
+            if device is not None:
+                _lib.check(lib.mh_memcpy_d2d(send.data_ptr(), d_send, nbytes), "d2d")
+                _lib.check(lib.mh_synchronize(), "sync")
+                dist.all_gather_into_tensor(recv, send)
+                torch.cuda.synchronize(device)
+                _lib.check(lib.mh_memcpy_d2d(d_recv, recv.data_ptr(), total), "d2d")
+                _lib.check(lib.mh_synchronize(), "sync")
+            else:
+                _lib.check(lib.mh_memcpy_d2h(send.data_ptr(), d_send, nbytes), "d2h")
+                dist.all_gather_into_tensor(recv, send)
+                _lib.check(lib.mh_memcpy_h2d(d_recv, recv.data_ptr(), total), "h2d")
+            return 0
+        except Exception as e:      # never unwind into C
+            import sys
+            print("device all_gather callback failed:", e, file=sys.stderr)
+            return -1
     cb = _ALLTOALL_T(_cb)
     _keepalive["a2a"] = cb
     _keepalive["a2a_state"] = st
     _lib.check(lib.mh_marlin_set_alltoall(C.cast(cb, C.c_void_p), None), "mh_marlin_set_alltoall")
+    if allgather_dev:
+        ag = _ALLTOALL_T(_ag)
+        _keepalive["ag_dev"] = ag
+        _lib.check(lib.mh_marlin_set_allgather_dev(C.cast(ag, C.c_void_p), None), "mh_marlin_set_allgather_dev")
     if st["stream_ordered"]:        # the library then calls the exchange without draining its stream first
         _lib.check(lib.mh_marlin_set_alltoall_mode(1), "mh_marlin_set_alltoall_mode")
 

@@ -49,6 +49,10 @@ pub type mh_allgather_fn =
 pub type mh_alltoall_fn =
     Option<unsafe extern "C" fn(d_send: *const c_void, bytes_per_peer: usize, d_recv: *mut c_void, user: *mut c_void) -> c_int>;
 
+/// `mh_allgather_dev_fn`: all-gather on DEVICE buffers (`bytes` from every rank into `d_recv`, rank-major).
+pub type mh_allgather_dev_fn =
+    Option<unsafe extern "C" fn(d_send: *const c_void, bytes: usize, d_recv: *mut c_void, user: *mut c_void) -> c_int>;
+
 extern "C" {
     pub fn mh_curve_info(curve_id: *mut c_int, fr_limbs64: *mut c_int, fq_limbs64: *mut c_int, fr_two_adicity: *mut c_int) -> c_int;
 
@@ -127,6 +131,15 @@ extern "C" {
     pub fn mh_marlin_set_shard(rank: c_int, world: c_int, allgather: mh_allgather_fn, user: *mut c_void) -> c_int;
     pub fn mh_marlin_set_alltoall(alltoall: mh_alltoall_fn, user: *mut c_void) -> c_int;
     pub fn mh_marlin_set_alltoall_mode(stream_ordered: c_int) -> c_int;
+    pub fn mh_marlin_set_allgather_dev(allgather_dev: mh_allgather_dev_fn, user: *mut c_void) -> c_int;
+    pub fn mh_marlin_test_exchange_dev(which: c_int, d_send: *const c_void, bytes: usize, d_recv: *mut c_void) -> c_int;
+    // native transport: RCCL called by the library on its own stream (marlin_amd/csrc/rccl_native.h)
+    pub fn mh_rccl_unique_id(id128_out: *mut u8) -> c_int;
+    pub fn mh_marlin_set_rccl(rank: c_int, world: c_int, id128: *const u8) -> c_int;
+    pub fn mh_marlin_rccl_sliced(sliced: c_int) -> c_int;
+    pub fn mh_marlin_rccl_destroy() -> c_int;
+    pub fn mh_marlin_rccl_info(info4: *mut u64, lib_path: *mut c_char, cap: usize) -> c_int;
+    pub fn mh_marlin_exchange_stats(calls_out: *mut u64, host_ms_out: *mut f64, reset: c_int) -> c_int;
     pub fn mh_ntt_dist_dev(field: c_int, d_in_local: *const c_void, d_out_local: *mut c_void, log_n: u32, inverse: c_int) -> c_int;
     pub fn mh_msm_batch_sliced_dev(bases_handle: u64, njobs: usize, first_index: *const usize, stride: usize, d_scalars_local: *const *const c_void,
                                    ns_local: *const usize, scalars_are_montgomery: c_int, combine: c_int, out_xyz_mont: *mut u64) -> c_int;

@@ -54,6 +54,91 @@ def test_rust_shim_binds_the_whole_header():
         assert "%s as usize" % n in link, n
 
 
+def _c_prototypes():
+    """{name: (return type, [parameter types])} of include/marlin_hip.h, C spelling normalised ("const T *" forms)."""
+    hdr = open(os.path.join(ROOT, "include", "marlin_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", hdr, flags=re.S)
+    hdr = re.sub(r"typedef\s+int\s*\(\*\w+\)\s*\(.*?\)\s*;", "", hdr, flags=re.S)
+    out = {}
+    for ret, name, args in re.findall(r"\b(int|const char\s*\*)\s+(mh_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
+        params = []
+        if args.strip() not in ("", "void"):
+            for a in args.split(","):
+                a = " ".join(a.replace("*", " * ").split())
+                toks = a.split(" ")
+                if toks[-1] != "*" and len(toks) > 1 and re.match(r"^[A-Za-z_]\w*$", toks[-1]) and toks[-1] not in ("int", "size_t", "char", "void", "double"):
+                    toks = toks[:-1]                                  # the parameter's name
+                params.append(" ".join(toks))
+        out[name] = (" ".join(ret.replace("*", " * ").split()), params)
+    return out
+
+
+_C2RUST_BASE = {"int": "c_int", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "char": "c_char", "void": "c_void",
+                "double": "f64", "mh_r1cs_matrices": "mh_r1cs_matrices", "mh_verifier_key": "mh_verifier_key",
+                "mh_allgather_fn": "mh_allgather_fn", "mh_alltoall_fn": "mh_alltoall_fn", "mh_allgather_dev_fn": "mh_allgather_dev_fn"}
+
+
+def _c_to_rust(ctype):
+    """`const uint64_t * const *` -> `*const *const u64`: pointers are read right to left, each with the constness of what
+    it points to."""
+    toks = ctype.split(" ")
+    const_base = False
+    if toks[0] == "const":
+        const_base, toks = True, toks[1:]
+    base, rest = _C2RUST_BASE[toks[0]], toks[1:]
+    levels, pointee_const = [], const_base              # constness of the thing the next '*' points to
+    i = 0
+    while i < len(rest):
+        assert rest[i] == "*", ctype
+        levels.append("*const" if pointee_const else "*mut")
+        pointee_const = i + 1 < len(rest) and rest[i + 1] == "const"
+        i += 2 if pointee_const else 1
+    return " ".join(levels[::-1] + [base]) if levels else base
+
+
+_RUST2CTYPES = {"c_int": "c_int", "usize": "c_size_t", "u64": "c_uint64", "u32": "c_uint32", "u8": "c_ubyte", "f64": "c_double"}
+
+
+def test_rust_and_ctypes_signatures_match_the_header():
+    """not only the NAMES of the header's entry points but every ARGUMENT LIST -- count, order and the
+    C <-> Rust type of each parameter, and the return type -- is compared between include/marlin_hip.h and the extern block of
+    shim/marlin-hip-sys/src/ffi.rs (which no rustc has ever seen), and the parameter COUNT and every by-value scalar type with
+    the ctypes table of marlin_amd/_lib.py (which every test calls through)."""
+    import ctypes as C
+    protos = _c_prototypes()
+    assert sorted(protos) == _declared()
+    ffi = open(os.path.join(ROOT, "shim", "marlin-hip-sys", "src", "ffi.rs")).read()
+    ffi = re.sub(r"//[^\n]*", "", ffi)
+    rust = {}
+    for name, args, ret in re.findall(r"pub fn (mh_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", ffi):
+        params = [" ".join(a.split(":", 1)[1].split()) for a in args.split(",") if a.strip()]
+        rust[name] = (" ".join((ret or "()").split()), params)
+    for name, (cret, cparams) in protos.items():
+        rret, rparams = rust[name]
+        assert rret == _c_to_rust(cret), (name, cret, rret)
+        assert len(rparams) == len(cparams), (name, cparams, rparams)
+        for k, (ct, rt) in enumerate(zip(cparams, rparams)):
+            assert rt == _c_to_rust(ct), "%s parameter %d: C `%s` is Rust `%s`, ffi.rs says `%s`" % (name, k, ct, _c_to_rust(ct), rt)
+        res, argtypes = _lib.SYMBOLS[name]
+        assert len(argtypes) == len(cparams), (name, "ctypes binds %d parameters, the header declares %d" % (len(argtypes), len(cparams)))
+        for k, (ct, at) in enumerate(zip(cparams, argtypes)):
+            rt = _c_to_rust(ct)
+            if rt in _RUST2CTYPES:                       # by-value scalars must agree exactly; pointers are void* / typed pointers in ctypes
+                assert at is getattr(C, _RUST2CTYPES[rt]), (name, k, ct, at)
+            else:
+                assert at in (C.c_void_p, C.c_char_p) or issubclass(at, C._Pointer), (name, k, ct, at)
+        assert res is (C.c_char_p if "char" in cret else C.c_int), (name, res)
+    # the callback typedefs and the two structs, field for field
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "marlin_hip.h")).read(), flags=re.S)
+    for tname, args in re.findall(r"typedef\s+int\s*\(\*(\w+)\)\s*\(([^)]*)\)\s*;", hdr):
+        want = [_c_to_rust(" ".join(" ".join(a.replace("*", " * ").split()).split(" ")[:-1])) for a in args.split(",")]
+        m = re.search(r"pub type %s\s*=\s*Option<unsafe extern \"C\" fn\(([^)]*)\)\s*->\s*c_int>;" % tname, ffi, flags=re.S)
+        assert m, tname
+        got = [" ".join(a.split(":", 1)[1].split()) for a in m.group(1).split(",") if a.strip()]
+        assert got == want, (tname, want, got)
+
+
 def _build_c_example(tmp_path):
     import subprocess
     exe = str(tmp_path / "prove_verify")

@@ -193,7 +193,9 @@ nc, ni, mats, inst, wit = GM.dummy_circuit(%(a)d, %(b)d, 10, n)
 pk = GM.index(srs, nc, ni, mats, pc=%(pc)r)
 MD.enable_sharded_prove(dist)
 if %(sliced)d:
-    MD.enable_alltoall(dist)                # rounds 2 and 3 run on slices (distributed transforms, one all-gather per round)
+    # rounds 2 and 3 run on slices (distributed transforms, one all-gather per round); sliced = 2: the round polynomials go
+    # through the all-to-all (every rank sending `world` copies) instead of the device all-gather
+    MD.enable_alltoall(dist, allgather_dev=%(sliced)d == 1)
 proof = GM.prove(pk, inst, wit, bytes(range(32)))
 proof2 = GM.prove(pk, inst, wit, bytes(range(1, 33)))        # the key's sliced tables are reused
 open(os.path.join(%(out)r, "proof%%d.bin" %% rank), "wb").write(proof + proof2)
@@ -204,7 +206,8 @@ dist.barrier(); dist.destroy_process_group()
 @pytest.mark.parametrize("world,log_n,pc,sliced", [(2, 12, "marlin", 0), (3, 12, "marlin", 0), (2, 16, "sonic", 0), (4, 16, "marlin", 0),
                                                    (8, 12, "marlin", 0), (8, 16, "marlin", 0),
                                                    (2, 12, "marlin", 1), (4, 12, "sonic", 1), (8, 12, "marlin", 1), (4, 16, "marlin", 1),
-                                                   (8, 16, "marlin", 1), (8, 16, "sonic", 1), (3, 12, "marlin", 1)])
+                                                   (8, 16, "marlin", 1), (8, 16, "sonic", 1), (3, 12, "marlin", 1),
+                                                   (4, 12, "marlin", 2), (8, 16, "marlin", 2)])
 def test_sharded_prove_ranks_equal_single(gpu, tmp_path, world, log_n, pc, sliced):
     """MSM sharding by bucket range across 2, 3, 4 and 8 ranks (gloo exchange, all ranks on the one GPU of this box), both PC
     schemes, yields the very same proof bytes as the unsharded prover.  At 2^12 the window table has 2 partitions (c = 13:
@@ -570,6 +573,12 @@ def test_bench_gpus_4_runs_the_sliced_rounds(gpu):
     assert rec["n_gpus"] == 4 and rec["value"] > 0 and "slices" in rec["config"]["parallelism"], rec["config"]
     assert len(rec["ranks_seen"]) == 4 and rec["distinct_devices"] == 1          # four ranks, one physical GPU on this box
     assert rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True, rec["proof"]
+    # a scaling record explains itself: every rank's own step time, kernel families and what the exchanges cost it
+    assert rec["transport"]["kind"] == "callback-torch.distributed-gloo" and rec["transport"]["native_rccl"] is None
+    assert sorted(r["rank"] for r in rec["per_rank"]) == [0, 1, 2, 3]
+    for r in rec["per_rank"]:
+        b = r["breakdown_ms_per_step"]
+        assert r["ms_per_step"] > 0 and b["msm_accum"] > 0 and b["exchanges_per_step"] >= 11 and b["exchange_host_wall"] > 0, r
 
 
 RCCL_WORKER = r'''
