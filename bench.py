@@ -178,6 +178,9 @@ class SeamRoute:
         self.N = 1 << log_n
         H, K = self.N, 4 * self.N
         self.ntts = W.ntt_inventory(H, K)
+        # what each Vec holds when the patched ark-poly hands it over, before its zero-padding: only that much is uploaded
+        # (mh_ntt_len); BENCH_SEAM_FULL_UPLOAD=1 uploads whole domains (the round-3 measurement)
+        self.in_lens = [1 << lg for lg, _, _ in self.ntts] if os.environ.get("BENCH_SEAM_FULL_UPLOAD") else W.ntt_input_lengths(H, K)
         self.msms, _ = W.msm_inventory(H, K)
         self.alg_ntt_bytes, self.alg_msm_bytes = W.algorithmic_bytes(H, K)
         D = max(3 * H - 1, K - 1)
@@ -208,8 +211,8 @@ class SeamRoute:
 
     def step(self, dist=None, torch=None):
         t0 = time.perf_counter()
-        for lg, inverse, _ in self.ntts:
-            rc = self.lib.mh_ntt(self.curve, self.data.ctypes.data, lg, 1 if inverse else 0)
+        for (lg, inverse, _), in_len in zip(self.ntts, self.in_lens):
+            rc = self.lib.mh_ntt_len(self.curve, self.data.ctypes.data, in_len, lg, 1 if inverse else 0)
             assert rc == 0
         t1 = time.perf_counter()
         if self.batched:
@@ -241,13 +244,16 @@ def seam_route_measure(M, log_n, bases, steps=2, batched=True):
     for _ in range(steps):
         sr.step()
     H = 1 << log_n
-    ntt_bytes = sum(64 << lg for lg, _, _ in sr.ntts)                  # each transform crosses PCIe both ways
+    ntt_bytes = sum((32 << lg) + 32 * l for (lg, _, _), l in zip(sr.ntts, sr.in_lens))   # the caller's elements up, the whole domain down
     msm_bytes = sum(32 * n for n, _ in sr.msms)                        # scalars only: the bases are resident
     return {"ms_per_proof": round((sr.ntt_s + sr.msm_s) * 1e3 / steps, 2), "ntt_ms": round(sr.ntt_s * 1e3 / steps, 2),
             "msm_ms": round(sr.msm_s * 1e3 / steps, 2), "steps": steps,
             "msm_calls": "one mh_msm_batch per PC::commit / opening point (5 calls)" if batched else "15 separate mh_msm calls",
             "pcie_bytes_per_proof": ntt_bytes + msm_bytes,
-            "what": "seam route lower bound: the reference's 30 transforms through mh_ntt and 15 MSMs through mh_msm_batch / mh_msm with "
+            "pcie_floor_ms": round((ntt_bytes + msm_bytes) / 57e9 * 1e3, 1),
+            "pcie_floor_note": "every byte of a transform crosses PCIe before (in) or after (out) its kernels and the calls are synchronous, "
+                               "so bytes / ~57 GB/s (one direction at a time) bounds the route from below, whatever the kernels cost",
+            "what": "seam route lower bound: the reference's 30 transforms through mh_ntt_len and 15 MSMs through mh_msm_batch / mh_msm with "
                     "HOST pointers (pageable, like Vec<Fr>), SRS + window table resident; the Rust host work between the "
                     "calls is not included.  Compare with ms_per_step of the device-resident prover (mh_marlin_prove_dev)",
             "constraints_per_s": round(H / ((sr.ntt_s + sr.msm_s) / steps), 1)}

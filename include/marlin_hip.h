@@ -76,6 +76,12 @@ int mh_memset(void* dst_dev, int byte, size_t bytes);
  * also multiplies by n^-1.  log_n in [0, 32] (bounded by device memory). */
 int mh_ntt(int field, uint64_t* data_mont, uint32_t log_n, int inverse);
 int mh_ntt_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse);
+/* mh_ntt for a vector that is SHORTER than the domain: ark-poly's fft_in_place / ifft_in_place first `resize(self.size(), zero)`
+ * the caller's Vec and then transform it [ark-poly 0.3 radix2/mod.rs], and most forward transforms of the prover are of that kind
+ * (a polynomial of H + 1 coefficients evaluated on the 4H domain, src/ahp/prover.rs:467,532-535; `const * v_H` products, :352).
+ * data_mont has room for 2^log_n elements, only the first in_len are read -- and only those cross PCIe on the way in; the
+ * rest of the domain counts as zero.  All 2^log_n results are written back.  in_len = 2^log_n is mh_ntt. */
+int mh_ntt_len(int field, uint64_t* data_mont, size_t in_len, uint32_t log_n, int inverse);
 /* Coset transforms: ark_poly Radix2EvaluationDomain::{coset_fft_in_place, coset_ifft_in_place} [ark-poly 0.3]:
  *   forward: data[i] *= g^i, then the NTT  (evaluations of the polynomial on the coset g H);
  *   inverse: the inverse NTT (with n^-1), then data[i] *= g^-i,

@@ -31,6 +31,7 @@ SYMBOLS = {
     "mh_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mh_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "mh_ntt": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_int]),
+    "mh_ntt_len": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int]),
     "mh_ntt_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_ntt_coset": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_ntt_coset_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),

@@ -461,7 +461,7 @@ struct FbRun {
     if (tile < 2048) tile = 2048;
     if (tile > F::MAX_TILE) tile = F::MAX_TILE;
     max_tiles_total = ent / tile + WT + 1;
-    MH_TRY(ws.dig.ensure(ent * 4)); MH_TRY(ws.val.ensure(ent * 4)); MH_TRY(ws.sorted.ensure(ent * 4));
+    MH_TRY(ws.dig.ensure(ent * 2 + 16)); MH_TRY(ws.val.ensure(ent * 4)); MH_TRY(ws.sorted.ensure(ent * 4));
     MH_TRY(ws.pc.ensure(pco * 4)); MH_TRY(ws.ptot.ensure((size_t)WT * 8)); MH_TRY(ws.desc.ensure((size_t)WT * sizeof(msmfb::FbWin)));
     MH_TRY(ws.blk.ensure(8 * max_tiles_total * sizeof(F::FbBlk)));
     MH_TRY(ws.bh.ensure(max_tiles_total * nb * 4));
@@ -503,16 +503,31 @@ struct FbRun {
   int sort(hipStream_t s) {
     namespace F = msmfb;
     ProfScope ps(c, PF_MSM_STAGES, s);
-    u32* key = (u32*)ws.dig.ptr; u32* val = (u32*)ws.val.ptr;
+    unsigned short* key = (unsigned short*)ws.dig.ptr; u32* val = (u32*)ws.val.ptr;
     u32* d_ptot = (u32*)ws.ptot.ptr; u32* d_pstart = d_ptot + WT;
     hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)ws.pc.ptr, W, win, is_mont, nparts, pshift, S, own);
     hipLaunchKernelGGL(F::pscan_kernel, dim3(nparts, nj), dim3(1024), 0, s, jobs, (u32*)ws.pc.ptr, d_ptot, nparts);
     hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
+    // The partition totals are final once pscan has run, BEFORE the split kernel: they go to the host on the copy stream while
+    // the split runs on `s`, so the host's round trip (descriptors, block list) hides behind a kernel instead of idling the GPU
+    // (one of the two host synchronisations per MSM batch; the other one carries the results).  MH_FB_PTOT_OVERLAP=0: the copy
+    // queued behind the split on `s`, as before.
+    static const bool ptot_overlap = [] { const char* e = getenv("MH_FB_PTOT_OVERLAP"); return !(e && atoi(e) == 0); }();
+    MH_TRY(ws.h_ptot.ensure((size_t)WT * 4));
+    const bool side_copy = ptot_overlap && c.copy_stream && c.copy_ev;
+    if (side_copy) {
+      MH_HIP(hipEventRecord(c.copy_ev, s));
+      MH_HIP(hipStreamWaitEvent(c.copy_stream, c.copy_ev, 0));
+      MH_HIP(hipMemcpyAsync(ws.h_ptot.ptr, ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, c.copy_stream));
+    }
     hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)ws.pc.ptr,
                        (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S, own);
-    MH_TRY(ws.h_ptot.ensure((size_t)WT * 4));
-    MH_HIP(hipMemcpyAsync(ws.h_ptot.ptr, ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    if (side_copy) {
+      MH_HIP(hipStreamSynchronize(c.copy_stream));
+    } else {
+      MH_HIP(hipMemcpyAsync(ws.h_ptot.ptr, ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
+      MH_HIP(hipStreamSynchronize(s));
+    }
     memcpy(ptot.data(), ws.h_ptot.ptr, (size_t)WT * 4);
     // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count.  The XCD of
     // a window is its rank among the windows that HAVE entries, mod 8: with the MSM sharded over G ranks a rank owns the
@@ -556,7 +571,7 @@ struct FbRun {
     const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;
     const size_t lds = (size_t)nb * 4;
     if (grid_tiles) {
-      hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), lds, s, fbw, dblk, (const u32*)key,
+      hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), lds, s, fbw, dblk, (const unsigned short*)key,
                          (u32*)ws.bh.ptr, nb, (u32)tile);
     }
     hipLaunchKernelGGL(F::colscan_kernel, dim3((nb + 255) / 256, WT), dim3(256), 0, s, fbw, (u32*)ws.bh.ptr, (u32*)ws.tot.ptr, nb);
@@ -569,7 +584,7 @@ struct FbRun {
         MH_HIP(hipMemcpyAsync((u32*)ws.base.ptr + (size_t)k * nbt, (const u32*)ws.base.ptr + (size_t)alias[k] * nbt, (size_t)nbt * 4, hipMemcpyDeviceToDevice, s));
       }
     if (grid_tiles) {
-      hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::scatter_lds_bytes(nb), s, fbw, dblk, (const u32*)key,
+      hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::scatter_lds_bytes(nb), s, fbw, dblk, (const unsigned short*)key,
                          (const u32*)val, (const u32*)ws.bh.ptr, (const u32*)ws.base.ptr, (u32*)ws.sorted.ptr, nb, (u32)tile);
     }
     // buckets ordered by size, largest first (before the skew decision comes back: a few tens of microseconds, wasted
@@ -1183,6 +1198,8 @@ int mh_init(int device_id) {
   c.own_stream = true;
   MH_HIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
   for (auto& e : c.fb_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  MH_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+  MH_HIP(hipEventCreateWithFlags(&c.copy_ev, hipEventDisableTiming));
   c.device = device_id;
   c.num_simds = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
   c.inited = true;
@@ -1220,6 +1237,8 @@ int mh_shutdown(void) {
   c.ntt_dist_buf[0].release(); c.ntt_dist_buf[1].release(); c.sl_send.release(); c.sl_recv.release();
   if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
   for (auto& e : c.fb_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (c.copy_stream) { (void)hipStreamSynchronize(c.copy_stream); (void)hipStreamDestroy(c.copy_stream); c.copy_stream = nullptr; }
+  if (c.copy_ev) { (void)hipEventDestroy(c.copy_ev); c.copy_ev = nullptr; }
   if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }
   for (auto& r : c.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   c.prof.clear();
@@ -1317,18 +1336,24 @@ int mh_ntt_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inv
   return ntt_device(c, d_in, d_out, log_n, inverse);
 }
 
-int mh_ntt(int field, uint64_t* data, uint32_t log_n, int inverse) {
+int mh_ntt_len(int field, uint64_t* data, size_t in_len, uint32_t log_n, int inverse) {
   LOCKED_CTX();
   if (field != hostff::CURVE_ID) return fail(MH_EINVAL, "mh_ntt: unsupported field");
   if (!data) return fail(MH_EINVAL, "mh_ntt: null pointer");
   if (log_n > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "log_n exceeds the two-adicity of Fr");
+  if (in_len > ((size_t)1 << log_n)) return fail(MH_EINVAL, "mh_ntt_len: in_len exceeds the domain");
   size_t bytes = (size_t)32 << log_n;
   MH_TRY(c.io.ensure(bytes));
-  MH_HIP(hipMemcpyAsync(c.io.ptr, data, bytes, hipMemcpyHostToDevice, c.stream));
-  MH_TRY(ntt_device(c, c.io.ptr, c.io.ptr, log_n, inverse));
+  // only the caller's coefficients go up; the transform reads the rest of the domain as zero (ntt_device_len)
+  if (in_len) MH_HIP(hipMemcpyAsync(c.io.ptr, data, in_len * 32, hipMemcpyHostToDevice, c.stream));
+  MH_TRY(ntt_device_len(c, c.io.ptr, in_len, c.io.ptr, log_n, inverse));
   MH_HIP(hipMemcpyAsync(data, c.io.ptr, bytes, hipMemcpyDeviceToHost, c.stream));
   MH_HIP(hipStreamSynchronize(c.stream));
   return MH_OK;
+}
+int mh_ntt(int field, uint64_t* data, uint32_t log_n, int inverse) {
+  if (log_n > hostff::FR_TWO_ADICITY_H) return fail(MH_EINVAL, "log_n exceeds the two-adicity of Fr");
+  return mh_ntt_len(field, data, (size_t)1 << log_n, log_n, inverse);
 }
 
 int mh_ntt_coset_dev(int field, const void* d_in, void* d_out, uint32_t log_n, int inverse) {

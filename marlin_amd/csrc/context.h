@@ -123,6 +123,10 @@ struct Context {
   } fbws[2];
   hipStream_t stream2 = nullptr;     // library-owned side stream of the fixed-base pipeline
   hipEvent_t fb_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // a library-owned stream for small device-to-host copies that must not wait behind the kernels queued on `stream` (the partition
+  // totals of the fixed-base sort travel to the host while the split kernel runs), and the event that orders it
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_ev = nullptr;
   uint64_t n_fb_groups = 0, n_vb_groups = 0;  // job groups that ran on the fixed-base / variable-base path
   Scratch tr_off[3], tr_cnt[2], tr_p[2], tr_sums, tr_ob, tr_pre, tr_prod, tr_scr;   // pair-tree accumulation
 

@@ -29,6 +29,9 @@
 namespace msmfb {
 using msm::Windows;
 
+// An entry between the two sort levels is a 16-bit key (its bucket inside the virtual window) and a 32-bit value (table index,
+// sign of the digit in bit 31): 6 bytes written by split, 2 read by hist, 6 by scatter -- the stages run at HBM / LDS-atomic
+// speed, so bytes are time (32-bit keys with the sign in the key: 8 / 4 / 8).
 // Virtual window: a variable-length run of the entry arrays holding the entries of 2^PART_BITS consecutive buckets
 // delta: added to every table index of the window's entries -- 0 except for a job that SHARES the sorted lists of another
 // job with the same scalars and a base range `delta` points further into the same base set (MarlinKZG10 commits a
@@ -73,7 +76,7 @@ constexpr int TILE_EPT = 16;           // scatter: entries per thread -> tiles o
 constexpr int MAX_TILE = TILE_EPT * SORT_THREADS;
 // scalars per count/split block for W windows
 inline u32 split_scalars(u32 W) { u32 sc = (SPLIT_ENTRIES / W) & ~63u; return sc > 1024 ? 1024 : sc; }
-inline size_t split_lds_bytes(u32 W) { return (size_t)(2 * MAX_PARTS + 32) * 4 + (size_t)split_scalars(W) * W * 9 + 16; }
+inline size_t split_lds_bytes(u32 W) { return (size_t)(2 * MAX_PARTS + 32) * 4 + (size_t)split_scalars(W) * W * 7 + 16; }
 inline size_t scatter_lds_bytes(u32 nb) { return (size_t)(2 * nb + 32) * 4 + (size_t)MAX_TILE * 6; }
 
 // exclusive scan of a[0, n) in LDS for n <= 2 * blockDim.x (blockDim.x a multiple of 64); tmp: 32 words of LDS
@@ -247,16 +250,16 @@ __global__ __launch_bounds__(MAX_PARTS) void pstart_kernel(const u32* __restrict
 // One block = S scalars (the same S as count_kernel): digits -> LDS counters -> local offsets -> entries placed in
 // LDS grouped by partition -> copied out, consecutive lanes to consecutive addresses of each partition's run.
 __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const u32* __restrict__ pc, const u32* __restrict__ ptot,
-                                                             const u32* __restrict__ pstart, u32* __restrict__ key,
+                                                             const u32* __restrict__ pstart, unsigned short* __restrict__ key,
                                                              u32* __restrict__ val, u32 W, Windows win, int is_mont, u32 nparts,
                                                              u32 pshift, u32 tab_n, u32 S, Own own) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* cur = lds;                                  // [MAX_PARTS] counts -> local starts -> cursors
   u32* gdst = lds + MAX_PARTS;                     // [MAX_PARTS] global position of local entry 0 of each partition
   u32* tmp = lds + 2 * MAX_PARTS;                  // [32]
-  u32* skey = lds + 2 * MAX_PARTS + 32;            // [S * W]
-  u32* sval = skey + S * W;
-  unsigned char* spart = (unsigned char*)(sval + S * W);
+  u32* sval = lds + 2 * MAX_PARTS + 32;            // [S * W] table index | sign << 31
+  unsigned short* skey = (unsigned short*)(sval + S * W);   // [S * W] bucket inside the virtual window (< 2^PART_BITS)
+  unsigned char* spart = (unsigned char*)(skey + S * W);
   const u32 job = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   if (blk >= jobs.nblk[job]) return;
   // this block's entries per partition = difference of consecutive entries of the scanned per-block counts
@@ -289,15 +292,15 @@ __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const 
         const u32 v = b >> pshift;
         if (!owns(own, v)) return;                  // another rank's partition
         const u32 p = atomicAdd(&cur[v], 1u);
-        skey[p] = ((b & ((1u << pshift) - 1)) + 1) | (e & 0x80000000u);
-        sval[p] = w * tab_n + t0;
+        skey[p] = (unsigned short)(b & ((1u << pshift) - 1));
+        sval[p] = (w * tab_n + t0) | (e & 0x80000000u);          // table indices stay below 2^31 (mh_bases_precompute checks)
         spart[p] = (unsigned char)v;
       }
     });
   }
   __syncthreads();
   const u32 total = cur[MAX_PARTS - 1];             // cursor of the last partition = number of entries of the block
-  u32* kj = key + jobs.ent_off[job];
+  unsigned short* kj = key + jobs.ent_off[job];
   u32* vj = val + jobs.ent_off[job];
   for (u32 idx = t; idx < total; idx += SORT_THREADS) {
     const u32 d = gdst[spart[idx]] + idx;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const 
 struct FbBlk { u32 gw, tile; };
 
 __global__ __launch_bounds__(SORT_THREADS) void hist_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk,
-                                                                 const u32* __restrict__ key, u32* __restrict__ bh, u32 nb, u32 tile) {
+                                                                 const unsigned short* __restrict__ key, u32* __restrict__ bh, u32 nb, u32 tile) {
   extern __shared__ __attribute__((aligned(16))) u32 h[];
   const u32 gw = blk[blockIdx.x].gw, tb = blk[blockIdx.x].tile;
   if (gw == 0xffffffffu) return;
@@ -322,8 +325,8 @@ __global__ __launch_bounds__(SORT_THREADS) void hist_kernel(const FbWin* __restr
   __syncthreads();
   const u32 lo = tb * tile;
   u32 hi = lo + tile; if (hi > d.cnt) hi = d.cnt;
-  const u32* k = key + d.off;
-  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[(k[i] & 0x7fffffffu) - 1], 1u);
+  const unsigned short* k = key + d.off;
+  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[k[i]], 1u);
   __syncthreads();
   u32* out = bh + d.bh_off + (u64)tb * nb;
   for (u32 b = threadIdx.x; b < nb; b += blockDim.x) out[b] = h[b];
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void colscan_kernel(const FbWin* __restrict__ 
 // a scan, entries placed in LDS in bucket order, then copied out (global position = where the tile's share of the
 // bucket starts + offset inside the tile's share).
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk,
-                                                               const u32* __restrict__ key, const u32* __restrict__ val,
+                                                               const unsigned short* __restrict__ key, const u32* __restrict__ val,
                                                                const u32* __restrict__ bh, const u32* __restrict__ base,
                                                                u32* __restrict__ sorted, u32 nb, u32 tile) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -365,16 +368,15 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __re
   __syncthreads();
   const u32 lo = tb * tile;
   const u32 cnt = d.cnt - lo < tile ? d.cnt - lo : tile;
-  const u32* k = key + d.off + lo;
+  const unsigned short* k = key + d.off + lo;
   const u32* v = val + d.off + lo;
   u32 rk[TILE_EPT], ev[TILE_EPT], bk[TILE_EPT];
 #pragma unroll
   for (int j = 0; j < TILE_EPT; j++) {
     const u32 i = j * SORT_THREADS + t;
     if (i < cnt) {
-      const u32 e = k[i];
-      bk[j] = (e & 0x7fffffffu) - 1;
-      ev[j] = v[i] | (e & 0x80000000u);
+      bk[j] = k[i];
+      ev[j] = v[i];
       rk[j] = atomicAdd(&lcnt[bk[j]], 1u);
     }
   }

@@ -135,12 +135,16 @@ def enable_native_rccl(dist=None, sliced=True):
     makes a communicator of one rank (tests on a one-GPU box).  Every rank first probes that it can reach librccl at all and the
     ranks agree on the outcome before anyone enters the collective ncclCommInitRank, so a box without RCCL makes this return
     False everywhere instead of hanging.  Returns True when the native transport is active on every rank."""
-    import torch
+    # torch is touched only when a process group is handed in: a process that has loaded libmarlin_hip.so WITHOUT torch runs on
+    # /opt/rocm's HIP runtime, and importing torch afterwards would map torch's bundled copy of libamdhip64 / libhsa-runtime64 /
+    # librccl next to it (its libraries ask for "libamdhip64.so", not the SONAME) -- two HIP runtimes in one process, the second of
+    # which finds no device.  A torch process imports torch FIRST (bench.py, the tests); then libmarlin_hip.so binds to torch's copy.
     lib = _lib.load()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     ident = np.zeros(128, dtype=np.uint8)
     ok = lib.mh_rccl_unique_id(ident.ctypes.data) == 0            # every rank draws one (the probe); rank 0's is the one used
     if dist is not None and world > 1:
+        import torch
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)

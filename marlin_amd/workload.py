@@ -33,6 +33,26 @@ def ntt_inventory(H, K=None, X=2):
     return inv
 
 
+def ntt_input_lengths(H, K=None, X=2):
+    """For each transform of ntt_inventory, how many elements the caller's Vec holds when it reaches ark-poly's `fft_in_place` /
+    `ifft_in_place` -- BEFORE their `resize(self.size(), zero)` -- i.e. what the seam has to upload (mh_ntt_len):
+    `DensePolynomial * DensePolynomial` evaluates both factors on np2(len_a + len_b - 1) points (prover.rs:352,360,366: a constant
+    times v_H of H + 1 coefficients; :467 z_a z_b, H + 1 each; :685 b f, K each), `evaluate_over_domain_by_ref` the q_1 factors
+    on 4H points (:532-535: r_alpha H, summed_z_m 2H + 1, z H + 1, t H); inverse transforms arrive full."""
+    K = 4 * H if K is None else K
+    L = [X, X]
+    for _ in range(3):
+        L += [H, 1, H + 1, 2 * H]
+    L += [H + 1, H + 1, 4 * H]
+    L += [H, H, X]
+    L += [H, 2 * H + 1, H + 1, H, 4 * H]
+    L += [K, K]
+    L += [K, K, 2 * K]
+    inv = ntt_inventory(H, K, X)
+    assert len(L) == len(inv) and all(l <= (1 << lg) for l, (lg, _, _) in zip(L, inv))
+    return L
+
+
 def ntt_executed(H, K=None, X=2):
     """[(log2 size, inverse?, what)]: the transforms mh_marlin_prove actually runs for the same proof (16 of the 30).
     Not executed, with identical outputs: the nine 2H transforms behind `const * v_H` (the product is known in closed

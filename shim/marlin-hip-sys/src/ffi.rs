@@ -76,6 +76,7 @@ extern "C" {
     // ---- NTT over Fr (seam B2)
     pub fn mh_ntt(field: c_int, data_mont: *mut u64, log_n: u32, inverse: c_int) -> c_int;
     pub fn mh_ntt_dev(field: c_int, d_in: *const c_void, d_out: *mut c_void, log_n: u32, inverse: c_int) -> c_int;
+    pub fn mh_ntt_len(field: c_int, data_mont: *mut u64, in_len: usize, log_n: u32, inverse: c_int) -> c_int;
     pub fn mh_ntt_coset(field: c_int, data_mont: *mut u64, log_n: u32, inverse: c_int) -> c_int;
     pub fn mh_ntt_coset_dev(field: c_int, d_in: *const c_void, d_out: *mut c_void, log_n: u32, inverse: c_int) -> c_int;
 

@@ -30,7 +30,10 @@ pub enum Kind {
 /// Returns `true` when the transform was done on the device (the caller then skips its own butterflies).
 /// `T` is ark-poly's `DomainCoeff<F>`; only `T = F = ark_bls12_381::Fr` is accelerated (group-element coefficient
 /// vectors, which `DomainCoeff` also admits, keep the host path).
-pub fn fft_in_place_hook<T: 'static>(coeffs: &mut [T], log_size_of_group: u32, kind: Kind) -> bool {
+/// `in_len`: how many elements the caller's `Vec` held BEFORE ark-poly padded it to the domain size (`coeffs.resize(self.size(),
+/// T::zero())` at the top of `fft_in_place`): only those are uploaded (`mh_ntt_len`); most forward transforms of Marlin's prover
+/// are of polynomials much shorter than their domain (H + 1 coefficients on 4H points).
+pub fn fft_in_place_hook<T: 'static>(coeffs: &mut [T], in_len: usize, log_size_of_group: u32, kind: Kind) -> bool {
     if TypeId::of::<T>() != TypeId::of::<Fr>() || log_size_of_group < GPU_NTT_THRESHOLD_LOG {
         return false;
     }
@@ -49,7 +52,7 @@ pub fn fft_in_place_hook<T: 'static>(coeffs: &mut [T], log_size_of_group: u32, k
         if coset {
             ffi::mh_ntt_coset(ffi::MH_FIELD_BLS12_381_FR, limbs.as_mut_ptr(), log_size_of_group, inverse)
         } else {
-            ffi::mh_ntt(ffi::MH_FIELD_BLS12_381_FR, limbs.as_mut_ptr(), log_size_of_group, inverse)
+            ffi::mh_ntt_len(ffi::MH_FIELD_BLS12_381_FR, limbs.as_mut_ptr(), in_len.min(1usize << log_size_of_group), log_size_of_group, inverse)
         }
     };
     if check(rc).is_err() {

@@ -8,7 +8,7 @@ fn every_header_symbol_links() {
         mh_curve_info as usize, mh_init as usize, mh_init_devices as usize, mh_shutdown as usize, mh_last_error as usize,
         mh_set_stream as usize, mh_synchronize as usize, mh_device_info as usize, mh_alloc as usize, mh_free as usize,
         mh_memcpy_h2d as usize, mh_memcpy_d2h as usize, mh_memcpy_d2d as usize, mh_memset as usize, mh_ntt as usize,
-        mh_ntt_dev as usize, mh_ntt_coset as usize, mh_ntt_coset_dev as usize, mh_bases_upload as usize,
+        mh_ntt_dev as usize, mh_ntt_len as usize, mh_ntt_coset as usize, mh_ntt_coset_dev as usize, mh_bases_upload as usize,
         mh_bases_from_dev as usize, mh_bases_upload_serialized as usize, mh_srs_powers as usize, mh_bases_download as usize, mh_bases_free as usize,
         mh_bases_len as usize, mh_bases_precompute as usize, mh_bases_table_info as usize, mh_msm_path_counts as usize,
         mh_msm as usize, mh_msm_dev as usize, mh_msm_batch_dev as usize, mh_msm_batch as usize, mh_msm_batch_sharded_dev as usize, mh_g1_to_affine as usize, mh_g1_sum as usize,

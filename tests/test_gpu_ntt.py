@@ -116,3 +116,25 @@ def test_coset_ntt_large_round_trip_and_spot(gpu):
     for e, i in zip(ev, [0, 1, 777, n - 1]):
         pt = F.FR_GENERATOR * pow(w, i, F.R_MOD) % F.R_MOD
         assert e == sum(c * pow(pt, k, F.R_MOD) for c, k in zip(coeffs, idx)) % F.R_MOD
+
+
+@pytest.mark.parametrize("log_n,in_len", [(10, 1), (10, 0), (12, 1025), (12, 4096), (14, 4097), (16, 3 * (1 << 14) + 1)])
+def test_ntt_len_equals_the_padded_transform(gpu, log_n, in_len):
+    """mh_ntt_len (the seam for ark-poly's fft_in_place, which first zero-pads the caller's Vec to the domain): uploading only
+    the in_len coefficients gives the transform of the padded vector, forward and inverse; what lies beyond in_len in the
+    caller's buffer is not read."""
+    import ctypes as C
+    from marlin_amd import _lib
+    lib = _lib.load()
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n * 7919 + in_len)
+    x = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    x[:, 3] &= np.uint64((1 << 59) - 1)
+    padded = x.copy()
+    padded[in_len:] = 0
+    for inverse in (0, 1):
+        want = gpu.ntt(padded) if not inverse else gpu.intt(padded)
+        buf = x.copy()                      # garbage beyond in_len: must not matter
+        _lib.check(lib.mh_ntt_len(_lib.CURVE_ID, buf.ctypes.data, in_len, log_n, inverse), "mh_ntt_len")
+        assert np.array_equal(buf, want)
+    assert lib.mh_ntt_len(_lib.CURVE_ID, x.ctypes.data, n + 1, log_n, 0) != 0          # in_len beyond the domain is refused

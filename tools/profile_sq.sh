@@ -12,7 +12,10 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"
-timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+# SQ_COUNTERS overrides the 8 SQ slots; the default set is the wave-cycle breakdown of MI355X_MICROARCH.md (rocprofv3 PMC slots):
+# WAIT_ANY (wave parked: s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES, all in quad-cycles
+SQ_COUNTERS=${SQ_COUNTERS:-"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES"}
+timeout 900 rocprofv3 --pmc $SQ_COUNTERS GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD1 > $OUT/pmc_sq.log 2>&1
 find $OUT/pmc_sq -name "*counter_collection.csv" -exec cp {} $OUT/pmc_sq.csv \;
 cd $REPO
@@ -46,6 +49,14 @@ def summarise(ds):
         s["valu_issue_cycles_per_wave_instr"] = round(4 * tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_INSTS_VALU"], 3)
     if tot.get("SQ_ACTIVE_INST_VALU") and tot.get("SQ_BUSY_CYCLES"):
         s["valu_active_over_busy"] = round(tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_BUSY_CYCLES"], 4)
+    if tot.get("SQ_WAVE_CYCLES"):
+        wc = tot["SQ_WAVE_CYCLES"]
+        s["wave_cycle_breakdown"] = {k: round(tot[c] / wc, 4) for k, c in (("parked_waitcnt_or_barrier", "SQ_WAIT_ANY"),
+                                     ("issue_stalled", "SQ_WAIT_INST_ANY"), ("issuing_any", "SQ_ACTIVE_INST_ANY"),
+                                     ("issuing_valu", "SQ_ACTIVE_INST_VALU")) if c in tot}
+        s["wave_cycle_breakdown"]["unaccounted"] = round(1.0 - sum(tot.get(c, 0) for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")) / wc, 4)
+    if tot.get("SQ_WAVE_CYCLES") and tot.get("SQ_BUSY_CYCLES"):
+        s["resident_waves_per_busy_simd_cycle"] = round(tot["SQ_WAVE_CYCLES"] / tot["SQ_BUSY_CYCLES"], 3)
     return s
 res = {"kernel": "msmfb::accum30_kernel", "all_dispatches": summarise(acc), "prove_only_last4": summarise(acc[-4:]),
        "per_dispatch": [dict(rows[d], dispatch=d, ms=dur.get(d)) for d in acc],
