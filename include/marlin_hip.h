@@ -207,6 +207,22 @@ int mh_marlin_zk_draw_count(uint64_t pk, size_t* n_out);
 int mh_marlin_prove_draws(uint64_t pk, const uint64_t* instance_mont, const uint64_t* witness_mont, const uint64_t* zk_draws_mont,
                           size_t n_draws, uint8_t* proof_out, size_t cap, size_t* len_out);
 
+/* Marlin<F, PC, FS> is generic over `FS: FiatShamirRng` (src/lib.rs:64-70; the trait -- RngCore + initialize + absorb -- is
+ * src/rng.rs:54-62).  The entry points above run the reference's own instantiation SimpleHashFiatShamirRng<Blake2s, ChaChaRng>
+ * (src/test.rs:128-130) inside the library; these take the caller's FS as three callbacks and route every transcript operation
+ * of prove / verify to them: initialize(b"MARLIN-2019" || vk || public input) (src/lib.rs:161-163), absorb(round commitments,
+ * then the evaluations) (:180,:201,:221,:289), and next_u64 under `F::rand(fs_rng)` -- four words per attempt, top bits shaved,
+ * rejected when >= r, like Fp256::rand -- and `u128::rand(fs_rng)` (two words, low first).  Callbacks run on the calling thread,
+ * between device batches; they must not call back into this library. */
+typedef struct {
+  void* user;
+  void (*initialize)(void* user, const uint8_t* input, size_t len);
+  void (*absorb)(void* user, const uint8_t* input, size_t len);
+  uint64_t (*next_u64)(void* user);
+} mh_fiat_shamir;
+int mh_marlin_prove_fs(uint64_t pk, const uint64_t* instance_mont, const uint64_t* witness_mont, const uint8_t* zk_seed32,
+                       int zk_chacha_rounds, const mh_fiat_shamir* fs, uint8_t* proof_out, size_t cap, size_t* len_out);
+
 /* Wire format (host only, no device needed): the flat ToBytes-layout proof of mh_marlin_prove <-> the bytes of
  * ark-serialize's `CanonicalSerialize for Proof<Fr, PC>` (src/data_structures.rs:100-110; ProverMsg as Option<Vec<F>>,
  * src/ahp/prover.rs:84-99): compressed G1 (x with the y-sign / infinity flags in the top two bits of the last byte), u64
@@ -233,6 +249,9 @@ typedef struct {
 } mh_verifier_key;
 int mh_marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, int pc, const uint64_t* public_input_mont,
                      size_t n_public, const uint8_t* flat_proof, size_t proof_len, int* ok_out);
+/* the same with the caller's FS (see mh_marlin_prove_fs) */
+int mh_marlin_verify_fs(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, int pc, const uint64_t* public_input_mont,
+                        size_t n_public, const uint8_t* flat_proof, size_t proof_len, const mh_fiat_shamir* fs, int* ok_out);
 /* prod_i e(P_i, Q_i) == 1 (ark_ec PairingEngine::product_of_pairings followed by the comparison), host only;
  * n affine G1 points (2 * fq_limbs64 limbs each) and n affine G2 points (4 * fq_limbs64 limbs each), none of them the
  * identity; G2 points are taken to be in the order-r subgroup. */

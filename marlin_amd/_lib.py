@@ -62,6 +62,10 @@ SYMBOLS = {
                                   C.POINTER(C.c_size_t)]),
     "mh_marlin_prove_dev": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_size_t)]),
+    "mh_marlin_prove_fs": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_size_t)]),
+    "mh_marlin_verify_fs": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p,
+                                      C.POINTER(C.c_int)]),
     "mh_marlin_zk_draw_count": (C.c_int, [C.c_uint64, C.POINTER(C.c_size_t)]),
     "mh_marlin_prove_draws": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.POINTER(C.c_size_t)]),

@@ -303,7 +303,8 @@ static int msm_set_attrs() {
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::reduce2_30_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::reduce2_30_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::reduce2_30_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   g_msm_attr_done = true;
   return MH_OK;
 }
@@ -599,7 +600,8 @@ struct FbRun {
     // by the host together with the results (finish): no host round trip between the sort and the accumulation.
     const u64 avg = ent / WB + 1;
     skew_limit = (u32)std::min<u64>(std::max<u64>(4096, 32 * avg), 0xffffffffull);
-    for (size_t st : strides) if (st != 1) skew_limit = 0xffffffffu;   // a strided slice has no variable-base fallback: the buckets are accumulated as they are
+    // (a strided slice has no variable-base fallback -- its bases are not a contiguous range --: msm_batch_strided_device turns a
+    // skewed batch into an error instead of letting one thread walk a list of millions)
     return MH_OK;
   }
 
@@ -651,15 +653,21 @@ struct FbRun {
   int reduce(hipStream_t s) {
     namespace F = msmfb;
     ProfScope ps(c, PF_MSM_STAGES, s);
+    // the group law with its independent multiplications as interleaved chains (msm_fb.cuh x30_add_ilp): one wave per SIMD
+    // issues ~1.4 x faster through the same chain of additions.  MH_FB_ILP=0: the one-chain group law.
+    static const bool ilp = [] { const char* e = getenv("MH_FB_ILP"); return !(e && atoi(e) == 0); }();
     F::G1Xyzz30* seg30 = (F::G1Xyzz30*)ws.seg.ptr;
     if (quad1)
       hipLaunchKernelGGL(F::reduce1_q_kernel, dim3((unsigned)(((u64)nj * nseg * 4 + 255) / 256)), dim3(256), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
-                         seg30, nbt, nseg, (u32)nj, seg, nb, own);
+                         seg30, nbt, nseg, (u32)nj, seg, nb, own, (const u32*)ws.sums.ptr, skew_limit);
+    else if (ilp)
+      hipLaunchKernelGGL(F::reduce1_30_kernel<true>, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
+                         seg30, nbt, nseg, (u32)nj, seg, nb, own, (const u32*)ws.sums.ptr, skew_limit);
     else
-      hipLaunchKernelGGL(F::reduce1_30_kernel, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
-                         seg30, nbt, nseg, (u32)nj, seg, nb, own);
+      hipLaunchKernelGGL(F::reduce1_30_kernel<false>, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
+                         seg30, nbt, nseg, (u32)nj, seg, nb, own, (const u32*)ws.sums.ptr, skew_limit);
     const size_t r2lds = (quad2 ? 64 : 256) * sizeof(F::G1Xyzz30);
-    auto r2 = quad2 ? F::reduce2_q_kernel : F::reduce2_30_kernel;
+    auto r2 = quad2 ? F::reduce2_q_kernel : (ilp ? F::reduce2_30_kernel<true> : F::reduce2_30_kernel<false>);
     if (chunks > 1) {
       F::G1Xyzz30* mid = seg30 + (size_t)nj * nseg;
       hipLaunchKernelGGL(r2, dim3(chunks, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, mid, (G1Xyzz*)nullptr, nseg, 0);
@@ -698,15 +706,15 @@ struct FbRun {
 // One group of <= MAX_JOBS jobs on the fixed-base path.  skewed = true (and nothing written) when a bucket is so overfull
 // that the caller should take the variable-base path with its pair-tree accumulation instead.
 //
-// The accumulate kernel is bound by VALU issue and takes 80 % of the group's time; the sort before it is bound by LDS and
-// HBM latency and the bucket reduction after it is a chain of dependent additions at one wave per SIMD.  So the group
-// runs as TWO sub-batches A, B (jobs that share sorted lists stay together) in a software pipeline over two streams:
+// DEFAULT: the whole group on the main stream, sort -> accumulate -> reduce.  OPT-IN (MH_FB_SPLIT=1), measured slower and kept
+// only as a switch (80.8 vs 78.1 ms per proof, profiles/r03a_*: the accumulate kernel fills every SIMD's registers, so a
+// second stream only ever runs in its tail): the group as TWO sub-batches A, B (jobs that share sorted lists stay together) in
+// a software pipeline over two streams --
 //     main stream :  sort(A)  accum(A)             accum(B)   reduce(B)
 //     side stream :                    sort(B)                reduce(A)
 // sort(B) fills the issue slots accum(A) leaves free and reduce(A) those of accum(B); only sort(A) and reduce(B) stay
 // exposed.  The split minimises the modelled makespan over all 2-partitions of the jobs (<= 2^8): the exposed sort wants
-// few entries in A, the exposed reduction few jobs in B (its cost is per bucket set, not per scalar).  MH_FB_SPLIT=0
-// keeps the whole group on the main stream.
+// few entries in A, the exposed reduction few jobs in B (its cost is per bucket set, not per scalar).
 static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* offs, const void* const* d_scalars, const size_t* ns,
                            int is_mont, HG1* out, bool& skewed, const int* shard, bool& partial, const size_t* strides = nullptr) {
   skewed = false;
@@ -1034,6 +1042,9 @@ int msm_batch_strided_device(Context& c, const BaseSet& bs, int njobs, const siz
     std::vector<HG1> res(nj);
     bool skewed = false, part = false;
     MH_TRY(msm_fb_pipeline(c, bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, nullptr, part, st.data()));
+    if (skewed)
+      return fail(MH_EINVAL, "strided MSM: one bucket holds more than max(4096, 32 x the average) entries (heavily repeated digits); gather the "
+                             "slice into a contiguous vector and use mh_msm_batch_dev, whose variable-base path handles skewed inputs");
     c.n_fb_groups++;
     for (int k = 0; k < nj; k++) {
       uint64_t* o = out_xyz + XYZ_L * live[g0 + k];

@@ -111,8 +111,8 @@ struct Context {
   std::map<uint64_t, G2Set> g2_bases;
   uint64_t next_handle = 1;
   Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win, msm_pend;
-  // fixed-base path (msm_fb.cuh): two workspaces, because a group of jobs runs as two sub-batches whose sort / bucket
-  // reduction overlap the other's accumulation on a second stream (capi.hip: msm_fb_pipeline)
+  // fixed-base path (msm_fb.cuh): two workspaces; the second one, stream2 and fb_ev serve only the opt-in two-stream pipeline
+  // (MH_FB_SPLIT=1, measured slower and off by default: capi.hip: msm_fb_pipeline)
   struct FbWs {
     Scratch dig, val, sorted, pc, ptot, desc, blk, bh, tot, base, pend, buckets, seg, win, sums, perm;
     Pinned h_ptot, h_desc, h_blk, h_out;      // host side of the partition totals, the descriptors, the block list, the results

@@ -140,6 +140,39 @@ __device__ __forceinline__ Fq30 f30_mul2(const Fq30& a, const Fq30& b, const Fq3
   return r;
 }
 
+// Two or three INDEPENDENT multiplications as interleaved dependency chains (gen_fq30.py `fused_multi`): for kernels that run one
+// wave per SIMD (the bucket reduction), where a single multiplication's chain of ~400 dependent instructions leaves the VALU idle
+// between issues.  Limb for limb the results of f30_mul / f30_sqr / f30_mul2 (mh_selftest_fq30).  Outputs may alias inputs.
+__device__ __forceinline__ void f30_mul_x2(Fq30& r0, const Fq30& a0, const Fq30& b0, Fq30& r1, const Fq30& a1, const Fq30& b1) {
+  Fq30 t0, t1;
+  F30_GEN(f30_multi_mul_mul)(t0.v, a0.v, b0.v, t1.v, a1.v, b1.v);
+  r0 = t0; r1 = t1;
+}
+__device__ __forceinline__ void f30_mul_x3(Fq30& r0, const Fq30& a0, const Fq30& b0, Fq30& r1, const Fq30& a1, const Fq30& b1,
+                                           Fq30& r2, const Fq30& a2, const Fq30& b2) {
+  Fq30 t0, t1, t2;
+  F30_GEN(f30_multi_mul_mul_mul)(t0.v, a0.v, b0.v, t1.v, a1.v, b1.v, t2.v, a2.v, b2.v);
+  r0 = t0; r1 = t1; r2 = t2;
+}
+__device__ __forceinline__ void f30_sqr_x2(Fq30& r0, const Fq30& a0, Fq30& r1, const Fq30& a1) {
+  Fq30 t0, t1;
+  F30_GEN(f30_multi_sqr_sqr)(t0.v, a0.v, t1.v, a1.v);
+  r0 = t0; r1 = t1;
+}
+// r0 = a0^2, r1 = a1 b1
+__device__ __forceinline__ void f30_sqr_mul(Fq30& r0, const Fq30& a0, Fq30& r1, const Fq30& a1, const Fq30& b1) {
+  Fq30 t0, t1;
+  F30_GEN(f30_multi_sqr_mul)(t0.v, a0.v, t1.v, a1.v, b1.v);
+  r0 = t0; r1 = t1;
+}
+// r0 = (a0 b0 + c0 d0) under one reduction, r1 = a1 b1
+__device__ __forceinline__ void f30_mul2_mul(Fq30& r0, const Fq30& a0, const Fq30& b0, const Fq30& c0, const Fq30& d0,
+                                             Fq30& r1, const Fq30& a1, const Fq30& b1) {
+  Fq30 t0, t1;
+  F30_GEN(f30_multi_mul2_mul)(t0.v, a0.v, b0.v, c0.v, d0.v, t1.v, a1.v, b1.v);
+  r0 = t0; r1 = t1;
+}
+
 // a + b (no reduction)
 __device__ __forceinline__ Fq30 f30_add(const Fq30& a, const Fq30& b) {
   Fq30 r;

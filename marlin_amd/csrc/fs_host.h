@@ -138,21 +138,42 @@ static inline void put_commitment(std::vector<uint8_t>& out, const Commitment& c
   else { hostff::HG1Affine e; e.inf = true; put_g1(out, e); }
 }
 
-// ---------------------------------------------------------------- SimpleHashFiatShamirRng
+// ---------------------------------------------------------------- SimpleHashFiatShamirRng, or the caller's FS
+// Marlin<F, PC, FS> is generic over `FS: FiatShamirRng` (/root/reference src/lib.rs:64-70; the trait, src/rng.rs:54-62, is
+// RngCore + initialize + absorb).  `ext` != nullptr routes the three operations the prover and the verifier use to the
+// caller's implementation (mh_marlin_prove_fs / mh_marlin_verify_fs); otherwise the reference's own instantiation
+// SimpleHashFiatShamirRng<Blake2s, ChaChaRng> (src/rng.rs:18-80, src/test.rs:128-130) runs here.
+struct ExternalFs {                       // field for field the C ABI's mh_fiat_shamir
+  void* user;
+  void (*initialize)(void* user, const uint8_t* input, size_t len);
+  void (*absorb)(void* user, const uint8_t* input, size_t len);
+  uint64_t (*next_u64)(void* user);
+};
 struct FiatShamirRng {
   uint8_t seed[32];
   ChaChaRng r;
-  void initialize(const std::vector<uint8_t>& input) { Blake2s::digest(input, seed); r = ChaChaRng(seed, 20); }
+  const ExternalFs* ext = nullptr;
+  struct ExtRng { const ExternalFs* e; uint64_t next_u64() { return e->next_u64(e->user); } };
+  void initialize(const std::vector<uint8_t>& input) {
+    if (ext) { ext->initialize(ext->user, input.data(), input.size()); return; }
+    Blake2s::digest(input, seed); r = ChaChaRng(seed, 20);
+  }
   void absorb(const std::vector<uint8_t>& input) {
+    if (ext) { ext->absorb(ext->user, input.data(), input.size()); return; }
     std::vector<uint8_t> b(input);
     b.insert(b.end(), seed, seed + 32);
     Blake2s::digest(b, seed);
     r = ChaChaRng(seed, 20);
   }
-  hostff::HFr rand_fr() { return fr_rand(r); }
+  hostff::HFr rand_fr() {
+    if (ext) { ExtRng x{ext}; return fr_rand(x); }
+    return fr_rand(r);
+  }
+  // u128::rand (rand 0.8 Standard: low word first) as a field element
   hostff::HFr rand_u128_as_fr() {
-    uint64_t c[4] = {r.next_u64(), 0, 0, 0};
-    c[1] = r.next_u64();
+    uint64_t c[4] = {0, 0, 0, 0};
+    if (ext) { c[0] = ext->next_u64(ext->user); c[1] = ext->next_u64(ext->user); }
+    else { c[0] = r.next_u64(); c[1] = r.next_u64(); }
     return hostff::HFr::from_canonical(c);
   }
 };

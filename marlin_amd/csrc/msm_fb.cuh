@@ -480,6 +480,56 @@ __device__ __noinline__ void x30_dbl(X30& a) {
   a.x = X3;
 }
 
+// ---- the same group law with its independent multiplications side by side (fq30.cuh f30_mul_x3 ...) -------------------
+// The bucket reduction runs ONE wave per SIMD through a chain of ~90 dependent group operations per thread: a latency chain, and
+// inside it every field multiplication is itself one chain of ~400 dependent instructions.  The addition's 14 multiplications
+// are not all dependent on each other: {U1, S1, ZZ1 ZZ2}, {U2, S2, ZZZ1 ZZZ2}, {P^2, R^2}, {Q, PPP, ZZ3}, {Y3, ZZZ3} -- five
+// steps of 2-3 interleaved chains instead of 14 single ones; the doubling's 10 become 4 steps.  Measured (profiles/r04e_*, r04f_*):
+// sort + reduce stages 11.85 -> 11.57 ms per proof at 2^20, nothing at 2^16 -- far less than the 1.4 x a latency-bound chain would
+// gain, so a lone wave is NOT waiting for its own v_mad_u64_u32 results: it issues an instruction every ~6 cycles whatever their
+// dependencies.  (CALLING the multi-chain operations instead of inlining them -- 50 KB of code instead of 100 KB, in case the
+// 64-KB instruction cache were the limit -- costs 3.3 ms per proof: the operands travel through scratch.)  Same values mod p (Y3 is taken
+// as ONE reduction of R (Q - X3) + (2p - S1) PPP, so its lazy representative differs from x30_add's: compared through the
+// canonical form by mh_selftest_fq30; bounds: X <= 6.2, Y <= 1.2, ZZ, ZZZ <= 1.1).
+__device__ __forceinline__ void x30_add_ilp_inl(X30& acc, const X30& b) {
+  if (x30_is_identity(b)) return;
+  if (x30_is_identity(acc)) { acc = b; return; }
+  Fq30 U1, S1, U2, S2, ZZ12, ZZZ12;
+  f30_mul_x3(U1, acc.x, b.zz, S1, acc.y, b.zzz, ZZ12, acc.zz, b.zz);
+  f30_mul_x3(U2, b.x, acc.zz, S2, b.y, acc.zzz, ZZZ12, acc.zzz, b.zzz);
+  const Fq30 P = f30_sub<2>(U2, U1);
+  if (__builtin_expect(f30_is_zero(P), 0)) { x30_add_slow(acc, b); return; }
+  const Fq30 R = f30_sub<2>(S2, S1);
+  Fq30 PP, RR;
+  f30_sqr_x2(PP, P, RR, R);
+  Fq30 Q, PPP;
+  f30_mul_x3(Q, U1, PP, PPP, P, PP, acc.zz, ZZ12, PP);
+  acc.x = f30_sub2<3>(f30_sub<2>(RR, PPP), Q);
+  Fq30 zero;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) zero.v[i] = 0;
+  // R <= 4 p, Q - X3 + 8p <= 10 p, (2p - S1) PPP <= 4 p^2: 44 p^2 < 64 p^2
+  f30_mul2_mul(acc.y, R, f30_sub<8>(Q, acc.x), f30_sub<2>(zero, S1), PPP, acc.zzz, ZZZ12, PPP);
+}
+__device__ __noinline__ void x30_add_ilp(X30& acc, const X30& b) { x30_add_ilp_inl(acc, b); }
+__device__ __noinline__ void x30_dbl_ilp(X30& a) {
+  if (x30_is_identity(a)) return;
+  const Fq30 U = f30_dbl(a.y);
+  Fq30 V, XX;
+  f30_sqr_x2(V, U, XX, a.x);
+  const Fq30 M = f30_add(f30_dbl(XX), XX);
+  Fq30 W, S, MM;
+  f30_mul_x3(W, U, V, S, a.x, V, a.zz, V, a.zz);
+  f30_sqr_mul(MM, M, a.zzz, W, a.zzz);
+  const Fq30 X3 = f30_sub2<3>(MM, S);
+  Fq30 zero;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) zero.v[i] = 0;
+  // M <= 3.7 p, S - X3 + 8p <= 10 p, (2p - W) Y <= 6.4 p^2: 44 p^2 < 64 p^2
+  a.y = f30_mul2(M, f30_sub<8>(S, X3), f30_sub<2>(zero, W), a.y);
+  a.x = X3;
+}
+
 // ---- bucket order: largest first -------------------------------------------------------------------------------
 // A wave of the accumulate kernel runs as long as its largest bucket.  msm::accum_kernel sorts bucket sizes inside each
 // block of 256; here all buckets of the launch are ordered by size with a counting sort (sizes are small integers), so
@@ -616,10 +666,13 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
 // (segment total) by double-and-add; the result goes to msm::reduce2_kernel in the standard representation.
 // nseg segments cover the buckets of the owned partitions (pbuckets = 2^pshift buckets each, seg divides pbuckets, so
 // a segment never straddles two partitions): local segment s lies in owned partition number (s * seg) / pbuckets
+template <bool ILP>
 __global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restrict__ buckets, G1Xyzz30* __restrict__ segsum, u32 nb,
-                                                        u32 nseg, u32 njobs, u32 seg, u32 pbuckets, Own own) {
+                                                        u32 nseg, u32 njobs, u32 seg, u32 pbuckets, Own own,
+                                                        const u32* __restrict__ largest, u32 skew_limit) {
   u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= njobs * nseg) return;
+  if (*largest > skew_limit) return;      // a skewed batch left this path in the accumulate kernel: the buckets hold nothing
   const u32 w = gid / nseg, s = gid % nseg;
   const u32 l = s * seg;                                          // index among the owned buckets
   const u32 lo = (own.first + (l / pbuckets) * own.stride) * pbuckets + l % pbuckets;
@@ -629,22 +682,17 @@ __global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restri
   static_assert(true, "");
   for (u32 b = hi; b-- > lo;) {
     X30 t = x30_load(B + b);
-#ifdef MH_REDUCE_INLINE
-    x30_add_inl(running, t);
-    x30_add_inl(acc, running);
-#else
-    x30_add(running, t);
-    x30_add(acc, running);
-#endif
+    if (ILP) { x30_add_ilp(running, t); x30_add_ilp(acc, running); }
+    else { x30_add(running, t); x30_add(acc, running); }
   }
   if (lo) {
     X30 m = x30_identity();
     const int top = 31 - __clz(lo);
     for (int bit = top; bit >= 0; bit--) {
-      x30_dbl(m);
-      if ((lo >> bit) & 1) x30_add(m, running);
+      if (ILP) x30_dbl_ilp(m); else x30_dbl(m);
+      if ((lo >> bit) & 1) { if (ILP) x30_add_ilp(m, running); else x30_add(m, running); }
     }
-    x30_add(acc, m);
+    if (ILP) x30_add_ilp(acc, m); else x30_add(acc, m);
   }
   x30_store(segsum + gid, acc);
 }
@@ -653,6 +701,7 @@ __global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restri
 // grid (chunks, jobs): block (k, w) sums elements [k * per, (k + 1) * per) of job w's nseg points.  last = 0: writes a
 // 30-bit point to out30[w * chunks + k] (first of two launches when nseg is large); last = 1: converts the sum to the
 // standard representation for the host (out_std[w * chunks + k]).
+template <bool ILP>
 __global__ __launch_bounds__(256) void reduce2_30_kernel(const G1Xyzz30* __restrict__ in, G1Xyzz30* __restrict__ out30,
                                                          G1Xyzz* __restrict__ out_std, u32 nseg, int last) {
   extern __shared__ __attribute__((aligned(16))) u32 lds30[];
@@ -664,7 +713,7 @@ __global__ __launch_bounds__(256) void reduce2_30_kernel(const G1Xyzz30* __restr
   X30 acc = x30_identity();
   for (u32 s = lo + threadIdx.x; s < hi; s += 256) {
     X30 t = x30_load(in + (u64)w * nseg + s);
-    x30_add(acc, t);
+    if (ILP) x30_add_ilp(acc, t); else x30_add(acc, t);
   }
   x30_store(sh + threadIdx.x, acc);
   __syncthreads();
@@ -672,7 +721,7 @@ __global__ __launch_bounds__(256) void reduce2_30_kernel(const G1Xyzz30* __restr
     if (threadIdx.x < off) {
       X30 a = x30_load(sh + threadIdx.x);
       X30 b = x30_load(sh + threadIdx.x + off);
-      x30_add(a, b);
+      if (ILP) x30_add_ilp(a, b); else x30_add(a, b);
       x30_store(sh + threadIdx.x, a);
     }
     __syncthreads();
@@ -709,6 +758,16 @@ __global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ 
     for (int k = 0; k < Fq30::NL; k++) ok = ok && w1.v[k] == w2.v[k] && w1.v[k] == w3.v[k] && q1.v[k] == q2.v[k] && q1.v[k] == q3.v[k];
     // two products under one reduction
     same(f30_to_fq(f30_mul2(a30, b30, wa, wb)), ff_add(ff_mul(a, b), ff_mul(f30_to_fq(wa), f30_to_fq(wb))));
+    // the interleaved chains against the single ones, limb for limb (reduced and lazily reduced operands, aliased outputs)
+    auto same30 = [&](const Fq30& x, const Fq30& y) { for (int k = 0; k < Fq30::NL; k++) ok = ok && x.v[k] == y.v[k]; };
+    Fq30 r0, r1, r2;
+    f30_mul_x2(r0, a30, b30, r1, wa, wb); same30(r0, c30); same30(r1, w1);
+    f30_mul_x3(r0, wa, wb, r1, a30, b30, r2, b30, wa); same30(r0, w1); same30(r1, c30); same30(r2, f30_mul(b30, wa));
+    f30_sqr_x2(r0, a30, r1, wa); same30(r0, sg); same30(r1, q1);
+    f30_sqr_mul(r0, wa, r1, a30, wb); same30(r0, q1); same30(r1, f30_mul(a30, wb));
+    f30_mul2_mul(r0, a30, b30, wa, wb, r1, wb, b30); same30(r0, f30_mul2(a30, b30, wa, wb)); same30(r1, f30_mul(wb, b30));
+    r0 = a30; r1 = b30;
+    f30_mul_x2(r0, r0, r1, r1, r1, r0); same30(r0, c30); same30(r1, c30);           // outputs alias inputs
   }
   same(f30_to_fq(f30_sub<2>(f30_add(c30, a30), a30)), ff_mul(a, b));
   same(f30_to_fq(f30_mul(f30_sub<2>(a30, b30), f30_add(a30, b30))), f30_to_fq(f30_sub<2>(f30_sqr(a30), f30_sqr(b30))));
@@ -734,6 +793,20 @@ __global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ 
     X30 e30 = p30; x30_add(e30, p30);
     G1Xyzz es = x30_to_std(e30);
     same(es.x, d.x); same(es.y, d.y); same(es.zz, d.zz); same(es.zzz, d.zzz);
+    // the group law with interleaved multiplications: doubling, addition, a chain of both (lazy bounds), equal x
+    X30 di = p30; x30_dbl_ilp(di);
+    G1Xyzz dis = x30_to_std(di);
+    same(dis.x, d.x); same(dis.y, d.y); same(dis.zz, d.zz); same(dis.zzz, d.zzz);
+    X30 si = p30; x30_add_ilp(si, q30);
+    G1Xyzz sis = x30_to_std(si);
+    same(sis.x, s.x); same(sis.y, s.y); same(sis.zz, s.zz); same(sis.zzz, s.zzz);
+    X30 ca = s30, cb = si;
+    for (int it = 0; it < 3; it++) { x30_add(ca, d30); x30_dbl(ca); x30_add(ca, q30); x30_add_ilp(cb, di); x30_dbl_ilp(cb); x30_add_ilp(cb, q30); }
+    G1Xyzz cas = x30_to_std(ca), cbs = x30_to_std(cb);
+    same(cas.x, cbs.x); same(cas.y, cbs.y); same(cas.zz, cbs.zz); same(cas.zzz, cbs.zzz);
+    X30 ei = p30; x30_add_ilp(ei, p30);
+    G1Xyzz eis = x30_to_std(ei);
+    same(eis.x, d.x); same(eis.y, d.y); same(eis.zz, d.zz); same(eis.zzz, d.zzz);
   }
   if (!ok) atomicAdd(bad, 1u);
 }

@@ -138,10 +138,12 @@ __device__ __noinline__ void q30_dbl(Fq30& A, u32 role) {
 
 // ---- reduce1, one segment per quad: the arguments and the result are those of reduce1_30_kernel ------------------
 __global__ __launch_bounds__(256) void reduce1_q_kernel(const G1Xyzz30* __restrict__ buckets, G1Xyzz30* __restrict__ segsum, u32 nb,
-                                                        u32 nseg, u32 njobs, u32 seg, u32 pbuckets, Own own) {
+                                                        u32 nseg, u32 njobs, u32 seg, u32 pbuckets, Own own,
+                                                        const u32* __restrict__ largest, u32 skew_limit) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 gid = t >> 2, role = t & 3;
   if (gid >= njobs * nseg) return;
+  if (*largest > skew_limit) return;      // skewed batch: see reduce1_30_kernel
   const u32 w = gid / nseg, s = gid % nseg;
   const u32 l = s * seg;                                          // index among the owned buckets
   const u32 lo = (own.first + (l / pbuckets) * own.stride) * pbuckets + l % pbuckets;

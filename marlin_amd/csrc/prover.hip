@@ -407,6 +407,16 @@ class HostPool {
   std::mutex mu_; std::condition_variable cv_; std::deque<std::function<void()>> q_; std::vector<std::thread> workers_; bool stop_ = false;
 };
 HostPool& host_pool() { static HostPool p; return p; }
+// The pool's tasks read locals of the submitting frame through pointers (blinding vectors, witness quotients), and a
+// packaged_task's future does not block in its destructor the way std::async's did: every frame that submits registers its
+// futures here, so that ANY way out of it -- an MH_TRY in between included -- first waits for the tasks still running.
+struct WaitAll {
+  std::vector<std::future<hostff::HG1>*> fs;
+  WaitAll() = default;
+  WaitAll(std::initializer_list<std::future<hostff::HG1>*> l) : fs(l) {}
+  void add(std::vector<std::future<hostff::HG1>>& v) { for (auto& f : v) fs.push_back(&f); }
+  ~WaitAll() { for (auto* f : fs) if (f->valid()) f->wait(); }
+};
 
 // sum_i scalars[i] * bases[i] for the 3-coefficient hiding polynomials (host): Straus' interleaving -- one shared
 // doubling chain, a table of the 2^k - 1 subset sums of the k <= 3 bases
@@ -573,9 +583,9 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
         const HG1Affine* gp = !reqs[i].has_bound ? pk.gamma_g : (reqs[i].bound == pk.H - 2 ? pk.gamma_g_h : pk.gamma_g_k);
         { const std::vector<HFr>* bl = &rands[i].rand.blind; hid[i] = host_pool().submit([gp, bl] { return small_msm(gp, *bl); }); }
       }
+    WaitAll wait_hid; wait_hid.add(hid);
     std::vector<HG1> res;
-    int rc_batch = sharded_msm_batch(c, jobs, res);
-    if (rc_batch != MH_OK) { for (auto& f : hid) if (f.valid()) f.wait(); return rc_batch; }
+    MH_TRY(sharded_msm_batch(c, jobs, res));
     std::vector<HG1> fin(reqs.size());
     for (size_t i = 0; i < reqs.size(); i++) {
       fin[i] = res[i];
@@ -607,9 +617,9 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
       { const HG1Affine* gp = pk.gamma_g; const std::vector<HFr>* bl = &rands[i].rand.blind; hid[i] = host_pool().submit([gp, bl] { return small_msm(gp, *bl); }); }
       if (reqs[i].has_bound) { const HG1Affine* gp = pk.gamma_g; const std::vector<HFr>* bl = &rands[i].shifted.blind; hid_sh[i] = host_pool().submit([gp, bl] { return small_msm(gp, *bl); }); }
     }
+  WaitAll wait_hid; wait_hid.add(hid); wait_hid.add(hid_sh);
   std::vector<HG1> res;
-  int rc_batch = sharded_msm_batch(c, jobs, res);
-  if (rc_batch != MH_OK) { for (auto& f : hid) if (f.valid()) f.wait(); for (auto& f : hid_sh) if (f.valid()) f.wait(); return rc_batch; }
+  MH_TRY(sharded_msm_batch(c, jobs, res));
   std::vector<HG1> fin;
   size_t j = 0;
   for (size_t i = 0; i < reqs.size(); i++) {
@@ -985,8 +995,21 @@ static bool load_g2(const uint64_t* p, hostpair::G2Aff* out) {
   for (const HFq* f : {&out->x.a, &out->x.b, &out->y.a, &out->y.b}) if (HFq::geq_mod(f->v)) return false;
   return hostpair::g2_on_curve(*out);
 }
+static int marlin_verify_impl(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, int pc, const uint64_t* public_input, size_t n_public,
+                              const uint8_t* flat_proof, size_t proof_len, int* ok_out, const fsh::ExternalFs* ext_fs);
 int mh_marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, int pc, const uint64_t* public_input, size_t n_public,
                      const uint8_t* flat_proof, size_t proof_len, int* ok_out) {
+  return marlin_verify_impl(vk_bytes, vk_len, vk, pc, public_input, n_public, flat_proof, proof_len, ok_out, nullptr);
+}
+// Marlin<F, PC, FS>::verify with the caller's FS (the counterpart of mh_marlin_prove_fs)
+int mh_marlin_verify_fs(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, int pc, const uint64_t* public_input, size_t n_public,
+                        const uint8_t* flat_proof, size_t proof_len, const mh_fiat_shamir* fs, int* ok_out) {
+  if (!fs || !fs->initialize || !fs->absorb || !fs->next_u64) return fail(MH_EINVAL, "mh_marlin_verify_fs: initialize, absorb and next_u64 must all be set");
+  const fsh::ExternalFs ext{fs->user, fs->initialize, fs->absorb, fs->next_u64};
+  return marlin_verify_impl(vk_bytes, vk_len, vk, pc, public_input, n_public, flat_proof, proof_len, ok_out, &ext);
+}
+static int marlin_verify_impl(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_key* vk, int pc, const uint64_t* public_input, size_t n_public,
+                              const uint8_t* flat_proof, size_t proof_len, int* ok_out, const fsh::ExternalFs* ext_fs) {
   if (!vk_bytes || !vk || !flat_proof || !ok_out || (!public_input && n_public)) return fail(MH_EINVAL, "mh_marlin_verify: null pointer");
   if (pc != 0 && pc != 1) return fail(MH_EINVAL, "mh_marlin_verify: pc must be 0 (MarlinKZG10) or 1 (SonicKZG10)");
   if (!vk->g_xy || !vk->gamma_g_xy || !vk->h_xy || !vk->beta_h_xy || !vk->shift_power_h_xy || !vk->shift_power_k_xy)
@@ -1008,7 +1031,7 @@ int mh_marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const mh_verifier_k
   }
   bool ok = false;
   std::string err;
-  if (hostverify::marlin_verify(vk_bytes, vk_len, k, pub, flat_proof, proof_len, &ok, &err) != 0) return fail(MH_EINVAL, "mh_marlin_verify: " + err);
+  if (hostverify::marlin_verify(vk_bytes, vk_len, k, pub, flat_proof, proof_len, &ok, &err, ext_fs) != 0) return fail(MH_EINVAL, "mh_marlin_verify: " + err);
   *ok_out = ok ? 1 : 0;
   return MH_OK;
 }
@@ -1350,7 +1373,7 @@ int mh_marlin_get_poly(uint64_t pk_handle, const char* label, uint64_t* out, siz
 // order of SURVEY.md Appendix C.  proof_out: the flat ToBytes-layout proof.
 static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, bool inputs_on_device,
                              const uint8_t* zk_seed, int zk_rounds, const uint64_t* zk_draws, size_t n_draws, uint8_t* proof_out, size_t cap,
-                             size_t* len_out);
+                             size_t* len_out, const fsh::ExternalFs* ext_fs = nullptr);
 int mh_marlin_prove(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, const uint8_t* zk_seed,
                     int zk_rounds, uint8_t* proof_out, size_t cap, size_t* len_out) {
   return marlin_prove_impl(pk_handle, instance, witness, false, zk_seed, zk_rounds, nullptr, 0, proof_out, cap, len_out);
@@ -1378,9 +1401,21 @@ int mh_marlin_prove_draws(uint64_t pk_handle, const uint64_t* instance, const ui
   static const uint8_t no_seed[32] = {0};
   return marlin_prove_impl(pk_handle, instance, witness, false, no_seed, 20, zk_draws, n_draws, proof_out, cap, len_out);
 }
+// Marlin<F, PC, FS>::prove for ANY `FS: FiatShamirRng` (src/lib.rs:64-70,151-155): the transcript operations go to the caller's
+// callbacks -- initialize (src/lib.rs:161-163), absorb after every round's commitments and after the evaluations
+// (:180,:201,:221,:289), and RngCore::next_u64 under `F::rand(fs_rng)` / `u128::rand(fs_rng)` (src/ahp/verifier.rs:58-61,86,98;
+// src/lib.rs:290).  With a sharded prove every rank's callbacks see the same byte sequence.
+static bool fs_callbacks_ok(const mh_fiat_shamir* fs) { return fs && fs->initialize && fs->absorb && fs->next_u64; }
+int mh_marlin_prove_fs(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, const uint8_t* zk_seed, int zk_rounds,
+                       const mh_fiat_shamir* fs, uint8_t* proof_out, size_t cap, size_t* len_out) {
+  if (!fs_callbacks_ok(fs)) return fail(MH_EINVAL, "mh_marlin_prove_fs: initialize, absorb and next_u64 must all be set");
+  static_assert(sizeof(mh_fiat_shamir) == sizeof(fsh::ExternalFs), "mh_fiat_shamir and fsh::ExternalFs are the same struct");
+  const fsh::ExternalFs ext{fs->user, fs->initialize, fs->absorb, fs->next_u64};
+  return marlin_prove_impl(pk_handle, instance, witness, false, zk_seed, zk_rounds, nullptr, 0, proof_out, cap, len_out, &ext);
+}
 static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, bool inputs_on_device,
                              const uint8_t* zk_seed, int zk_rounds, const uint64_t* zk_draws, size_t n_draws, uint8_t* proof_out, size_t cap,
-                             size_t* len_out) {
+                             size_t* len_out, const fsh::ExternalFs* ext_fs) {
   LOCKED_CTX();
   auto pit = g_pks.find(pk_handle);
   if (pit == g_pks.end()) return fail(MH_EINVAL, "mh_marlin_prove: unknown prover key");
@@ -1419,6 +1454,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   std::vector<HFr> pub(X - 1);                      // public_input() = formatted input without the leading one
   for (uint64_t i = 1; i < X; i++) memcpy(pub[i - 1].v, instance + 4 * i, 32);
   fsh::FiatShamirRng fs;
+  fs.ext = ext_fs;                                        // the caller's FS: FiatShamirRng, or SimpleHashFiatShamirRng<Blake2s, ChaChaRng>
   {
     std::vector<uint8_t> init; const char* name = "MARLIN-2019";
     init.insert(init.end(), name, name + 11);
@@ -1843,6 +1879,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   const HG1Affine* gp_open = pk.gamma_g;
   std::future<HG1> f_rw, f_srw = host_pool().submit([gp_open, &srw] { return small_msm(gp_open, srw); });
   if (r_nonzero) f_rw = host_pool().submit([gp_open, &rw] { return small_msm(gp_open, rw); });
+  WaitAll wait_open{&f_rw, &f_srw};       // `rw` and `srw` live in this frame: no return below may leave a worker reading them
   // The reference multiplies witness and shifted witness separately (kzg10::open on powers and on shifted_powers) and
   // adds the two commitments (marlin_pc open: w = w + shifted_w).  shifted_powers(d) is the same SRS array from index
   // max_degree - d, so the sum is ONE multi-scalar multiplication with the shifted witness's coefficients added at
@@ -1863,8 +1900,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     if (!merge_b) jobs.push_back({srs_pts + off_b * PT_B, S[4], swb_len});
     if (!merge_g) jobs.push_back({srs_pts + off_g * PT_B, S[6], swg_len});
     std::vector<HG1> res;
-    int rc_batch = sharded_msm_batch(c, jobs, res);
-    if (rc_batch != MH_OK) { f_srw.wait(); if (f_rw.valid()) f_rw.wait(); return rc_batch; }
+    MH_TRY(sharded_msm_batch(c, jobs, res));
     om = {res[0], res[1]};
     size_t nx = 2;
     if (!merge_b) om[0] = om[0].add(res[nx++]);

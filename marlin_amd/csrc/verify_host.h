@@ -85,7 +85,7 @@ inline G2Aff g2_mul_fr(const G2Aff& a, const HFr& k) {
 
 // returns 0 and *ok; a negative value for malformed inputs
 inline int marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const VerifierKey& vk, const std::vector<HFr>& public_input,
-                         const uint8_t* proof, size_t proof_len, bool* ok, std::string* err) {
+                         const uint8_t* proof, size_t proof_len, bool* ok, std::string* err, const fsh::ExternalFs* ext_fs = nullptr) {
   *ok = false;
   const bool sonic = vk.pc == 1;
   // marlin_pc::Commitment: comm || has_shifted || shifted (195 / 131 bytes); sonic_pc: a bare kzg10::Commitment
@@ -129,6 +129,7 @@ inline int marlin_verify(const uint8_t* vk_bytes, size_t vk_len, const VerifierK
   while (x.size() < X) x.push_back(HFr::zero());
   // ---- transcript (lib.rs:335-383)
   fsh::FiatShamirRng fs;
+  fs.ext = ext_fs;
   {
     std::vector<uint8_t> b;
     const char* name = "MARLIN-2019";

@@ -184,6 +184,39 @@ def prove(pk, instance_mont, witness_mont, zk_seed, zk_rounds=20):
     return bytes(out[:n.value])
 
 
+class _FiatShamirC(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("initialize", C.c_void_p), ("absorb", C.c_void_p), ("next_u64", C.c_void_p)]
+
+
+_FS_BYTES_T = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+_FS_U64_T = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
+
+
+def _fs_struct(fs):
+    """The caller's `FS: FiatShamirRng` (an object with initialize(bytes), absorb(bytes), next_u64() -> int) as mh_fiat_shamir.
+    Returns (struct, keepalive)."""
+    init = _FS_BYTES_T(lambda _u, p, n: fs.initialize(bytes(p[:n])))
+    absorb = _FS_BYTES_T(lambda _u, p, n: fs.absorb(bytes(p[:n])))
+    nxt = _FS_U64_T(lambda _u: int(fs.next_u64()) & 0xffffffffffffffff)
+    st = _FiatShamirC(None, C.cast(init, C.c_void_p), C.cast(absorb, C.c_void_p), C.cast(nxt, C.c_void_p))
+    return st, (init, absorb, nxt)
+
+
+def prove_fs(pk, instance_mont, witness_mont, zk_seed, fs, zk_rounds=20):
+    """Marlin<F, PC, FS>::prove for any `FS: FiatShamirRng` (src/lib.rs:64-70,151-155; mh_marlin_prove_fs): `fs` supplies
+    initialize / absorb / next_u64."""
+    x = np.ascontiguousarray(instance_mont, dtype=np.uint64)
+    w = np.ascontiguousarray(witness_mont, dtype=np.uint64)
+    assert x.shape == (pk.num_instance, 4) and w.shape == (pk.num_constraints - pk.num_instance, 4), (x.shape, w.shape)
+    st, keep = _fs_struct(fs)
+    out = (C.c_uint8 * 4096)()
+    n = C.c_size_t()
+    _lib.check(_lib.load().mh_marlin_prove_fs(pk.handle, x.ctypes.data, w.ctypes.data, bytes(zk_seed), int(zk_rounds), C.byref(st), out, 4096,
+                                              C.byref(n)), "mh_marlin_prove_fs")
+    del keep
+    return bytes(out[:n.value])
+
+
 def zk_draw_count(pk):
     n = C.c_size_t()
     _lib.check(_lib.load().mh_marlin_zk_draw_count(pk.handle, C.byref(n)), "mh_marlin_zk_draw_count")
@@ -231,6 +264,19 @@ def verify(vk_bytes, g_xy, gamma_g_xy, h_xy, beta_h_xy, shift_power_h_xy, shift_
     ok = C.c_int(0)
     _lib.check(_lib.load().mh_marlin_verify(bytes(vk_bytes), len(vk_bytes), C.byref(vk), {"marlin": 0, "sonic": 1}[pc], pub.ctypes.data,
                                             pub.shape[0], bytes(flat_proof), len(flat_proof), C.byref(ok)), "mh_marlin_verify")
+    return bool(ok.value)
+
+
+def verify_fs(vk_bytes, g_xy, gamma_g_xy, h_xy, beta_h_xy, shift_power_h_xy, shift_power_k_xy, public_input_mont, flat_proof, fs, pc="marlin"):
+    """verify() with the caller's `FS: FiatShamirRng` (mh_marlin_verify_fs)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (g_xy, gamma_g_xy, h_xy, beta_h_xy, shift_power_h_xy, shift_power_k_xy)]
+    vk = _VerifierKeyC(*[a.ctypes.data for a in arrs])
+    pub = np.ascontiguousarray(public_input_mont, dtype=np.uint64).reshape(-1, 4)
+    st, keep = _fs_struct(fs)
+    ok = C.c_int(0)
+    _lib.check(_lib.load().mh_marlin_verify_fs(bytes(vk_bytes), len(vk_bytes), C.byref(vk), {"marlin": 0, "sonic": 1}[pc], pub.ctypes.data,
+                                               pub.shape[0], bytes(flat_proof), len(flat_proof), C.byref(st), C.byref(ok)), "mh_marlin_verify_fs")
+    del keep
     return bool(ok.value)
 
 

@@ -41,6 +41,15 @@ pub struct mh_verifier_key {
     pub shift_power_k_xy: *const u64,
 }
 
+/// `mh_fiat_shamir`: the caller's `FS: FiatShamirRng` as three callbacks (`mh_marlin_prove_fs` / `mh_marlin_verify_fs`).
+#[repr(C)]
+pub struct mh_fiat_shamir {
+    pub user: *mut c_void,
+    pub initialize: Option<unsafe extern "C" fn(user: *mut c_void, input: *const u8, len: usize)>,
+    pub absorb: Option<unsafe extern "C" fn(user: *mut c_void, input: *const u8, len: usize)>,
+    pub next_u64: Option<unsafe extern "C" fn(user: *mut c_void) -> u64>,
+}
+
 /// `mh_allgather_fn`: gather `bytes` bytes from every rank into `recv` (rank-major).
 pub type mh_allgather_fn =
     Option<unsafe extern "C" fn(send: *const c_void, bytes: usize, recv: *mut c_void, user: *mut c_void) -> c_int>;
@@ -121,6 +130,10 @@ extern "C" {
                            zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
     pub fn mh_marlin_prove_dev(pk: u64, d_instance_mont: *const c_void, d_witness_mont: *const c_void, zk_seed32: *const u8,
                                zk_chacha_rounds: c_int, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
+    pub fn mh_marlin_prove_fs(pk: u64, instance_mont: *const u64, witness_mont: *const u64, zk_seed32: *const u8, zk_chacha_rounds: c_int,
+                              fs: *const mh_fiat_shamir, proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
+    pub fn mh_marlin_verify_fs(vk_bytes: *const u8, vk_len: usize, vk: *const mh_verifier_key, pc: c_int, public_input_mont: *const u64, n_public: usize,
+                               flat_proof: *const u8, proof_len: usize, fs: *const mh_fiat_shamir, ok_out: *mut c_int) -> c_int;
     pub fn mh_marlin_zk_draw_count(pk: u64, n_out: *mut usize) -> c_int;
     pub fn mh_marlin_prove_draws(pk: u64, instance_mont: *const u64, witness_mont: *const u64, zk_draws_mont: *const u64, n_draws: usize,
                                  proof_out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;

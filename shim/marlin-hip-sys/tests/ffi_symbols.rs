@@ -13,7 +13,7 @@ fn every_header_symbol_links() {
         mh_bases_len as usize, mh_bases_precompute as usize, mh_bases_table_info as usize, mh_msm_path_counts as usize,
         mh_msm as usize, mh_msm_dev as usize, mh_msm_batch_dev as usize, mh_msm_batch as usize, mh_msm_batch_sharded_dev as usize, mh_g1_to_affine as usize, mh_g1_sum as usize,
         mh_marlin_index as usize, mh_marlin_index_pc as usize, mh_marlin_pk_free as usize, mh_marlin_pk_info as usize,
-        mh_marlin_vk_bytes as usize, mh_marlin_prove as usize, mh_marlin_prove_dev as usize, mh_marlin_zk_draw_count as usize, mh_marlin_prove_draws as usize, mh_marlin_verify as usize, mh_pairing_product_is_one as usize, mh_marlin_proof_serialize as usize,
+        mh_marlin_vk_bytes as usize, mh_marlin_prove as usize, mh_marlin_prove_dev as usize, mh_marlin_prove_fs as usize, mh_marlin_verify_fs as usize, mh_marlin_zk_draw_count as usize, mh_marlin_prove_draws as usize, mh_marlin_verify as usize, mh_pairing_product_is_one as usize, mh_marlin_proof_serialize as usize,
         mh_marlin_proof_deserialize as usize, mh_marlin_set_shard as usize, mh_marlin_test_allgather as usize, mh_marlin_set_alltoall as usize, mh_marlin_set_alltoall_mode as usize, mh_marlin_set_allgather_dev as usize, mh_marlin_test_exchange_dev as usize, mh_rccl_unique_id as usize, mh_marlin_set_rccl as usize, mh_marlin_rccl_sliced as usize, mh_marlin_rccl_destroy as usize, mh_marlin_rccl_info as usize, mh_marlin_exchange_stats as usize,
         mh_ntt_dist_dev as usize, mh_msm_batch_sliced_dev as usize,
         mh_marlin_get_poly as usize, mh_prof_enable as usize, mh_prof_reset as usize, mh_prof_get as usize,

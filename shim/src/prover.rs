@@ -176,6 +176,56 @@ pub mod wire {
     use ark_ff::{BigInteger384, FromBytes, PrimeField};
     use ark_poly_commit::{kzg10, marlin_pc};
 
+    /// `Marlin::<Fr, MultiPC, FS2>::prove` for ANY `FS2: FiatShamirRng` (`src/lib.rs:64-70,151-155`; the trait is
+    /// `src/rng.rs:54-62`): the library's transcript operations are routed to `fs` through `mh_marlin_prove_fs` -- `initialize`
+    /// (`src/lib.rs:161-163`), `absorb` after each round's commitments and after the evaluations (`:180,:201,:221,:289`) and
+    /// `RngCore::next_u64` under `F::rand(fs_rng)` / `u128::rand(fs_rng)`.  `FS2::initialize` is a constructor upstream, so the
+    /// state lives in an `Option<FS2>` that the first callback fills.
+    pub fn prove_with_fs<C: ConstraintSynthesizer<Fr>, FS2: ark_marlin::rng::FiatShamirRng>(
+        pk: &GpuIndexProverKey,
+        c: C,
+        zk_seed: [u8; 32],
+    ) -> Result<Proof<Fr, MultiPC>, HipError> {
+        use core::ffi::c_void;
+        use rand_core::RngCore;
+        unsafe extern "C" fn init<F: ark_marlin::rng::FiatShamirRng>(user: *mut c_void, input: *const u8, len: usize) {
+            let slot = &mut *(user as *mut Option<F>);
+            *slot = Some(F::initialize(&core::slice::from_raw_parts(input, len)));
+        }
+        unsafe extern "C" fn absorb<F: ark_marlin::rng::FiatShamirRng>(user: *mut c_void, input: *const u8, len: usize) {
+            let slot = &mut *(user as *mut Option<F>);
+            slot.as_mut().expect("initialize first").absorb(&core::slice::from_raw_parts(input, len));
+        }
+        unsafe extern "C" fn next<F: ark_marlin::rng::FiatShamirRng>(user: *mut c_void) -> u64 {
+            let slot = &mut *(user as *mut Option<F>);
+            slot.as_mut().expect("initialize first").next_u64()
+        }
+        let pcs = ConstraintSystem::<Fr>::new_ref();
+        pcs.set_optimization_goal(OptimizationGoal::Weight);
+        pcs.set_mode(SynthesisMode::Prove { construct_matrices: true });
+        c.generate_constraints(pcs.clone()).map_err(|_| HipError::Unsupported("constraint synthesis failed"))?;
+        pad_and_square(pcs.clone());
+        let pcs = pcs.into_inner().unwrap();
+        let instance = fr_slice_to_limbs(&pcs.instance_assignment);
+        let witness = fr_slice_to_limbs(&pcs.witness_assignment);
+        let mut state: Option<FS2> = None;
+        let cb = ffi::mh_fiat_shamir {
+            user: &mut state as *mut Option<FS2> as *mut c_void,
+            initialize: Some(init::<FS2>),
+            absorb: Some(absorb::<FS2>),
+            next_u64: Some(next::<FS2>),
+        };
+        let mut flat = vec![0u8; 4096];
+        let mut flat_len = 0usize;
+        check(unsafe {
+            ffi::mh_marlin_prove_fs(pk.pk, instance.as_ptr(), witness.as_ptr(), zk_seed.as_ptr(), 20, &cb, flat.as_mut_ptr(), flat.len(), &mut flat_len)
+        })?;
+        let mut wire = vec![0u8; 4096];
+        let mut wire_len = 0usize;
+        check(unsafe { ffi::mh_marlin_proof_serialize(flat.as_ptr(), flat_len, 0, wire.as_mut_ptr(), wire.len(), &mut wire_len) })?;
+        Proof::<Fr, MultiPC>::deserialize(&wire[..wire_len]).map_err(|_| HipError::Unsupported("Proof::deserialize rejected the library's bytes"))
+    }
+
     fn g1_from_tobytes(b: &[u8]) -> G1Affine {
         // x (48 B LE canonical) || y (48 B) || infinity (1 B)   [SURVEY.md Appendix B-6]
         let x = Fq::from_repr(BigInteger384::read(&b[0..48]).unwrap()).unwrap();

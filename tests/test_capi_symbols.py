@@ -76,7 +76,8 @@ def _c_prototypes():
 
 _C2RUST_BASE = {"int": "c_int", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "char": "c_char", "void": "c_void",
                 "double": "f64", "mh_r1cs_matrices": "mh_r1cs_matrices", "mh_verifier_key": "mh_verifier_key",
-                "mh_allgather_fn": "mh_allgather_fn", "mh_alltoall_fn": "mh_alltoall_fn", "mh_allgather_dev_fn": "mh_allgather_dev_fn"}
+                "mh_allgather_fn": "mh_allgather_fn", "mh_alltoall_fn": "mh_alltoall_fn", "mh_allgather_dev_fn": "mh_allgather_dev_fn",
+                "mh_fiat_shamir": "mh_fiat_shamir"}
 
 
 def _c_to_rust(ctype):

@@ -96,3 +96,33 @@ def test_distributed_ntt_and_sliced_msm(gpu, tmp_path, world, logs):
     outs = [p.communicate(timeout=600) for p in procs]
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "rank %d ok" % r in so, "rank %d:\n%s\n%s" % (r, so[-1500:], se[-3000:])
+
+
+def test_sliced_msm_refuses_skewed_digits(gpu):
+    """a strided selection has no variable-base fallback (its bases are not a contiguous range).  A slice whose
+    digits repeat so heavily that one bucket holds most of the entries is refused with MH_EINVAL -- the accumulate kernel
+    returns at once on the device flag -- instead of one thread walking a list of tens of thousands of entries; the same
+    vector through mh_msm_batch_dev takes the variable-base path and gives the result."""
+    import numpy as np
+    import marlin_amd as M
+    from marlin_amd import dist as MD, _lib
+    n = 1 << 16
+    tau = np.array([0x1234567, 0, 0, 0], dtype=np.uint64)
+    B = M.Bases.srs_powers(tau, 2 * n)
+    B.precompute(14)
+    hot = np.zeros((n, 4), dtype=np.uint64)
+    hot[:] = np.array([0x1234, 0, 0, 0], dtype=np.uint64)           # Montgomery words with ONE non-zero digit: one bucket gets everything
+    d = M.DeviceBuffer.from_numpy(hot)
+    with pytest.raises(_lib.MarlinHipError, match="strided MSM: one bucket"):
+        MD.msm_batch_sliced_dev(B, [(0, d, n)], 2, combine=False)
+    fb0, vb0 = M.msm_path_counts()
+    M.msm_batch_dev([(B, 0, d, n)])
+    fb1, vb1 = M.msm_path_counts()
+    assert vb1 == vb0 + 1                                             # the contiguous call left the fixed-base path and finished
+    # a well-spread slice still works after the refusal
+    rng = np.random.default_rng(3)
+    ok = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    d2 = M.DeviceBuffer.from_numpy(ok)
+    part = MD.msm_batch_sliced_dev(B, [(0, d2, n)], 1, combine=False)
+    whole = M.msm_batch_dev([(B, 0, d2, n)])
+    assert tuple(M.g1_to_affine(part[0])[0]) == tuple(M.g1_to_affine(whole[0])[0])

@@ -142,6 +142,60 @@ def test_device_proof_passes_the_products_own_verifier(gpu, log_n, pc):
     assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), bytes(bad), pc=pc)
 
 
+@pytest.mark.parametrize("pc", ["marlin", "sonic"])
+def test_prove_and_verify_with_the_callers_fiat_shamir(gpu, pc):
+    """Marlin<F, PC, FS> is generic over FS: FiatShamirRng (src/lib.rs:64-70; VERDICT r03 missing 5).  mh_marlin_prove_fs routes
+    initialize / absorb / next_u64 to the caller: (i) with the oracle's SimpleHashFiatShamirRng<Blake2s, ChaChaRng> behind the
+    callbacks the proof is the built-in entry point's proof, byte for byte, and the transcript the callbacks saw is the
+    reference's (initialize once with "MARLIN-2019" || vk || input, then one absorb per round and one for the evaluations);
+    (ii) with ANOTHER FS (SHA-256 in counter mode) the proof differs, verifies under mh_marlin_verify_fs with that FS, and is
+    rejected by the built-in verifier and for a wrong input."""
+    import hashlib
+    import numpy as np
+    from oracle import g2 as G2
+    from tests.util import fr_to_np, fq_to_limbs
+    rng = FS.test_rng()
+    a, b = FS.fr_rand(rng), FS.fr_rand(rng)
+    n = 1 << 10
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc=pc)
+    ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
+    pk = GM.index(srs, ncp, ni, mats, pc=pc)
+    want = GM.prove(pk, inst, wit, SEED)
+
+    class Ref:                                   # the reference's instantiation, through the callbacks
+        def __init__(self):
+            self.log, self.fs = [], None
+        def initialize(self, data):
+            self.log.append(("initialize", len(data))); self.fs = FS.SimpleHashFiatShamirRng(data); self.first = data
+        def absorb(self, data):
+            self.log.append(("absorb", len(data))); self.fs.absorb(data)
+        def next_u64(self):
+            return self.fs.next_u64()
+    ref = Ref()
+    assert GM.prove_fs(pk, inst, wit, SEED, ref) == want
+    assert [k for k, _ in ref.log] == ["initialize", "absorb", "absorb", "absorb", "absorb"]
+    assert ref.first.startswith(b"MARLIN-2019" + pk.vk_bytes())
+
+    class Sha:                                   # some other FiatShamirRng: SHA-256 state, counter-mode output
+        def initialize(self, data):
+            self.state, self.ctr = hashlib.sha256(b"init" + data).digest(), 0
+        def absorb(self, data):
+            self.state, self.ctr = hashlib.sha256(self.state + data).digest(), 0
+        def next_u64(self):
+            self.ctr += 1
+            return int.from_bytes(hashlib.sha256(self.state + self.ctr.to_bytes(8, "little")).digest()[:8], "little")
+    other = GM.prove_fs(pk, inst, wit, SEED, Sha())
+    assert other != want and len(other) == len(want)
+    h = G2.g2_mul(G2.G2_GEN, 0x5eed)
+    h_np = np.array(sum([fq_to_limbs(c) for c in (h[0][0], h[0][1], h[1][0], h[1][1])], []), dtype=np.uint64)
+    els = srs.verifier_key(pk, h_np, pc=pc)
+    c = a * b % F.R_MOD
+    assert GM.verify_fs(pk.vk_bytes(), *els, fr_to_np([c]), other, Sha(), pc=pc)
+    assert not GM.verify_fs(pk.vk_bytes(), *els, fr_to_np([a]), other, Sha(), pc=pc)
+    assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), other, pc=pc)              # another transcript, other challenges
+    assert GM.verify_fs(pk.vk_bytes(), *els, fr_to_np([c]), want, Ref(), pc=pc)          # and the built-in proof under the callbacks
+
+
 TOGGLE_WORKER = r'''
 import sys
 sys.path.insert(0, %(root)r)

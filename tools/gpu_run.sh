@@ -1,0 +1,72 @@
+#!/bin/bash
+# ONE parameterised runner for a gpurun lease (replaces the 31 frozen tools/gpu_run_r03*.sh of round 3; those stay readable in
+# history: `git show db7f097:tools/gpu_run_r03zz.sh`).  On the GPU box, from the repo root:
+#     gpurun --timeout 1800 -- 'bash tools/gpu_run.sh <tag> <recipe> [<recipe> ...]'
+# Everything a recipe writes goes to gpurun_out/<tag>/ (merged back by gpurun); what is to be judged is copied to profiles/<tag>_*.
+# Recipes:
+#   suite        pytest -m gpu (whole suite) + __graft_entry__.smoke()
+#   bench        the default bench line (2^20, BLS12-381, MarlinKZG10, CPU baseline at the same size, seam route)
+#   profile      tools/profile.sh <tag>: rocprofv3 kernel stats, accumulate dispatches, PMC traffic
+#   sq           tools/profile_sq.sh <tag>: SQ wave-cycle breakdown of the accumulate kernel
+#   sims         one rank of 2 / 4 / 8 simulated on this GPU at 2^20, one of 8 at 2^22
+#   configs      the other BASELINE configurations (2^16 Sonic, 2^18, 2^22, BLS Sonic, BN254 Marlin / Sonic)
+#   small        the reference's own bench shape (2^16, SonicKZG10) with a kernel trace of the last prove and its gap analysis
+#   seam         the seam route (host pointers), with and without the short uploads of mh_ntt_len
+#   ab=<lib.so>  tools/ab.sh: alternate the in-tree build and another build of the same ABI
+set -u
+TAG=${1:?tag}; shift
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+O=$(pwd)/gpurun_out/$TAG; mkdir -p $O
+export TMPDIR=/tmp
+B="timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-seam-route"
+line() { python - "$@" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        p = d.get("proof") or {}
+        print(f.split("/")[-1], d["ms_per_step"], d["value"], {k: v for k, v in d["breakdown_ms_per_step"].items() if k != "measured_on"},
+              "verified", p.get("verified"), "golden", (p.get("oracle_golden") or {}).get("byte_identical"))
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+}
+for R in "$@"; do
+  case $R in
+    suite)
+      ( timeout 2400 python -m pytest tests -m gpu -q --durations=6 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log ); tail -8 $O/pytest.log
+      python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt ;;
+    bench)
+      timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; line $O/bench_default.json ;;
+    profile)
+      timeout 1500 bash tools/profile.sh $TAG > $O/profile.log 2>&1; tail -3 $O/profile.log ;;
+    sq)
+      timeout 1200 bash tools/profile_sq.sh $TAG --no-seam-route > $O/sq.log 2>&1; cp gpurun_out/prof_$TAG/sq_counters.json $O/ 2>/dev/null; tail -25 $O/sq.log ;;
+    sims)
+      $B --simulate-rank 1/2 > $O/sim_1_2.json 2>/dev/null; $B --simulate-rank 3/4 > $O/sim_3_4.json 2>/dev/null
+      $B --simulate-rank 5/8 > $O/sim_5_8.json 2>/dev/null; $B --log-constraints 22 --simulate-rank 3/8 > $O/sim_3_8_2p22.json 2>/dev/null
+      line $O/sim_*.json ;;
+    configs)
+      $B --log-constraints 16 --pc sonic --steps 20 > $O/bench_reference_shape_2p16_sonickzg10.json 2>/dev/null
+      $B --log-constraints 18 > $O/bench_2p18.json 2>/dev/null
+      $B --log-constraints 22 --steps 5 --warmup 2 > $O/bench_2p22.json 2>/dev/null
+      $B --pc sonic > $O/bench_bls12_381_sonickzg10_2p20.json 2>/dev/null
+      MARLIN_AMD_CURVE=bn254 $B > $O/bench_bn254_marlinkzg10_2p20.json 2>/dev/null
+      MARLIN_AMD_CURVE=bn254 $B --pc sonic > $O/bench_bn254_sonickzg10_2p20.json 2>/dev/null
+      line $O/bench_reference_shape_*.json $O/bench_2p18.json $O/bench_2p22.json $O/bench_bls12_381_sonic*.json $O/bench_bn254_*.json ;;
+    small)
+      $B --log-constraints 16 --pc sonic --steps 20 > $O/bench_2p16_sonic.json 2>/dev/null; line $O/bench_2p16_sonic.json
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace_2p16 -o t -- python $OLDPWD/bench.py --steps 3 --warmup 1 \
+          --no-cpu-baseline --no-seam-route --no-verify --log-constraints 16 --pc sonic > $O/trace_2p16.log 2>&1 )
+      T=$(find $O/trace_2p16 -name "*kernel_trace.csv" | head -1)
+      [ -n "$T" ] && python tools/gap_analysis.py $T 4 > $O/gaps_2p16_sonic.txt 2>&1 && python tools/prove_kernels.py $T > $O/last_prove_kernels_2p16_sonic.txt 2>&1
+      rm -rf $O/trace_2p16; tail -30 $O/gaps_2p16_sonic.txt ;;
+    seam)
+      timeout 600 python bench.py --workload seam-route --steps 3 --warmup 1 > $O/bench_seam.json 2> $O/bench_seam.err
+      BENCH_SEAM_FULL_UPLOAD=1 timeout 600 python bench.py --workload seam-route --steps 3 --warmup 1 > $O/bench_seam_full_upload.json 2>> $O/bench_seam.err
+      line $O/bench_seam.json $O/bench_seam_full_upload.json ;;
+    ab=*)
+      bash tools/ab.sh "${R#ab=}" --no-seam-route > $O/ab.txt 2>&1; cut -c1-330 $O/ab.txt ;;
+    *) echo "unknown recipe $R" ;;
+  esac
+done
