@@ -697,6 +697,12 @@ __global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restri
   x30_store(segsum + gid, acc);
 }
 
+// (Round 4 also built the segment loop around ONE inlined copy of the group law -- a step is "dst += src" with (dst, src) =
+// (running, bucket) on even and (acc, running) on odd steps, operands selected into one pair of register sets -- to spare the
+// called law its operands' round trip through scratch: 255 VGPRs + 75 AGPRs, and SLOWER, 12.75 vs 11.55 ms of sort + reduce
+// stages per proof at 2^20 (profiles/r04g_ab_reduce_single_inlined_site.txt).  Together with the called field operations
+// (slower too) that brackets the form in the tree: group law called, field operations inlined.)
+
 // ---- reduce2: tree sums of the segment results, still on 30-bit limbs ------------------------------------------------
 // grid (chunks, jobs): block (k, w) sums elements [k * per, (k + 1) * per) of job w's nseg points.  last = 0: writes a
 // 30-bit point to out30[w * chunks + k] (first of two launches when nseg is large); last = 1: converts the sum to the
