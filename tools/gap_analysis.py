@@ -21,3 +21,14 @@ for lo, hi in ((0, 5), (5, 15), (15, 40), (40, 100), (100, 1e9)):
 print("largest gaps (us, after kernel -> before kernel):")
 for g, a, b in sorted(gaps, reverse=True)[:25]:
     print("  %8.1f  %s -> %s" % (g, a, b))
+
+# the same gaps in dispatch order with their neighbourhood (which phase of the prove each host round trip belongs to)
+print("gaps >= 15 us in order (index, us, two kernels before -> two after):")
+short = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "")[-34:]
+for i, (a, b) in enumerate(zip(pr, pr[1:])):
+    g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3
+    if g >= 15:
+        before = " | ".join(short(r) for r in pr[max(0, i - 1):i + 1])
+        after = " | ".join(short(r) for r in pr[i + 1:i + 3])
+        t = (int(a["End_Timestamp"]) - int(pr[0]["Start_Timestamp"])) / 1e3
+        print("  #%3d  t=%8.1f us  gap %6.1f   %s  ->  %s" % (i, t, g, before, after))
