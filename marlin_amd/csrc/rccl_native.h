@@ -54,11 +54,19 @@ inline State& state() { static State s; return s; }
 inline int load_api() {
   Api& a = state().api;
   if (a.lib) return MH_OK;
-  // the copy that is already mapped (a torch process) first, then the loader's search path, then the ROCm tree
+  // the copy that is already mapped (a torch process) first, then the loader's search path, then the ROCm tree.
+  // MH_RCCL_LIB=<path>: that library and no other -- the hook the tests use to run this transport at N > 1 on ONE GPU over a
+  // shared-memory stand-in (tests/mock_rccl/), since RCCL itself refuses two ranks on one device
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  void* h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
-  for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-  if (!h) return fail(MH_EINVAL, std::string("native RCCL transport: librccl.so.1 not found (") + (dlerror() ? dlerror() : "?") + ")");
+  const char* forced = getenv("MH_RCCL_LIB");
+  void* h = nullptr;
+  if (forced && *forced) {
+    h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+  } else {
+    h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+    for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+  }
+  if (!h) return fail(MH_EINVAL, std::string("native RCCL transport: ") + (forced && *forced ? forced : "librccl.so.1") + " not found (" + (dlerror() ? dlerror() : "?") + ")");
 #define RCCL_SYM(field, name, required)                                                                         \
   a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                                                \
   if (required && !a.field) { dlclose(h); return fail(MH_EINVAL, std::string("native RCCL transport: symbol missing: ") + name); }

@@ -1,0 +1,102 @@
+// TEST INFRASTRUCTURE (never loaded by the product unless MH_RCCL_LIB points at it): a stand-in for librccl that lets SEVERAL
+// processes sharing ONE GPU run the library's native transport (marlin_amd/csrc/rccl_native.h) -- RCCL itself refuses two ranks on
+// one device, and a gpurun lease has one device.  It implements exactly the entry points rccl_native.h resolves, with RCCL's
+// signatures and semantics, over a POSIX shared-memory segment: a collective drains the caller's stream, stages through the
+// segment (device -> host slot, barrier, host slots -> device, barrier) and returns.  What this exercises is everything on OUR
+// side of the call at N = 2 / 4 / 8 -- buffer sizes, counts, staging, chunk order, the device all-gather of round polynomials,
+// bench.py's transport set-up and self-tests -- not RCCL (AMD's code; executed for real at world 1 by
+// tests/test_gpu_rccl_native.py).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+extern "C" {
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4 } ncclResult_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+struct Header { std::atomic<uint32_t> arrived; std::atomic<uint32_t> generation; std::atomic<uint32_t> attached; uint32_t nranks; };
+struct ncclComm { int rank, nranks; size_t slot; char name[64]; Header* hdr; char* slots; size_t map_bytes; };
+typedef ncclComm* ncclComm_t;
+
+static const size_t kSlot = 96ull << 20;        // per rank: the largest payload a test moves is a few MB
+
+static void barrier(ncclComm* c) {
+  Header* h = c->hdr;
+  const uint32_t gen = h->generation.load(std::memory_order_acquire);
+  if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)c->nranks) {
+    h->arrived.store(0, std::memory_order_relaxed);
+    h->generation.fetch_add(1, std::memory_order_release);
+  } else {
+    while (h->generation.load(std::memory_order_acquire) == gen) usleep(20);
+  }
+}
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+  memset(id->internal, 0, sizeof(id->internal));
+  snprintf(id->internal, sizeof(id->internal), "/mh_mock_rccl_%d_%ld", (int)getpid(), (long)random());
+  return ncclSuccess;
+}
+ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int rank) {
+  if (!out || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+  ncclComm* c = new ncclComm();
+  c->rank = rank; c->nranks = nranks; c->slot = kSlot;
+  snprintf(c->name, sizeof(c->name), "%s", id.internal);
+  c->map_bytes = 4096 + (size_t)nranks * kSlot;
+  int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) { delete c; return ncclSystemError; }
+  if (ftruncate(fd, (off_t)c->map_bytes) != 0) { close(fd); delete c; return ncclSystemError; }
+  void* p = mmap(nullptr, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) { delete c; return ncclSystemError; }
+  c->hdr = (Header*)p; c->slots = (char*)p + 4096;
+  // a fresh segment is zero-filled: the counters start at 0 without an initialisation race
+  c->hdr->attached.fetch_add(1, std::memory_order_acq_rel);
+  while (c->hdr->attached.load(std::memory_order_acquire) < (uint32_t)nranks) usleep(100);     // ncclCommInitRank is collective
+  *out = c;
+  return ncclSuccess;
+}
+ncclResult_t ncclCommDestroy(ncclComm_t c) {
+  if (!c) return ncclSuccess;
+  munmap((void*)c->hdr, c->map_bytes);
+  if (c->rank == 0) shm_unlink(c->name);
+  delete c;
+  return ncclSuccess;
+}
+ncclResult_t ncclCommAbort(ncclComm_t c) { return ncclCommDestroy(c); }
+const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "mock rccl error"; }
+ncclResult_t ncclGetVersion(int* v) { if (v) *v = 0; return ncclSuccess; }
+
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t c, hipStream_t s) {
+  if (count > c->slot) return ncclInvalidArgument;
+  if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
+  if (hipMemcpy(c->slots + (size_t)c->rank * c->slot, send, count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+  barrier(c);
+  for (int p = 0; p < c->nranks; p++)
+    if (hipMemcpy((char*)recv + (size_t)p * count, c->slots + (size_t)p * c->slot, count, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+  barrier(c);                        // nobody overwrites a slot before every rank has read it
+  return ncclSuccess;
+}
+ncclResult_t ncclAllToAll(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t c, hipStream_t s) {
+  if (count * (size_t)c->nranks > c->slot) return ncclInvalidArgument;
+  if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
+  if (hipMemcpy(c->slots + (size_t)c->rank * c->slot, send, count * c->nranks, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+  barrier(c);
+  for (int p = 0; p < c->nranks; p++)         // chunk `rank` of peer p's send buffer is what p sends to this rank
+    if (hipMemcpy((char*)recv + (size_t)p * count, c->slots + (size_t)p * c->slot + (size_t)c->rank * count, count, hipMemcpyHostToDevice) != hipSuccess)
+      return ncclUnhandledCudaError;
+  barrier(c);
+  return ncclSuccess;
+}
+// resolved by rccl_native.h but never reached while ncclAllToAll exists
+ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclInternalError; }
+ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclInternalError; }
+ncclResult_t ncclGroupStart(void) { return ncclSuccess; }
+ncclResult_t ncclGroupEnd(void) { return ncclSuccess; }
+}

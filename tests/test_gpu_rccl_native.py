@@ -123,3 +123,96 @@ def test_bench_world_1_under_torchrun_uses_no_transport(gpu):
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["transport"] is None and rec["proof"]["verified"] is True
+
+
+# ---- N > 1 through the native transport, on ONE GPU: the shared-memory stand-in for librccl (tests/mock_rccl/) ----------------
+MOCK = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+
+MOCK_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+import marlin_amd as M
+from marlin_amd import marlin as GM, dist as MD
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)      # used ONCE: to hand rank 0's unique id to the others
+M.init(0)                                                          # every rank on the box's one GPU
+n = 1 << %(log_n)d
+srs = GM.universal_setup(n, n, 3 * n, %(tau)d, %(gamma)d, pc=%(pc)r)
+nc, ni, mats, inst, wit = GM.dummy_circuit(%(a)d, %(b)d, 10, n)
+pk = GM.index(srs, nc, ni, mats, pc=%(pc)r)
+assert MD.enable_native_rccl(dist, sliced=bool(%(sliced)d))
+info = MD.native_rccl_info()
+assert info["active"] and "mock_rccl" in info["librccl"], info
+assert MD.selftest_allgather(dist)
+if %(sliced)d and world & (world - 1) == 0:
+    assert MD.selftest_alltoall(dist, log_n=10)
+before = MD.native_rccl_info()
+proof = GM.prove(pk, inst, wit, bytes(range(32)))
+proof2 = GM.prove(pk, inst, wit, bytes(range(1, 33)))
+after = MD.native_rccl_info()
+open(os.path.join(%(out)r, "proof%%d.bin" %% rank), "wb").write(proof + proof2)
+open(os.path.join(%(out)r, "info%%d.txt" %% rank), "w").write("%%d %%d %%d" %% tuple(after[k] - before[k] for k in ("allgather_host", "alltoall", "allgather_dev")))
+dist.barrier(); MD.disable_sharded_prove(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,log_n,pc,sliced", [(2, 12, "marlin", 0), (4, 16, "marlin", 0), (2, 12, "marlin", 1), (4, 12, "sonic", 1),
+                                                   (4, 16, "marlin", 1), (8, 16, "marlin", 1), (8, 16, "sonic", 1), (3, 12, "marlin", 1)])
+def test_native_transport_at_n_ranks_gives_the_single_gpu_proof(gpu, tmp_path, world, log_n, pc, sliced):
+    """mh_marlin_set_rccl with N = 2 / 3 / 4 / 8 ranks -- the C++ all-gather of partial points, the all-to-all of the distributed
+    transforms and the device all-gather of round polynomials (rccl_native.h), entered from mh_marlin_prove exactly as on a
+    multi-GPU node -- with the collectives carried by the shared-memory stand-in for librccl (RCCL refuses two ranks on the one
+    device of this box): every rank's two proofs are the unsharded prover's bytes, and the counters show which collectives ran
+    (sliced = 1 and a power-of-two world: distributed transforms and two device all-gathers per proof)."""
+    from marlin_amd import marlin as GM
+    import json
+    GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "marlin_proofs.json")))
+    TAU, GAMMA = int(GOLD["tau"], 16), int(GOLD["gamma"], 16)
+    assert os.path.exists(MOCK), "tests/mock_rccl/libmock_rccl.so not built (python -c 'import __graft_entry__ as g; g.build()')"
+    a, b = 0x1234567, 0x7654321
+    n = 1 << log_n
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA, pc=pc)
+    nc, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
+    pk = GM.index(srs, nc, ni, mats, pc=pc)
+    want = GM.prove(pk, inst, wit, bytes(range(32))) + GM.prove(pk, inst, wit, bytes(range(1, 33)))
+    script = tmp_path / "mock_worker.py"
+    script.write_text(MOCK_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "pc": pc, "sliced": sliced})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29913 + world + log_n + 40 * sliced + (7 if pc == "sonic" else 0)), WORLD_SIZE=str(world),
+               MH_RCCL_LIB=MOCK)
+    if sliced:
+        env["MH_SLICED"] = "2"               # also with 2 ranks, where the library would keep the rounds replicated
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-800:] + se[-2500:]
+    pow2 = world & (world - 1) == 0
+    for r in range(world):
+        assert open(tmp_path / ("proof%d.bin" % r), "rb").read() == want, r
+        ag_host, a2a, ag_dev = (int(x) for x in open(tmp_path / ("info%d.txt" % r)).read().split())
+        assert ag_host >= 8                                        # >= 4 per proof: one per commit round and the openings
+        if sliced and pow2 and n >= world * world:
+            assert a2a >= 2 * 9 and ag_dev == 2 * 2, (a2a, ag_dev)   # nine distributed transforms, two round gathers per proof
+        else:
+            assert a2a == 0 and ag_dev == 0
+
+
+def test_bench_native_transport_with_four_ranks(gpu):
+    """`python bench.py --gpus 4 --transport native` on this box's one GPU, the collectives carried by the stand-in: the set-up the
+    driver's 8-GPU run goes through -- unique id handed over, all-gather and distributed-transform self-tests agreed on by all
+    ranks, sliced rounds -- and a line that explains itself (transport, per-rank breakdown with the exchanges)."""
+    import json
+    assert os.path.exists(MOCK)
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1", MH_RCCL_LIB=MOCK)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--transport", "native",
+                          "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 4 and rec["value"] > 0 and "slices" in rec["config"]["parallelism"], rec["config"]
+    assert rec["transport"]["kind"] == "native-rccl" and rec["transport"]["native_rccl"]["alltoall"] > 0, rec["transport"]
+    assert rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True, rec["proof"]
+    for r in rec["per_rank"]:
+        b = r["breakdown_ms_per_step"]
+        assert b["exchanges_per_step"] >= 11 and b["exchange_on_stream"] > 0 and b["exchange_host_wall"] > 0, r
