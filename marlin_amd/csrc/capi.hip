@@ -646,6 +646,20 @@ struct FbRun {
                        (const F::G1Aff30*)bs.d_table, (const u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr,
                        (const u32*)ws.pend.ptr, (const u32*)(d_max + 1), (F::G1Xyzz30*)ws.buckets.ptr, nb, (u64)WB);
     MH_HIP(hipGetLastError());
+    // the caller's independent work (Context::side_job) goes to stream2 behind the accumulation: beside the reduction that follows
+    if (c.side_job && s == c.stream && c.stream2 && c.side_ev[0] && c.side_ev[1]) {
+      MH_HIP(hipEventRecord(c.side_ev[0], s));
+      MH_HIP(hipStreamWaitEvent(c.stream2, c.side_ev[0], 0));
+      std::function<int()> job;
+      job.swap(c.side_job);                          // consumed, whatever it returns
+      hipStream_t main_stream = c.stream;
+      c.stream = c.stream2;
+      const int rc = job();
+      c.stream = main_stream;
+      MH_HIP(hipEventRecord(c.side_ev[1], c.stream2));
+      c.side_ran = true;
+      MH_TRY(rc);
+    }
     return MH_OK;
   }
 
@@ -1211,6 +1225,7 @@ int mh_init(int device_id) {
   for (auto& e : c.fb_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   MH_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
   MH_HIP(hipEventCreateWithFlags(&c.copy_ev, hipEventDisableTiming));
+  for (auto& e : c.side_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   c.device = device_id;
   c.num_simds = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
   c.inited = true;
@@ -1250,6 +1265,8 @@ int mh_shutdown(void) {
   for (auto& e : c.fb_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (c.copy_stream) { (void)hipStreamSynchronize(c.copy_stream); (void)hipStreamDestroy(c.copy_stream); c.copy_stream = nullptr; }
   if (c.copy_ev) { (void)hipEventDestroy(c.copy_ev); c.copy_ev = nullptr; }
+  for (auto& e : c.side_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  c.side_job = nullptr; c.side_ran = false;
   if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }
   for (auto& r : c.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   c.prof.clear();

@@ -2,6 +2,7 @@
 // twiddle table, scratch buffers, uploaded base sets, HIP-event profiling.
 #pragma once
 #include <cstdlib>
+#include <functional>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -127,6 +128,15 @@ struct Context {
   // totals of the fixed-base sort travel to the host while the split kernel runs), and the event that orders it
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_ev = nullptr;
+  // Work of the CALLER that does not depend on the batch's results, issued on stream2 the moment the batch's accumulation has
+  // been launched, behind an event recorded after it: it then runs beside the bucket reduction -- a latency chain at one wave per
+  // SIMD that leaves a third of the VALU's issue slots idle -- and through the host round trip that follows.  The prover hands
+  // over the three challenge-independent 4H transforms of round 2 this way during round 1's commitment (prover.hip).  The job is
+  // called with `stream` temporarily set to stream2; side_ev[1] marks its end.  A batch that never reaches the fixed-base
+  // accumulation (variable-base fallback) leaves the job untouched and the caller runs it itself.
+  std::function<int()> side_job;
+  hipEvent_t side_ev[2] = {nullptr, nullptr};
+  bool side_ran = false;
   uint64_t n_fb_groups = 0, n_vb_groups = 0;  // job groups that ran on the fixed-base / variable-base path
   Scratch tr_off[3], tr_cnt[2], tr_p[2], tr_sums, tr_ob, tr_pre, tr_prod, tr_scr;   // pair-tree accumulation
 

@@ -1496,10 +1496,34 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   MH_TRY(device_poly_rand(c, pk, zk, pk.mask.fr(), mask_len, S[0], (u32*)S[1]));
   hipLaunchKernelGGL(rng::mask_fix_kernel, dim3(1), dim3(1), 0, c.stream, pk.mask.fr(), (u64)H, (u64)mask_len);
   tr.mark("AHP::Prover::FirstRound (w, z_A, z_B, mask polys)");
+  // Three of round 2's five forward 4H transforms need no challenge: z_a and z_b (prover.rs:467) and z = w v_X + x
+  // (prover.rs:503-516, 534).  They are handed to the commitment's MSM batch as its side job (Context::side_job): issued on the
+  // second stream behind the bucket accumulation, they run beside the bucket reduction -- one wave per SIMD, a third of the
+  // issue slots idle -- and through the host round trip that brings the commitments back.  Same values, same buffers (S[0],
+  // S[1], S[7] -> S[2]; nothing else touches them before round 2).  Not with sliced rounds (the transforms are distributed
+  // there).  MH_SIDE_NTT=0: in their place in round 2.
+  const uint32_t lg4H = lgH + 2; const uint64_t H4 = 4 * H;
+  const uint64_t z_len = w_len + X;
+  static const bool side_ntt_env = [] { const char* e = getenv("MH_SIDE_NTT"); return !(e && atoi(e) == 0); }();
+  const bool side_ntt = side_ntt_env && !sliced;
+  auto early_transforms = [&]() -> int {
+    MH_TRY(ntt_device_len(c, pk.za.fr(), za_len, S[0], lg4H, 0));
+    MH_TRY(ntt_device_len(c, pk.zb.fr(), za_len, S[1], lg4H, 0));
+    { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::z_poly_kernel, z_len, S[7], (const Fr*)pk.w.fr(), (u64)w_len, (u64)X, (const Fr*)pk.xpoly.fr(), (u64)X); }
+    MH_TRY(ntt_device_len(c, S[7], z_len, S[2], lg4H, 0));
+    return MH_OK;
+  };
+  struct SideJobGuard { Context& c; ~SideJobGuard() { c.side_job = nullptr; } } side_guard{c};   // the job captures this frame
+  c.side_ran = false;
+  if (side_ntt) c.side_job = early_transforms;
   // PC::commit first round (lib.rs:172): w, z_a, z_b hiding 1; mask none
   std::vector<fsh::Commitment> cm1; std::vector<PolyRand> rd1;
   MH_TRY(marlin_commit(c, pk, {{pk.w.fr(), w_len, false, 0, true}, {pk.za.fr(), za_len, false, 0, true},
                                {pk.zb.fr(), za_len, false, 0, true}, {pk.mask.fr(), mask_len, false, 0, false}}, &zk, cm1, rd1));
+  if (side_ntt) {
+    if (c.side_ran) { MH_HIP(hipStreamWaitEvent(c.stream, c.side_ev[1], 0)); c.side_ran = false; }   // round 2 starts behind the side stream
+    else { c.side_job = nullptr; MH_TRY(early_transforms()); }                                       // the batch never took it (variable-base path)
+  }
   fsh::Commitment &c_w = cm1[0], &c_za = cm1[1], &c_zb = cm1[2], &c_mask = cm1[3];
   PolyRand &rd_w = rd1[0], &rd_za = rd1[1], &rd_zb = rd1[2];
   {
@@ -1515,12 +1539,11 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   HFr eta_a = fs.rand_fr(), eta_b = fs.rand_fr(), eta_c = fs.rand_fr();
 
   // ---------------- second round (prover.rs:443-570) ---------------------------------------------------------
-  const uint32_t lg4H = lgH + 2; const uint64_t H4 = 4 * H;
   const uint64_t H4loc = sliced ? H4 / Gs : H4;          // elements of a 4H-vector this rank works on
   if (sliced) {
     MH_TRY(ntt_dist_device(c, S[0], slice_c(c, S[0], pk.za.fr(), za_len), S[0], lg4H, 0));
     MH_TRY(ntt_dist_device(c, S[1], slice_c(c, S[1], pk.zb.fr(), za_len), S[1], lg4H, 0));
-  } else {
+  } else if (!side_ntt) {
   MH_TRY(ntt_device_len(c, pk.za.fr(), za_len, S[0], lg4H, 0));
   MH_TRY(ntt_device_len(c, pk.zb.fr(), za_len, S[1], lg4H, 0));
   }
@@ -1546,8 +1569,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     KLAUNCH(poly::t_sum_kernel, H, S[6], (const Fr*)partial2, (const u64*)pk.t_item_ptr.p, (u64)H); }
   MH_TRY(ntt_device(c, S[6], pk.t.fr(), lgH, 1));
   // z = w * v_X + x  (prover.rs:503-516)
-  const uint64_t z_len = w_len + X;
-  { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::z_poly_kernel, z_len, S[7], (const Fr*)pk.w.fr(), (u64)w_len, (u64)X, (const Fr*)pk.xpoly.fr(), (u64)X); }
+  if (!side_ntt) { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::z_poly_kernel, z_len, S[7], (const Fr*)pk.w.fr(), (u64)w_len, (u64)X, (const Fr*)pk.xpoly.fr(), (u64)X); }
   // q_1 (prover.rs:520-547): forward transforms on the 4H domain (summed_z_m's is known, see above), pointwise, one inverse
   const uint64_t h1_len = 2 * H;                                                // deg <= 2H + 2*zk_bound - 2 - ... (upper H coefficients are zero)
   if (sliced) {
@@ -1573,7 +1595,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   } else {
   MH_TRY(ntt_device_len(c, S[5], H, S[0], lg4H, 0));                                     // r_alpha
   // summed_z_m: already in S[1]
-  MH_TRY(ntt_device_len(c, S[7], z_len, S[2], lg4H, 0));                                 // z
+  if (!side_ntt) MH_TRY(ntt_device_len(c, S[7], z_len, S[2], lg4H, 0));                  // z (else: already there, beside round 1's commitment)
   MH_TRY(ntt_device_len(c, pk.t.fr(), H, S[4], lg4H, 0));                                // t
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_sub_mul_kernel, H4, S[0], (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2], (const Fr*)S[4], (u64)H4); }
   MH_TRY(ntt_device(c, S[0], S[1], lg4H, 1));                                  // rhs
