@@ -651,6 +651,7 @@ def main():
 
     # ---- roofline of the dominant kernel (MSM bucket accumulation), live HIP-event timing ----
     ntt_ms, ntt_launches = M.prof_get(0)
+    ntt_side_ms, _ = M.prof_get(6)      # the transforms that ran beside round 1's bucket reduction (their own family: concurrent with msm)
     msm_ms, _ = M.prof_get(1)
     glue_ms, _ = M.prof_get(3)
     stages_ms, _ = M.prof_get(4)      # sort + bucket reduction by themselves; they run beside the other half's accumulation
@@ -725,11 +726,12 @@ def main():
                         "(%d VALU instr per bucket addition, %d additions per pair), see roofline_valu and DESIGN.md; "
                         "NTT family: %.1f GB/s over the %s" % (
                             int(pair_bytes), sum(mix.values()), W_windows,
-                            (ntt_bytes * breakdown_steps) / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0, ntt_what)}
+                            (ntt_bytes * breakdown_steps) / ((ntt_ms + ntt_side_ms) * 1e-3) / 1e9 if ntt_ms > 0 else 0.0, ntt_what)}
 
     # ---- every rank's own view (a SCALE record has to explain itself): its wall time per step, its kernel families, and what
     # the exchanges cost it -- events on the library's stream around each collective (family 5) and the host's wall clock inside them
     exch_ms, exch_n = M.prof_get(5)
+    side_ms, _ = M.prof_get(6)          # transforms on the second stream beside round 1's bucket reduction: concurrent with `msm`
     exch_calls, exch_host_ms = (0, 0.0)
     if world > 1 or args.simulate_rank:
         from marlin_amd import dist as _MDx
@@ -774,6 +776,7 @@ def main():
                                   "msm_hidden_under_accum": round(max(0.0, acc_b_ms + stages_ms - msm_ms) / breakdown_steps, 3),
                                   "glue": round(glue_ms / breakdown_steps, 3),
                                   "exchange": round(exch_ms / breakdown_steps, 3),
+                                  "ntt_beside_msm_reduction": round(side_ms / breakdown_steps, 3),
                                   "host_and_other": round(breakdown_ms_per_step - (ntt_ms + msm_ms + glue_ms + exch_ms) / breakdown_steps, 3),
                                   "measured_on": ("the timed steps" if args.full_prof else
                                                   "%d further untimed proofs with events around every kernel family (%.3f ms each: the events cost "

@@ -346,7 +346,9 @@ int mh_marlin_get_poly(uint64_t pk, const char* label, uint64_t* out, size_t cap
 /* ---- profiling: accumulated HIP-event time per kernel family on the library stream ----
  * family: 0 = ntt passes, 1 = msm (wall time of the MSM groups, all stages), 2 = msm accum only, 3 = glue, 4 = the msm sort and
  * bucket-reduction stages by themselves, 5 = the exchanges of a sharded proof (events on the library's stream around each
- * collective; with a host-synchronising callback transport the host's wait is in mh_marlin_exchange_stats instead).
+ * collective; with a host-synchronising callback transport the host's wait is in mh_marlin_exchange_stats instead), 6 = work the
+ * prover runs on a second stream BESIDE an MSM batch's bucket reduction (the challenge-independent transforms of round 2 during
+ * round 1's commitment): concurrent with family 1, so families 0 + 1 + 3 + 5 still add up to the step.
  * mh_prof_enable(on): 0 = off, 1 = every family, any other value = a mask with bit (f + 1) set for each family f to record
  * (8 = the accumulate kernel only).  An event pair per scope is not free: ~90 scopes per proof cost ~1 ms of launch gaps, so a
  * timed run records the one family it needs (bench.py) and takes the full breakdown from untimed proofs.  */

@@ -654,7 +654,9 @@ struct FbRun {
       job.swap(c.side_job);                          // consumed, whatever it returns
       hipStream_t main_stream = c.stream;
       c.stream = c.stream2;
+      c.prof_override = PF_SIDE;
       const int rc = job();
+      c.prof_override = -1;
       c.stream = main_stream;
       MH_HIP(hipEventRecord(c.side_ev[1], c.stream2));
       c.side_ran = true;

@@ -86,7 +86,9 @@ struct G2Set { void* d_points = nullptr; size_t n = 0; };   // G2Affine[n] (x.c0
 // stages by themselves, on whichever stream they ran (they overlap the accumulation of the other sub-batch)
 // PF_EXCHANGE: the collectives of a sharded proof (all-gather of partial points, all-to-all of the distributed transforms, all-gather of
 // round polynomials), events on the library's stream around each
-enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_MSM_STAGES = 4, PF_EXCHANGE = 5, PF_COUNT = 6 };
+// PF_SIDE: whatever a side job (Context::side_job) runs on the second stream beside an MSM batch's bucket reduction -- kept apart from
+// its own family so that the families of the main stream still add up to the step
+enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_MSM_STAGES = 4, PF_EXCHANGE = 5, PF_SIDE = 6, PF_COUNT = 7 };
 
 struct ProfRec { int family; hipEvent_t a, b; };
 
@@ -143,10 +145,11 @@ struct Context {
   // profiling
   bool prof_on = false;
   unsigned prof_mask = ~0u;            // families whose scopes record events (mh_prof_enable)
+  int prof_override = -1;              // >= 0: every scope opened meanwhile records under this family (side jobs: PF_SIDE)
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
-  double prof_ms[PF_COUNT] = {0, 0, 0, 0, 0, 0};
-  uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0, 0, 0};
+  double prof_ms[PF_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 Context& ctx();
@@ -156,7 +159,7 @@ struct ProfScope {
   int fam;
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t st;
-  ProfScope(Context& c_, int fam_, hipStream_t s_ = nullptr) : c(c_), fam(fam_), st(s_ ? s_ : c_.stream) {
+  ProfScope(Context& c_, int fam_, hipStream_t s_ = nullptr) : c(c_), fam(c_.prof_override >= 0 ? c_.prof_override : fam_), st(s_ ? s_ : c_.stream) {
     if (!c.prof_on || !((c.prof_mask >> fam) & 1u)) return;
     auto get = [&]() { hipEvent_t e; if (!c.ev_pool.empty()) { e = c.ev_pool.back(); c.ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
     a = get(); b = get();
