@@ -530,7 +530,16 @@ def main():
             sr, sg = (int(x) for x in args.simulate_rank.split("/"))
             if sg < 4:
                 args.no_sliced = True               # the library keeps the rounds replicated below 4 ranks
-            if args.no_sliced:
+            if args.transport == "native":
+                # the native transport's own code path without peers: the stand-in for librccl in its solo mode turns every
+                # collective into a stream-ordered local copy issued from C++ (no Python in the exchange, unlike the callbacks below)
+                mock = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+                if not os.path.exists(mock):
+                    sys.exit("bench.py: --simulate-rank with --transport native needs tests/mock_rccl/libmock_rccl.so (build())")
+                os.environ["MH_RCCL_LIB"] = mock
+                os.environ["MH_MOCK_RCCL_SOLO"] = "1"
+                MD.enable_native_rccl_solo(sr, sg, sliced=not args.no_sliced)
+            elif args.no_sliced:
                 MD.enable_simulated_shard(sr, sg)
             else:
                 MD.enable_simulated_alltoall(sr, sg, stream_ordered=not os.environ.get("BENCH_SIM_SYNC_EXCHANGE"))
@@ -752,7 +761,9 @@ def main():
     if workload == "marlin-prove" and (world > 1 or args.simulate_rank):
         from marlin_amd import dist as _MDx
         ni = _MDx.native_rccl_info()
-        transport_info = {"kind": transport if world > 1 else "simulated (local copies)", "native_rccl": ni if ni["active"] else None}
+        transport_info = {"kind": transport if world > 1 else ("simulated: native transport over the solo stand-in (local copies issued from C++)"
+                                                               if ni["active"] else "simulated: Python callbacks (local copies)"),
+                          "native_rccl": ni if ni["active"] else None}
 
     out = {
         "metric": "marlin_prove_constraints_per_sec", "value": round(value, 1), "unit": "constraints/s",

@@ -161,6 +161,19 @@ def enable_native_rccl(dist=None, sliced=True):
     return True
 
 
+def enable_native_rccl_solo(rank, world, sliced=True):
+    """MEASUREMENT ONLY (bench.py --simulate-rank R/G --transport native): the native transport as rank `rank` of `world` without
+    peers, over the stand-in for librccl in its solo mode (tests/mock_rccl/: MH_RCCL_LIB must point at it and MH_MOCK_RCCL_SOLO=1
+    be set before the first call): every collective is a stream-ordered local copy issued from C++ -- what the native transport
+    costs one rank's host, with no interpreter in the path.  Proofs made this way are not valid."""
+    lib = _lib.load()
+    ident = np.zeros(128, dtype=np.uint8)
+    _lib.check(lib.mh_rccl_unique_id(ident.ctypes.data), "mh_rccl_unique_id")
+    _lib.check(lib.mh_marlin_set_rccl(int(rank), int(world), ident.ctypes.data), "mh_marlin_set_rccl")
+    if not sliced:
+        _lib.check(lib.mh_marlin_rccl_sliced(0), "mh_marlin_rccl_sliced")
+
+
 def native_rccl_info():
     """{"active", "allgather_host", "alltoall", "allgather_dev", "bytes_sent", "librccl"} of the native transport."""
     lib = _lib.load()

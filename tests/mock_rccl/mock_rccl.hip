@@ -22,7 +22,7 @@ typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2,
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
 struct Header { std::atomic<uint32_t> arrived; std::atomic<uint32_t> generation; std::atomic<uint32_t> attached; uint32_t nranks; };
-struct ncclComm { int rank, nranks; size_t slot; char name[64]; Header* hdr; char* slots; size_t map_bytes; };
+struct ncclComm { int rank, nranks; size_t slot; char name[64]; Header* hdr; char* slots; size_t map_bytes; bool solo; void* filled[16]; size_t filled_bytes[16]; };
 typedef ncclComm* ncclComm_t;
 
 static const size_t kSlot = 96ull << 20;        // per rank: the largest payload a test moves is a few MB
@@ -43,10 +43,33 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
   snprintf(id->internal, sizeof(id->internal), "/mh_mock_rccl_%d_%ld", (int)getpid(), (long)random());
   return ncclSuccess;
 }
+// MH_MOCK_RCCL_SOLO=1 (MEASUREMENT ONLY, bench.py --simulate-rank R/G --transport native): this process is rank R of G WITHOUT
+// peers.  A collective is then a stream-ordered local copy of the caller's own chunk into its slot -- what the native transport
+// costs the HOST of one rank, with no interpreter and no synchronisation, on the one GPU of a lease.  Small payloads (the partial
+// points) are replicated into every slot; the foreign slots of large receive buffers are filled ONCE with pseudo-random field
+// elements, so that what the prover feeds to its MSMs afterwards has realistic digits.  Results are meaningless; timings are not.
+static bool solo_mode() { const char* e = getenv("MH_MOCK_RCCL_SOLO"); return e && atoi(e) == 1; }
+static ncclResult_t solo_fill(ncclComm* c, void* recv, size_t total) {
+  for (int i = 0; i < 16; i++) if (c->filled[i] == recv && c->filled_bytes[i] >= total) return ncclSuccess;
+  uint64_t* h = (uint64_t*)malloc(total + 32);
+  if (!h) return ncclSystemError;
+  uint64_t x = 0x9e3779b97f4a7c15ull ^ (uint64_t)total;
+  for (size_t i = 0; i < total / 8; i++) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    h[i] = (i & 3) == 3 ? (x & ((1ull << 60) - 1)) : x;       // the top word of every 32-byte element below 2^60: a valid Fr
+  }
+  const hipError_t e = hipMemcpy(recv, h, total, hipMemcpyHostToDevice);
+  free(h);
+  if (e != hipSuccess) return ncclUnhandledCudaError;
+  static int next = 0;
+  c->filled[next & 15] = recv; c->filled_bytes[next & 15] = total; next++;
+  return ncclSuccess;
+}
 ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int rank) {
   if (!out || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
   ncclComm* c = new ncclComm();
   c->rank = rank; c->nranks = nranks; c->slot = kSlot;
+  if (solo_mode()) { c->solo = true; c->hdr = nullptr; memset(c->filled, 0, sizeof(c->filled)); *out = c; return ncclSuccess; }
   snprintf(c->name, sizeof(c->name), "%s", id.internal);
   c->map_bytes = 4096 + (size_t)nranks * kSlot;
   int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
@@ -64,6 +87,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
 }
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
   if (!c) return ncclSuccess;
+  if (c->solo) { delete c; return ncclSuccess; }
   munmap((void*)c->hdr, c->map_bytes);
   if (c->rank == 0) shm_unlink(c->name);
   delete c;
@@ -74,6 +98,15 @@ const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no e
 ncclResult_t ncclGetVersion(int* v) { if (v) *v = 0; return ncclSuccess; }
 
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t c, hipStream_t s) {
+  if (c->solo) {
+    if (count <= (64u << 10)) {                 // partial points: the own chunk in every slot
+      for (int p = 0; p < c->nranks; p++)
+        if (hipMemcpyAsync((char*)recv + (size_t)p * count, send, count, hipMemcpyDeviceToDevice, s) != hipSuccess) return ncclUnhandledCudaError;
+      return ncclSuccess;
+    }
+    if (solo_fill(c, recv, count * c->nranks) != ncclSuccess) return ncclUnhandledCudaError;
+    return hipMemcpyAsync((char*)recv + (size_t)c->rank * count, send, count, hipMemcpyDeviceToDevice, s) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+  }
   if (count > c->slot) return ncclInvalidArgument;
   if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slots + (size_t)c->rank * c->slot, send, count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
@@ -84,6 +117,11 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
   return ncclSuccess;
 }
 ncclResult_t ncclAllToAll(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t c, hipStream_t s) {
+  if (c->solo) {
+    if (solo_fill(c, recv, count * c->nranks) != ncclSuccess) return ncclUnhandledCudaError;
+    const size_t off = (size_t)c->rank * count;
+    return hipMemcpyAsync((char*)recv + off, (const char*)send + off, count, hipMemcpyDeviceToDevice, s) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+  }
   if (count * (size_t)c->nranks > c->slot) return ncclInvalidArgument;
   if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slots + (size_t)c->rank * c->slot, send, count * c->nranks, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;

@@ -197,20 +197,27 @@ def test_native_transport_at_n_ranks_gives_the_single_gpu_proof(gpu, tmp_path, w
             assert a2a == 0 and ag_dev == 0
 
 
-def test_bench_native_transport_with_four_ranks(gpu):
-    """`python bench.py --gpus 4 --transport native` on this box's one GPU, the collectives carried by the stand-in: the set-up the
-    driver's 8-GPU run goes through -- unique id handed over, all-gather and distributed-transform self-tests agreed on by all
-    ranks, sliced rounds -- and a line that explains itself (transport, per-rank breakdown with the exchanges)."""
+@pytest.mark.parametrize("world,log_n", [(4, 14), (8, 16), (2, 14)])
+def test_bench_native_transport_with_n_ranks(gpu, world, log_n):
+    """`python bench.py --gpus N --transport native` (N = 2, 4, 8) on this box's one GPU, the collectives carried by the stand-in:
+    the set-up the driver's 8-GPU run goes through -- unique id handed over, all-gather and distributed-transform self-tests
+    agreed on by all ranks, sliced rounds from 4 ranks on -- and a line that explains itself (transport, per-rank breakdown with
+    the exchanges, every rank holding the one-GPU proof)."""
     import json
     assert os.path.exists(MOCK)
     env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1", MH_RCCL_LIB=MOCK)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--transport", "native",
-                          "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--transport", "native",
+                          "--log-constraints", str(log_n), "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert rec["n_gpus"] == 4 and rec["value"] > 0 and "slices" in rec["config"]["parallelism"], rec["config"]
+    assert rec["n_gpus"] == world and rec["value"] > 0 and len(rec["per_rank"]) == world
+    assert rec["transport"]["kind"] == "native-rccl" and rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True, (rec["transport"], rec["proof"])
+    if world < 4:                                         # 2 ranks: the rounds stay replicated (the exchanges would cost more than they save)
+        assert "replicated" in rec["config"]["parallelism"] and rec["transport"]["native_rccl"]["alltoall"] == 0
+        return
+    assert "slices" in rec["config"]["parallelism"], rec["config"]
     assert rec["transport"]["kind"] == "native-rccl" and rec["transport"]["native_rccl"]["alltoall"] > 0, rec["transport"]
     assert rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True, rec["proof"]
     for r in rec["per_rank"]:

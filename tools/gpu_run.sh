@@ -8,7 +8,8 @@
 #   bench        the default bench line (2^20, BLS12-381, MarlinKZG10, CPU baseline at the same size, seam route)
 #   profile      tools/profile.sh <tag>: rocprofv3 kernel stats, accumulate dispatches, PMC traffic
 #   sq           tools/profile_sq.sh <tag>: SQ wave-cycle breakdown of the accumulate kernel
-#   sims         one rank of 2 / 4 / 8 simulated on this GPU at 2^20, one of 8 at 2^22
+#   sims         one rank of 2 / 4 / 8 simulated on this GPU at 2^20, one of 8 at 2^22 (exchanges: Python callbacks making local copies)
+#   sims_native  the same through the native transport (local copies issued from C++ by the solo stand-in for librccl)
 #   configs      the other BASELINE configurations (2^16 Sonic, 2^18, 2^22, BLS Sonic, BN254 Marlin / Sonic)
 #   small        the reference's own bench shape (2^16, SonicKZG10) with a kernel trace of the last prove and its gap analysis
 #   seam         the seam route (host pointers), with and without the short uploads of mh_ntt_len
@@ -46,6 +47,10 @@ for R in "$@"; do
       $B --simulate-rank 1/2 > $O/sim_1_2.json 2>/dev/null; $B --simulate-rank 3/4 > $O/sim_3_4.json 2>/dev/null
       $B --simulate-rank 5/8 > $O/sim_5_8.json 2>/dev/null; $B --log-constraints 22 --simulate-rank 3/8 > $O/sim_3_8_2p22.json 2>/dev/null
       line $O/sim_*.json ;;
+    sims_native)    # the same ranks through the native transport's own code path (solo stand-in: local copies issued from C++)
+      $B --transport native --simulate-rank 1/2 > $O/simn_1_2.json 2>/dev/null; $B --transport native --simulate-rank 3/4 > $O/simn_3_4.json 2>/dev/null
+      $B --transport native --simulate-rank 5/8 > $O/simn_5_8.json 2>/dev/null; $B --transport native --log-constraints 22 --simulate-rank 3/8 > $O/simn_3_8_2p22.json 2>/dev/null
+      line $O/simn_*.json ;;
     configs)
       $B --log-constraints 16 --pc sonic --steps 20 > $O/bench_reference_shape_2p16_sonickzg10.json 2>/dev/null
       $B --log-constraints 18 > $O/bench_2p18.json 2>/dev/null
