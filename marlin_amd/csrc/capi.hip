@@ -562,11 +562,19 @@ struct FbRun {
     }
     // the pinned copies are reused by the next group only after this group's finish() has synchronised the stream
     MH_TRY(ws.h_desc.ensure((size_t)WT * sizeof(msmfb::FbWin))); MH_TRY(ws.h_blk.ensure(blk.size() * sizeof(F::FbBlk) + 8));
+    // descriptors and block list go up on the copy stream as well (nothing on `s` reads them before the hist kernel, and the split
+    // kernel that is still running does not either): `s` only waits for the event behind them, so the hist kernel starts when the
+    // split ends instead of behind two more copies
+    hipStream_t up = side_copy ? c.copy_stream : s;
     memcpy(ws.h_desc.ptr, desc.data(), (size_t)WT * sizeof(msmfb::FbWin));
-    MH_HIP(hipMemcpyAsync(ws.desc.ptr, ws.h_desc.ptr, (size_t)WT * sizeof(msmfb::FbWin), hipMemcpyHostToDevice, s));
+    MH_HIP(hipMemcpyAsync(ws.desc.ptr, ws.h_desc.ptr, (size_t)WT * sizeof(msmfb::FbWin), hipMemcpyHostToDevice, up));
     if (grid_tiles) {
       memcpy(ws.h_blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk));
-      MH_HIP(hipMemcpyAsync(ws.blk.ptr, ws.h_blk.ptr, blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
+      MH_HIP(hipMemcpyAsync(ws.blk.ptr, ws.h_blk.ptr, blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, up));
+    }
+    if (side_copy) {
+      MH_HIP(hipEventRecord(c.copy_ev, c.copy_stream));
+      MH_HIP(hipStreamWaitEvent(s, c.copy_ev, 0));
     }
     const msmfb::FbWin* fbw = (const msmfb::FbWin*)ws.desc.ptr;
     const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;

@@ -8,10 +8,15 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "spmv" in r["Kernel_Name"]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 pr = rows[starts[-2 * k]:(starts[-2 * (k - 1)] if k > 1 else len(rows))]
+# Dispatches overlap since round 4 (copies on the copy stream beside the split kernel, transforms on the second stream beside the
+# bucket reduction): a gap is time in which NOTHING runs -- from the latest end seen so far to the next start.
 gaps = []
-for a, b in zip(pr, pr[1:]):
-    g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3      # us
-    gaps.append((max(g, 0.0), a["Kernel_Name"].split("(")[0][-40:], b["Kernel_Name"].split("(")[0][-40:]))
+latest_end, latest = int(pr[0]["End_Timestamp"]), pr[0]
+for b in pr[1:]:
+    g = (int(b["Start_Timestamp"]) - latest_end) / 1e3      # us
+    gaps.append((max(g, 0.0), latest["Kernel_Name"].split("(")[0][-40:], b["Kernel_Name"].split("(")[0][-40:]))
+    if int(b["End_Timestamp"]) > latest_end:
+        latest_end, latest = int(b["End_Timestamp"]), b
 tot = sum(g for g, _, _ in gaps)
 span = (int(pr[-1]["End_Timestamp"]) - int(pr[0]["Start_Timestamp"])) / 1e3
 print("dispatches %d, span %.1f us, idle between dispatches %.1f us" % (len(pr), span, tot))
@@ -25,8 +30,10 @@ for g, a, b in sorted(gaps, reverse=True)[:25]:
 # the same gaps in dispatch order with their neighbourhood (which phase of the prove each host round trip belongs to)
 print("gaps >= 15 us in order (index, us, two kernels before -> two after):")
 short = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "")[-34:]
+latest_end = int(pr[0]["End_Timestamp"])
 for i, (a, b) in enumerate(zip(pr, pr[1:])):
-    g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3
+    latest_end = max(latest_end, int(a["End_Timestamp"]))
+    g = (int(b["Start_Timestamp"]) - latest_end) / 1e3
     if g >= 15:
         before = " | ".join(short(r) for r in pr[max(0, i - 1):i + 1])
         after = " | ".join(short(r) for r in pr[i + 1:i + 3])
