@@ -134,3 +134,25 @@ def test_zkstream_numpy_matches_sequential_oracle():
     assert np_to_fr(d["mask"]) == mask
     for name in ("blind_w", "blind_za", "blind_zb", "blind_g1", "blind_g1_shifted"):
         assert d[name] == [FS.fr_rand(r) for _ in range(3)]
+
+
+def test_workload_inventories_are_consistent():
+    """marlin_amd/workload.py restates SURVEY Appendix A as data (bench.py, the CPU baseline and the seam route all run these
+    lists): 30 transforms / 15 MSMs of the reference against the 16 / 13 the prover executes, and -- for the seam -- how many
+    elements each transform's Vec holds BEFORE ark-poly zero-pads it (mh_ntt_len uploads only those)."""
+    from marlin_amd import workload as W
+    for lg in (10, 16, 20):
+        H = 1 << lg
+        K = 4 * H
+        inv, ex, lens = W.ntt_inventory(H), W.ntt_executed(H), W.ntt_input_lengths(H)
+        assert len(inv) == 30 and len(ex) == 16 and len(lens) == 30
+        assert all(0 < l <= (1 << lg_n) for l, (lg_n, _, _) in zip(lens, inv))
+        # inverse transforms arrive full; at least the nine `const * v_H` factors and the z_a z_b / q_1 / b f factors arrive short
+        assert all(l == (1 << lg_n) for l, (lg_n, inverse, _) in zip(lens, inv) if inverse)
+        assert sum(1 for l, (lg_n, inverse, _) in zip(lens, inv) if not inverse and l < (1 << lg_n)) >= 14
+        up, full = sum(32 * l for l in lens), sum(32 << lg_n for lg_n, _, _ in inv)
+        assert 0.55 < up / full < 0.65                       # 1.78 GB instead of 2.95 GB at 2^20
+        big, small = W.msm_inventory(H)
+        assert len(big) == 15 and len(W.msm_executed(H)) == 13 and len(W.msm_executed(H, pc="sonic")) == 11
+        assert sum(n for n, _ in W.msm_executed(H)) < sum(n for n, _ in big)
+        assert W.executed_ntt_bytes(H) < W.algorithmic_bytes(H)[0]
