@@ -114,6 +114,10 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
   for (int p = 0; p < c->nranks; p++)
     if (hipMemcpy((char*)recv + (size_t)p * count, c->slots + (size_t)p * c->slot, count, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
   barrier(c);                        // nobody overwrites a slot before every rank has read it
+  // MH_MOCK_RCCL_CORRUPT_RANK=<r>: rank r receives a damaged byte -- lets a test see a transport self-test FAIL on one rank
+  // and the caller fall back on all of them
+  if (const char* e = getenv("MH_MOCK_RCCL_CORRUPT_RANK"))
+    if (atoi(e) == c->rank && hipMemset(recv, 0xA5, 1) != hipSuccess) return ncclUnhandledCudaError;
   return ncclSuccess;
 }
 ncclResult_t ncclAllToAll(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t c, hipStream_t s) {

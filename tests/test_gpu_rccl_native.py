@@ -223,3 +223,20 @@ def test_bench_native_transport_with_n_ranks(gpu, world, log_n):
     for r in rec["per_rank"]:
         b = r["breakdown_ms_per_step"]
         assert b["exchanges_per_step"] >= 11 and b["exchange_on_stream"] > 0 and b["exchange_host_wall"] > 0, r
+
+
+def test_bench_falls_back_to_the_callbacks_when_one_rank_fails_the_native_self_test(gpu):
+    """The stand-in damages what rank 1 receives: the native all-gather self-test fails THERE only, the ranks agree on the outcome
+    (all-reduce MIN) before anyone enters another collective, every rank tears the native transport down and the run proceeds on
+    the torch.distributed callbacks -- a line with the right proof instead of a hang or a wrong commitment."""
+    import json
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1", MH_RCCL_LIB=MOCK, MH_MOCK_RCCL_CORRUPT_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--transport", "native",
+                          "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "native RCCL transport unavailable" in out.stderr
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["transport"]["kind"] == "callback-torch.distributed-gloo" and rec["transport"]["native_rccl"] is None, rec["transport"]
+    assert rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True and "slices" in rec["config"]["parallelism"]
