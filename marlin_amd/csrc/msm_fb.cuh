@@ -439,14 +439,9 @@ __device__ __forceinline__ X30 x30_from_std(const G1Xyzz& a) {
   r.x = f30_from_fq(a.x); r.y = f30_from_fq(a.y); r.zz = f30_from_fq(a.zz); r.zzz = f30_from_fq(a.zzz);
   return r;
 }
-// complete addition through the standard representation: the rare equal-x cases
-__device__ __noinline__ void x30_add_slow(X30& acc, const X30& b) {
-  G1Xyzz a = x30_to_std(acc), bb = x30_to_std(b);
-  g1_add(a, bb);
-  acc = x30_from_std(a);
-}
 // acc += b   [EFD add-2008-s]  12M + 2S
 __device__ __forceinline__ void x30_add_inl(X30& acc, const X30& b);
+__device__ __noinline__ void x30_dbl(X30& a);
 __device__ __noinline__ void x30_add(X30& acc, const X30& b) { x30_add_inl(acc, b); }
 __device__ __forceinline__ void x30_add_inl(X30& acc, const X30& b) {
   if (x30_is_identity(b)) return;
@@ -454,8 +449,11 @@ __device__ __forceinline__ void x30_add_inl(X30& acc, const X30& b) {
   const Fq30 U1 = f30_mul(acc.x, b.zz);
   const Fq30 S1 = f30_mul(acc.y, b.zzz);
   const Fq30 P = f30_sub<2>(f30_mul(b.x, acc.zz), U1);
-  if (__builtin_expect(f30_is_zero(P), 0)) { x30_add_slow(acc, b); return; }
   const Fq30 R = f30_sub<2>(f30_mul(b.y, acc.zzz), S1);
+  if (__builtin_expect(f30_is_zero(P), 0)) {            // equal x: the same point (doubling) or opposite points (see x30_add_ilp_inl)
+    if (f30_is_zero(R)) x30_dbl(acc); else acc = x30_identity();
+    return;
+  }
   Fq30 PP = f30_sqr(P);
   const Fq30 Q = f30_mul(U1, PP);
   acc.zz = f30_mul(f30_mul(acc.zz, b.zz), PP);
@@ -491,6 +489,7 @@ __device__ __noinline__ void x30_dbl(X30& a) {
 // 64-KB instruction cache were the limit -- costs 3.3 ms per proof: the operands travel through scratch.)  Same values mod p (Y3 is taken
 // as ONE reduction of R (Q - X3) + (2p - S1) PPP, so its lazy representative differs from x30_add's: compared through the
 // canonical form by mh_selftest_fq30; bounds: X <= 6.2, Y <= 1.2, ZZ, ZZZ <= 1.1).
+__device__ __noinline__ void x30_dbl_ilp(X30& a);
 __device__ __forceinline__ void x30_add_ilp_inl(X30& acc, const X30& b) {
   if (x30_is_identity(b)) return;
   if (x30_is_identity(acc)) { acc = b; return; }
@@ -498,8 +497,16 @@ __device__ __forceinline__ void x30_add_ilp_inl(X30& acc, const X30& b) {
   f30_mul_x3(U1, acc.x, b.zz, S1, acc.y, b.zzz, ZZ12, acc.zz, b.zz);
   f30_mul_x3(U2, b.x, acc.zz, S2, b.y, acc.zzz, ZZZ12, acc.zzz, b.zzz);
   const Fq30 P = f30_sub<2>(U2, U1);
-  if (__builtin_expect(f30_is_zero(P), 0)) { x30_add_slow(acc, b); return; }
   const Fq30 R = f30_sub<2>(S2, S1);
+  // Equal x is NOT rare in the bucket reduction: with an empty bucket right after a segment's first non-empty one the running sum
+  // and the accumulator are the same point (acc = running = B), and acc += running is a doubling -- at 2^16 a quarter of the
+  // waves of an H-sized job meet one.  Round 3 sent these through the complete law in the 32-bit representation (four
+  // conversions each way around g1_add, ~5 additions' time, with the whole wave waiting); here the two cases are told apart
+  // by R -- same point: the 30-bit doubling; opposite points: the identity.
+  if (__builtin_expect(f30_is_zero(P), 0)) {
+    if (f30_is_zero(R)) x30_dbl_ilp(acc); else acc = x30_identity();
+    return;
+  }
   Fq30 PP, RR;
   f30_sqr_x2(PP, P, RR, R);
   Fq30 Q, PPP;
@@ -795,7 +802,7 @@ __global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ 
     X30 s30 = p30; x30_add(s30, q30);
     G1Xyzz ss = x30_to_std(s30);
     same(ss.x, s.x); same(ss.y, s.y); same(ss.zz, s.zz); same(ss.zzz, s.zzz);
-    // equal x: the slow path (doubling)
+    // equal x with equal y: the doubling inside the addition
     X30 e30 = p30; x30_add(e30, p30);
     G1Xyzz es = x30_to_std(e30);
     same(es.x, d.x); same(es.y, d.y); same(es.zz, d.zz); same(es.zzz, d.zzz);

@@ -87,10 +87,12 @@ __device__ __forceinline__ X30 q30_gather(const Fq30& a) {
 __device__ __forceinline__ Fq30 q30_pick(const X30& p, u32 role) {
   return fsel(role == 0, p.x, fsel(role == 1, p.y, fsel(role == 2, p.zz, p.zzz)));
 }
-// the rare equal-x case: every lane of the quad runs the complete addition on the whole points
+// the equal-x case (the same point, or opposite points): every lane of the quad treats the whole points the way the one-lane law
+// does (x30_add_inl: the 30-bit doubling, or the identity) -- limb for limb the same result
 __device__ __noinline__ void q30_add_slow(Fq30& a, const Fq30& b, u32 role) {
   X30 A = q30_gather(a), B = q30_gather(b);
-  x30_add_slow(A, B);
+  const Fq30 R = f30_sub<2>(f30_mul(B.y, A.zzz), f30_mul(A.y, B.zzz));
+  if (f30_is_zero(R)) x30_dbl(A); else A = x30_identity();
   a = q30_pick(A, role);
 }
 
