@@ -824,17 +824,21 @@ static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* 
 }
 
 // Build the window table of a base set: level j = 2^{start_j} * P (c-bit windows tiling 256 bits), affine.
-// Automatic window width: lg(n) - 1, at most 20 (measured on the prover: 2^20-point SRS 51.0 / 42.4 / 40.7 / 44.4 ms per
-// proof at c = 16 / 18 / 19 / 20; 2^22-point SRS 115.8 / 113.2 ms at c = 19 / 20).  Multi-GPU proving shards every MSM by
-// bucket range, which leaves the width alone.
+// Automatic window width: lg(n) up to 2^18 points, lg(n) - 1 above, at most 20 (measured on the prover: 2^20-point SRS 51.0 /
+// 42.4 / 40.7 / 44.4 ms per proof at c = 16 / 18 / 19 / 20; 2^22-point SRS 115.8 / 113.2 ms at c = 19 / 20).  Multi-GPU proving
+// shards every MSM by bucket range, which leaves the width alone.
 static uint32_t auto_window_bits(size_t n) {
   static const int env_c = [] { const char* e = getenv("MH_FB_C"); return e ? atoi(e) : 0; }();
   if (env_c) return (uint32_t)env_c;
   size_t eff = n;
   u32 lg = 0;
   while ((1ull << lg) < eff) lg++;
-  int cc = (int)lg - 1;
-  if (cc == 17) cc = 18;               // 17 tiles 256 bits with 16 windows of 16 bits: same digits as 16, twice the buckets
+  // Round 4 sweep with the reduction's equal-x doublings fixed (profiles/r04w_window_width_sweep_small_sizes.txt): below 2^19 points
+  // the best width is lg(n) itself, not lg(n) - 1 -- at these sizes a bucket thread's chain of additions and the lone wave per
+  // SIMD are what costs, and twice the buckets halve the chains (2^14 constraints: 10.5 -> 7.3 ms per proof, 2^12: 8.4 -> 7.4,
+  // 2^10: 8.8 -> 6.5); one more bit underloads the H-sized jobs, which then leave for the variable-base path (2^14: 14.7 ms).
+  int cc = lg <= 18 ? (int)lg : (int)lg - 1;
+  if (cc == 17) cc = 16;               // 17 tiles 256 bits with 16 windows of 16 bits: same digits as 16, twice the buckets
   return (uint32_t)(cc > msmfb::MAX_C ? msmfb::MAX_C : (cc < 8 ? 8 : cc));
 }
 
