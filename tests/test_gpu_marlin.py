@@ -96,9 +96,9 @@ def test_full_size_proof_verifies(gpu, log_n):
     ncp, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
     pk = GM.index(srs, ncp, ni, mats)
     assert (pk.H, pk.K) == (n, 4 * n)
-    # the index built the fixed-base window table for powers_of_g (width lg(n_srs) - 1, at most 20) ...
-    want_c = min(20, (srs.max_degree + 1).bit_length() - 1 - 1 + (0 if (srs.max_degree + 1) & srs.max_degree == 0 else 1))
-    assert srs.powers_of_g.table_info()[0] == (18 if want_c == 17 else want_c)   # 17 would tile 256 bits like 16 with twice the buckets
+    # the index built the fixed-base window table for powers_of_g (automatic width) ...
+    from tests.util import auto_window_bits
+    assert srs.powers_of_g.table_info()[0] == auto_window_bits(srs.max_degree + 1)
     fb0, vb0 = gpu.msm_path_counts()
     proof = GM.prove(pk, inst, wit, SEED)
     # ... and every MSM batch of the proof ran on it: three commit rounds and the openings, no variable-base group

@@ -233,7 +233,7 @@ def test_msm_fixed_base_offsets_batch_and_edges(gpu, bases4k):
 
 
 def test_fixed_base_table_info_and_shard_resize(gpu, bases4k):
-    """automatic window width = lg(n) - 1 (<= 20), 128-byte table points; mh_marlin_set_shard leaves the tables alone
+    """automatic window width (lg(n) below 2^19 points, lg(n) - 1 above, <= 20), 128-byte table points; mh_marlin_set_shard leaves the tables alone
     (the prover shards by bucket range, the window width does not depend on the number of ranks) and a plain mh_msm
     is never sharded: results do not change."""
     import ctypes as C
@@ -247,7 +247,9 @@ def test_fixed_base_table_info_and_shard_resize(gpu, bases4k):
     B.precompute()
     c, w, nbytes = B.table_info()
     pt = 128 if F.FQ_LIMBS64 == 6 else 96
-    assert (c, w, nbytes) == (14, (256 + 13) // 14, ((256 + 13) // 14) * n * pt)
+    from tests.util import auto_window_bits
+    c0 = auto_window_bits(n)
+    assert c0 == 15 and (c, w, nbytes) == (c0, (256 + c0 - 1) // c0, ((256 + c0 - 1) // c0) * n * pt)
     Bx = gpu.Bases(big).precompute(9)
     sc = rand_fr(n, 4242)
     want = EC.scalar_mul(EC.G1_GEN, sum(s * a for s, a in zip(sc, dlb)) % F.R_MOD)
@@ -257,11 +259,11 @@ def test_fixed_base_table_info_and_shard_resize(gpu, bases4k):
     cb = cb_t(lambda *a: -1)                       # never called: plain mh_msm does not shard
     try:
         _lib.check(L.mh_marlin_set_shard(0, 4, C.cast(cb, C.c_void_p), None), "mh_marlin_set_shard")
-        assert B.table_info()[0] == 14 and Bx.table_info()[0] == 9
+        assert B.table_info()[0] == c0 and Bx.table_info()[0] == 9
         assert jac_np_to_affine(gpu.msm(B, fr_to_np(sc))) == want
     finally:
         _lib.check(L.mh_marlin_set_shard(0, 1, None, None), "mh_marlin_set_shard")
-    assert B.table_info()[0] == 14
+    assert B.table_info()[0] == c0
 
 
 def test_msm_fixed_base_jobs_sharing_scalars(gpu, bases4k):

@@ -62,7 +62,7 @@ def test_commit_full_size_properties(gpu, log_n):
 @pytest.mark.parametrize("log_n", [13, 20, 22])
 def test_fixed_base_commit_full_size(gpu, log_n):
     """the same known-tau and linearity properties through the fixed-base path (window table with the automatic width:
-    12 / 19 / 20 bits), plus equality with the variable-base result on dense scalars and on a vector with a long zero
+    13 / 19 / 20 bits), plus equality with the variable-base result on dense scalars and on a vector with a long zero
     gap (the shape of an opening proof's merged witness)."""
     n = 1 << log_n
     r = F.R_MOD
@@ -74,7 +74,8 @@ def test_fixed_base_commit_full_size(gpu, log_n):
     vb_full = jac_np_to_affine(gpu.msm(B, sc, montgomery=False))
     vb_gap = jac_np_to_affine(gpu.msm(B, gap, montgomery=False))
     B.precompute()
-    assert B.table_info()[0] == min(20, log_n - 1)
+    from tests.util import auto_window_bits
+    assert B.table_info()[0] == auto_window_bits(n)
     fb0, vb0 = gpu.msm_path_counts()
     assert jac_np_to_affine(gpu.msm(B, sc, montgomery=False)) == vb_full
     assert jac_np_to_affine(gpu.msm(B, gap, montgomery=False)) == vb_gap

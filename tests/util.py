@@ -82,3 +82,13 @@ def arith_bases(n, a0=0x1234567, d=0xabcdef1):
 def rand_fr(n, seed):
     rng = random.Random(seed)
     return [rng.randrange(F.R_MOD) for _ in range(n)]
+
+
+def auto_window_bits(n):
+    """The library's automatic window width for a base set of n points (capi.hip: auto_window_bits): lg(n) up to 2^18 points,
+    lg(n) - 1 above, never 17 (it tiles 256 bits like 16 with twice the buckets), within [8, 20]."""
+    lg = max(0, (int(n) - 1).bit_length())
+    c = lg if lg <= 18 else lg - 1
+    if c == 17:
+        c = 16
+    return min(20, max(8, c))
