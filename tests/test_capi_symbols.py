@@ -210,3 +210,24 @@ def test_rust_crates_have_no_dependency_cycle():
         state[n] = 2
     for n in list(graph):
         visit(n, [])
+
+
+def test_mock_rccl_exports_what_the_native_transport_resolves():
+    """tests/mock_rccl/libmock_rccl.so (test infrastructure, built by __graft_entry__.build(); the product loads it only through
+    MH_RCCL_LIB) exports every entry point marlin_amd/csrc/rccl_native.h resolves with dlsym -- a renamed symbol on either side
+    fails here, on the CPU, not in the GPU suite's multi-rank tests."""
+    import ctypes as C
+    mock = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+    if not os.path.exists(mock):
+        pytest.skip("tests/mock_rccl/libmock_rccl.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    src = open(os.path.join(ROOT, "marlin_amd", "csrc", "rccl_native.h")).read()
+    wanted = re.findall(r'RCCL_SYM\(\w+, "(nccl\w+)", (?:true|false)\)', src)
+    assert len(wanted) >= 10 and "ncclAllToAll" in wanted and "ncclCommInitRank" in wanted
+    lib = C.CDLL(mock)
+    for name in wanted:
+        assert hasattr(lib, name), "the stand-in lacks %s" % name
+    # ... and the product never names the stand-in: it is reached through the environment variable only
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "marlin_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
+                assert "libmock_rccl" not in open(os.path.join(dirpath, f)).read(), f
