@@ -168,13 +168,6 @@ impl GpuMarlin {
         check(unsafe { ffi::mh_marlin_proof_serialize(flat.as_ptr(), flat_len, 0, wire.as_mut_ptr(), wire.len(), &mut wire_len) })?;
         Proof::<Fr, MultiPC>::deserialize(&wire[..wire_len]).map_err(|_| HipError::Unsupported("Proof::deserialize rejected the library's bytes"))
     }
-}
-
-/// `ToBytes` images (uncompressed, with presence bytes) -> upstream commitment structs.
-pub mod wire {
-    use ark_bls12_381::{Bls12_381, Fq, G1Affine};
-    use ark_ff::{BigInteger384, FromBytes, PrimeField};
-    use ark_poly_commit::{kzg10, marlin_pc};
 
     /// `Marlin::<Fr, MultiPC, FS2>::prove` for ANY `FS2: FiatShamirRng` (`src/lib.rs:64-70,151-155`; the trait is
     /// `src/rng.rs:54-62`): the library's transcript operations are routed to `fs` through `mh_marlin_prove_fs` -- `initialize`
@@ -187,14 +180,15 @@ pub mod wire {
         zk_seed: [u8; 32],
     ) -> Result<Proof<Fr, MultiPC>, HipError> {
         use core::ffi::c_void;
-        use rand_core::RngCore;
+        use ark_std::rand::RngCore;
         unsafe extern "C" fn init<F: ark_marlin::rng::FiatShamirRng>(user: *mut c_void, input: *const u8, len: usize) {
             let slot = &mut *(user as *mut Option<F>);
-            *slot = Some(F::initialize(&core::slice::from_raw_parts(input, len)));
+            // Vec<u8> is what upstream's own call sites pass (`to_bytes![..]`, src/lib.rs:161)
+            *slot = Some(F::initialize(&core::slice::from_raw_parts(input, len).to_vec()));
         }
         unsafe extern "C" fn absorb<F: ark_marlin::rng::FiatShamirRng>(user: *mut c_void, input: *const u8, len: usize) {
             let slot = &mut *(user as *mut Option<F>);
-            slot.as_mut().expect("initialize first").absorb(&core::slice::from_raw_parts(input, len));
+            slot.as_mut().expect("initialize first").absorb(&core::slice::from_raw_parts(input, len).to_vec());
         }
         unsafe extern "C" fn next<F: ark_marlin::rng::FiatShamirRng>(user: *mut c_void) -> u64 {
             let slot = &mut *(user as *mut Option<F>);
@@ -225,6 +219,13 @@ pub mod wire {
         check(unsafe { ffi::mh_marlin_proof_serialize(flat.as_ptr(), flat_len, 0, wire.as_mut_ptr(), wire.len(), &mut wire_len) })?;
         Proof::<Fr, MultiPC>::deserialize(&wire[..wire_len]).map_err(|_| HipError::Unsupported("Proof::deserialize rejected the library's bytes"))
     }
+}
+
+/// `ToBytes` images (uncompressed, with presence bytes) -> upstream commitment structs.
+pub mod wire {
+    use ark_bls12_381::{Bls12_381, Fq, G1Affine};
+    use ark_ff::{BigInteger384, FromBytes, PrimeField};
+    use ark_poly_commit::{kzg10, marlin_pc};
 
     fn g1_from_tobytes(b: &[u8]) -> G1Affine {
         // x (48 B LE canonical) || y (48 B) || infinity (1 B)   [SURVEY.md Appendix B-6]

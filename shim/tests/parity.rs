@@ -300,6 +300,39 @@ fn sonic_pc_is_byte_identical() {
     assert_eq!(bytes(&cpu_proof), bytes(&gpu_proof));
 }
 
+/// `Marlin` is generic over `FS: FiatShamirRng` (src/lib.rs:64-70): the whole-prover route with the transcript supplied by the
+/// caller (`mh_marlin_prove_fs`), once with the stock `SimpleHashFiatShamirRng<Blake2s, ChaChaRng>` routed through the callbacks
+/// (must equal the built-in transcript AND the CPU) and once with a different digest (must equal the CPU prover instantiated
+/// with that digest; the built-in transcript cannot produce it).
+#[test]
+fn caller_supplied_fiat_shamir_is_byte_identical() {
+    type FsSha = SimpleHashFiatShamirRng<sha2::Sha256, ChaChaRng>;
+    type CpuMarlinSha = Marlin<Fr, MarlinKZG10<Bls12_381, DensePolynomial<Fr>>, FsSha>;
+    let mut rng = ChaChaRng::from_seed([11u8; 32]);
+    let srs = CpuMarlin::universal_setup(100, 25, 300, &mut rng).unwrap();
+    let a = Fr::rand(&mut rng);
+    let b = Fr::rand(&mut rng);
+    let circ = Circuit { a: Some(a), b: Some(b), num_constraints: 100, num_variables: 25 };
+    let zk_seed = [42u8; 32];
+    let (dev_pk, _dev_vk) = GpuMarlin::index(&srs, circ).unwrap();
+
+    let (cpu_pk, cpu_vk) = CpuMarlin::index(&srs, circ).unwrap();
+    let cpu_proof = CpuMarlin::prove(&cpu_pk, circ, &mut ChaChaRng::from_seed(zk_seed)).unwrap();
+    let builtin = GpuMarlin::prove(&dev_pk, circ, zk_seed).unwrap();
+    let routed = GpuMarlin::prove_with_fs::<_, FS>(&dev_pk, circ, zk_seed).unwrap();
+    assert_eq!(bytes(&cpu_proof), bytes(&builtin));
+    assert_eq!(bytes(&cpu_proof), bytes(&routed), "Blake2s transcript through the callbacks");
+
+    // the index does not depend on FS (src/lib.rs:100-148 never touches fs_rng): the same device key serves both
+    let (sha_pk, sha_vk) = CpuMarlinSha::index(&srs, circ).unwrap();
+    assert_eq!(bytes(&cpu_vk), bytes(&sha_vk));
+    let sha_cpu = CpuMarlinSha::prove(&sha_pk, circ, &mut ChaChaRng::from_seed(zk_seed)).unwrap();
+    let sha_dev = GpuMarlin::prove_with_fs::<_, FsSha>(&dev_pk, circ, zk_seed).unwrap();
+    assert_ne!(bytes(&sha_cpu), bytes(&cpu_proof));
+    assert_eq!(bytes(&sha_cpu), bytes(&sha_dev), "Sha256 transcript through the callbacks");
+    assert!(CpuMarlinSha::verify(&sha_vk, &[a * b, a * b * b], &sha_dev, &mut ChaChaRng::from_seed([1u8; 32])).unwrap());
+}
+
 /// Seam B2 alone: the patched radix-2 domain against the unpatched algorithm (which the patch keeps as
 /// `in_order_fft_in_place_host`), forward / inverse / coset, 2^12 .. 2^20.
 #[test]
