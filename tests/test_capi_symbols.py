@@ -140,6 +140,63 @@ def test_rust_and_ctypes_signatures_match_the_header():
         assert got == want, (tname, want, got)
 
 
+def _rust_call_sites(src):
+    """[(name, argument count, line)] of every `mh_*(...)` CALL in a Rust source (declarations `fn mh_*` excluded): the
+    argument list is split at top-level commas with brackets, strings and `|closure|` bars left alone."""
+    src = re.sub(r"//[^\n]*", lambda m: " " * len(m.group(0)), src)
+    out = []
+    for m in re.finditer(r"\b(mh_[a-z0-9_]+)\s*\(", src):
+        if re.search(r"\bfn\s+$", src[:m.start()]):
+            continue
+        i, depth, args, cur, in_str = m.end(), 1, [], "", False
+        while depth:
+            ch = src[i]
+            if in_str:
+                in_str = not (ch == '"' and src[i - 1] != "\\")
+            elif ch == '"':
+                in_str = True
+            elif ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+                if depth == 0:
+                    break
+            elif ch == "," and depth == 1:
+                args.append(cur)
+                cur = ""
+                i += 1
+                continue
+            cur += ch
+            i += 1
+        if cur.strip():
+            args.append(cur)
+        out.append((m.group(1), len(args), src.count("\n", 0, m.start()) + 1))
+    return out
+
+
+def test_rust_call_sites_pass_what_the_header_declares():
+    """No rustc has seen the shim: at least every CALL of an entry point in it (src/, marlin-hip-sys/src/, both tests/ and the
+    ark-poly / ark-ec patches) passes as many arguments as include/marlin_hip.h declares, and names an entry point that exists."""
+    protos = _c_prototypes()
+    files = []
+    for d, _, fs in os.walk(os.path.join(ROOT, "shim")):
+        files += [os.path.join(d, f) for f in fs if f.endswith((".rs", ".patch"))]
+    assert len(files) >= 10, files
+    seen = 0
+    for f in sorted(files):
+        src = open(f).read()
+        if f.endswith(".patch"):
+            src = "\n".join(l[1:] for l in src.split("\n") if l.startswith("+") and not l.startswith("+++"))
+        for name, nargs, line in _rust_call_sites(src):
+            if f.endswith("ffi_symbols.rs") and nargs == 0:
+                continue                                    # `mh_x as usize`-style address-of uses carry no argument list
+            assert name in protos, "%s:%d calls %s, which include/marlin_hip.h does not declare" % (os.path.relpath(f, ROOT), line, name)
+            assert nargs == len(protos[name][1]), "%s:%d passes %d arguments to %s; the header declares %d" % (
+                os.path.relpath(f, ROOT), line, nargs, name, len(protos[name][1]))
+            seen += 1
+    assert seen >= 25, seen
+
+
 def _build_c_example(tmp_path):
     import subprocess
     exe = str(tmp_path / "prove_verify")
