@@ -7,6 +7,7 @@
 #   suite        pytest -m gpu (whole suite) + __graft_entry__.smoke()
 #   bench        the default bench line (2^20, BLS12-381, MarlinKZG10, CPU baseline at the same size, seam route)
 #   profile      tools/profile.sh <tag>: rocprofv3 kernel stats, accumulate dispatches, PMC traffic
+#   stats        the first third of `profile`: rocprofv3 --kernel-trace --stats of a short bench + the accumulate dispatches (no PMC passes)
 #   sq           tools/profile_sq.sh <tag>: SQ wave-cycle breakdown of the accumulate kernel
 #   sims         one rank of 2 / 4 / 8 simulated on this GPU at 2^20, one of 8 at 2^22 (exchanges: Python callbacks making local copies)
 #   sims_native  the same through the native transport (local copies issued from C++ by the solo stand-in for librccl)
@@ -41,6 +42,8 @@ for R in "$@"; do
       timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; line $O/bench_default.json ;;
     profile)
       timeout 1500 bash tools/profile.sh $TAG > $O/profile.log 2>&1; tail -3 $O/profile.log ;;
+    stats)
+      PROFILE_STATS_ONLY=1 timeout 700 bash tools/profile.sh $TAG > $O/stats.log 2>&1; cp gpurun_out/prof_$TAG/*.json gpurun_out/prof_$TAG/*.csv $O/ 2>/dev/null; tail -3 $O/stats.log ;;
     sq)
       timeout 1200 bash tools/profile_sq.sh $TAG --no-seam-route > $O/sq.log 2>&1; cp gpurun_out/prof_$TAG/sq_counters.json $O/ 2>/dev/null; tail -25 $O/sq.log ;;
     sims)

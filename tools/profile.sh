@@ -33,6 +33,8 @@ json.dump({"kernel": "bucket accumulation (msmfb::accum30_kernel)", "dispatch_ms
                    "earlier dispatches belong to Marlin::index (larger batches) and the warm-up prove" % steps},
           open(out + "/accum_dispatches.json", "w"), indent=1)
 PY
+grep '^{' $OUT/trace.log | tail -1 > $OUT/bench_line_under_rocprof.json
+if [ "${PROFILE_STATS_ONLY:-0}" = 1 ]; then rm -rf $OUT/trace; ls -la $OUT; exit 0; fi
 CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam-route --full-prof $*"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD1 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $CMD1 > $OUT/pmc_write.log 2>&1
