@@ -25,7 +25,9 @@ struct Header { std::atomic<uint32_t> arrived; std::atomic<uint32_t> generation;
 struct ncclComm { int rank, nranks; size_t slot; char name[64]; Header* hdr; char* slots; size_t map_bytes; bool solo; void* filled[16]; size_t filled_bytes[16]; };
 typedef ncclComm* ncclComm_t;
 
-static const size_t kSlot = 96ull << 20;        // per rank: the largest payload a test moves is a few MB
+// per rank; the tests move a few MB, a 2^20 rehearsal 34 MB, a 2^22 one with 4 ranks 134 MB: MH_MOCK_RCCL_SLOT_MB (the same on
+// every rank) raises it (the segment is sparse: only what is written is ever backed by memory)
+static size_t slot_bytes() { const char* e = getenv("MH_MOCK_RCCL_SLOT_MB"); const long mb = e ? atol(e) : 96; return (size_t)(mb > 0 ? mb : 96) << 20; }
 
 static void barrier(ncclComm* c) {
   Header* h = c->hdr;
@@ -68,10 +70,10 @@ static ncclResult_t solo_fill(ncclComm* c, void* recv, size_t total) {
 ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int rank) {
   if (!out || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
   ncclComm* c = new ncclComm();
-  c->rank = rank; c->nranks = nranks; c->slot = kSlot;
+  c->rank = rank; c->nranks = nranks; c->slot = slot_bytes();
   if (solo_mode()) { c->solo = true; c->hdr = nullptr; memset(c->filled, 0, sizeof(c->filled)); *out = c; return ncclSuccess; }
   snprintf(c->name, sizeof(c->name), "%s", id.internal);
-  c->map_bytes = 4096 + (size_t)nranks * kSlot;
+  c->map_bytes = 4096 + (size_t)nranks * c->slot;
   int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
   if (fd < 0) { delete c; return ncclSystemError; }
   if (ftruncate(fd, (off_t)c->map_bytes) != 0) { close(fd); delete c; return ncclSystemError; }
