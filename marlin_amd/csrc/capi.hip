@@ -36,6 +36,7 @@ static Fr to_dev_fr(const HFr& h) {
 // --------------------------------------------------------------------------------
 // NTT driver
 // --------------------------------------------------------------------------------
+static bool ntt_shoup();
 static int ensure_twiddles(Context& c, uint32_t log_n) {
   if (c.tw && c.tw_log >= log_n) return MH_OK;
   uint32_t want = log_n < 16 ? 16 : log_n;
@@ -50,6 +51,12 @@ static int ensure_twiddles(Context& c, uint32_t log_n) {
   MH_HIP(hipMalloc(&c.tw30, (size_t)36 << want));
   hipLaunchKernelGGL(ntt30::build_twiddles30, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, (u32*)c.tw30, (const Fr*)c.tw, (u64)n);
   MH_HIP(hipGetLastError());
+  if (c.tw30s) { (void)hipFree(c.tw30s); c.tw30s = nullptr; }
+  if (ntt_shoup()) {
+    MH_HIP(hipMalloc(&c.tw30s, (size_t)72 << want));
+    hipLaunchKernelGGL(ntt30::build_twiddles30s, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, (u32*)c.tw30s, (const Fr*)c.tw, (u64)n);
+    MH_HIP(hipGetLastError());
+  }
   c.tw_log = want;
   return MH_OK;
 }
@@ -64,8 +71,10 @@ static void plan_passes(uint32_t log_n, uint32_t* bits, int* npass) {
   *npass = np;
 }
 
-// MH_NTT=32 selects the 32-bit-limb radix-2 kernel of ntt.cuh (the cross-check of the 30-bit radix-8 kernel of ntt30.cuh)
+// MH_NTT=32 selects the 32-bit-limb radix-2 kernel of ntt.cuh (the cross-check of the 30-bit radix-8 kernel of ntt30.cuh);
+// MH_NTT=shoup the 30-bit kernel with the twiddle products as Shoup multiplications (opt-in, ntt30.cuh: butterfly_shoup)
 static bool ntt_use30() { static const bool v = [] { const char* e = getenv("MH_NTT"); return !(e && atoi(e) == 32); }(); return v; }
+static bool ntt_shoup() { static const bool v = [] { const char* e = getenv("MH_NTT"); return e && !strcmp(e, "shoup"); }(); return v; }
 
 static int launch_pass(Context& c, const Fr* x, Fr* y, uint32_t log_n, uint32_t B, uint32_t logP, uint32_t flags,
                        const Fr& ninv, uint64_t in_len) {
@@ -77,10 +86,16 @@ static int launch_pass(Context& c, const Fr* x, Fr* y, uint32_t log_n, uint32_t 
     // stages per register round: 2 from 2^23 points on, 1 below (measured, see ntt30.cuh); MH_NTT_NS overrides
     static const int env_ns = [] { const char* e = getenv("MH_NTT_NS"); return e ? atoi(e) : 0; }();
     const int ns = env_ns ? env_ns : (log_n >= 23 ? 2 : 1);
-#define NTT30_LAUNCH(LC, NS) hipLaunchKernelGGL((ntt30::pass30_kernel<LC, NS, 256, 4, 0, false>), dim3((unsigned)blocks30), dim3(256), \
-    ntt30::pass_lds_bytes(B, (int)logc, logP == 0, 0, false), c.stream, x, y, tw30, log_n, B, logP, flags, ninv, (u64)in_len)
+#define NTT30_LAUNCH_T(LC, NS, SH, TW) hipLaunchKernelGGL((ntt30::pass30_kernel<LC, NS, 256, 4, 0, false, SH>), dim3((unsigned)blocks30), dim3(256), \
+    ntt30::pass_lds_bytes(B, (int)logc, logP == 0, 0, false), c.stream, x, y, TW, log_n, B, logP, flags, ninv, (u64)in_len)
+#define NTT30_LAUNCH(LC, NS) NTT30_LAUNCH_T(LC, NS, false, tw30)
+#define NTT30_LAUNCH_S(LC) do { if (shoup) NTT30_LAUNCH_T(LC, 1, true, tw30s); else NTT30_LAUNCH_T(LC, 1, false, tw30); } while (0)
+    // Shoup twiddle products only in the one-stage rounds: with two stages per round the 18-word twiddles cost more registers
+    // than the shorter products give back (2^22 constraints: 15.2 -> 16.1 ms of transforms, profiles/r04zj_*)
+    const bool shoup = ntt_shoup() && ns == 1;
+    const u32* tw30s = (const u32*)c.tw30s;
     if (ns == 2) { switch (logc) { case 0: NTT30_LAUNCH(0, 2); break; case 1: NTT30_LAUNCH(1, 2); break; default: NTT30_LAUNCH(2, 2); break; } }
-    else { switch (logc) { case 0: NTT30_LAUNCH(0, 1); break; case 1: NTT30_LAUNCH(1, 1); break; default: NTT30_LAUNCH(2, 1); break; } }
+    else { switch (logc) { case 0: NTT30_LAUNCH_S(0); break; case 1: NTT30_LAUNCH_S(1); break; default: NTT30_LAUNCH_S(2); break; } }
     MH_HIP(hipGetLastError());
     return MH_OK;
   }
@@ -111,6 +126,9 @@ static int ntt_set_attrs() {
   MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<1, NS, 256, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30)); \
   MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<2, NS, 256, 4, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30));
   NTT30_ATTR(1) NTT30_ATTR(2)
+  MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<0, 1, 256, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30));
+  MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<1, 1, 256, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30));
+  MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<2, 1, 256, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30));
   g_ntt_attr_done = true;
   return MH_OK;
 }
@@ -1261,7 +1279,8 @@ int mh_shutdown(void) {
   (void)mh_marlin_release_all();
   if (c.tw) (void)hipFree(c.tw);
   if (c.tw30) (void)hipFree(c.tw30);
-  c.tw = nullptr; c.tw30 = nullptr; c.tw_log = 0;
+  if (c.tw30s) (void)hipFree(c.tw30s);
+  c.tw = nullptr; c.tw30 = nullptr; c.tw30s = nullptr; c.tw_log = 0;
   c.ntt_tmp[0].release(); c.ntt_tmp[1].release(); c.io.release();
   c.msm_dig.release(); c.msm_sorted.release(); c.msm_bh.release(); c.msm_tot.release(); c.msm_base.release();
   c.msm_buckets.release(); c.msm_seg.release(); c.msm_win.release(); c.msm_pend.release();

@@ -103,6 +103,7 @@ struct Context {
   // NTT
   void* tw = nullptr;        // Fr[2^tw_log]
   void* tw30 = nullptr;      // the same table as 9 x 30-bit limbs of w R' mod r (ntt30.cuh), 36 B per entry
+  void* tw30s = nullptr;     // MH_NTT=shoup only: plain w and floor(w R' / r), 72 B per entry (ntt30.cuh: butterfly_shoup)
   uint32_t tw_log = 0;
   Scratch ntt_tmp[2];
   Scratch ntt_dist_buf[2], sl_send, sl_recv;

@@ -138,6 +138,33 @@ __device__ __forceinline__ void butterfly(Fr30& a, Fr30& b, const u32* w) {
   a = add30(a, t);
 }
 
+// ---- the same butterfly with the twiddle product as a Shoup multiplication (MH_NTT=shoup; opt-in) -----------------------
+// The twiddle is a constant: with w' = floor(w R' / r) stored beside the PLAIN w (18 words per entry, tw30s), w b mod r is
+// t = w b - q r, q ~ floor(b w' / R') -- 135 limb products (the high half of b w', the low halves of b w and q (R' - r)) instead
+// of the Montgomery product's 162, no m_k chain, 18 column carries instead of 27 (gen_fq30.py: shoup).  No Montgomery factor
+// either: the data keeps its standard representation as before.  q is taken from the columns i + j >= 8 only, so
+// 0 <= t < 11 r; the butterfly subtracts with 16 r: values grow by at most 16 r per stage, (1 + 16 * 28) r < 2^9 r << R' / r.
+__device__ __forceinline__ Fr30 sub30_16(const Fr30& a, const Fr30& b) {
+  Fr30 r;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    int s = (int)(a.v[i] - b.v[i]) + (int)RP::P16[i] + c;
+    if (i < NL - 1) { r.v[i] = (u32)s & M30; c = s >> 30; } else r.v[i] = (u32)s;
+  }
+  return r;
+}
+__device__ __forceinline__ void butterfly_shoup(Fr30& a, Fr30& b, const u32* w) {      // w[0..9) = w, w[9..18) = w'
+  Fr30 t;
+  FR30_GEN(f30_mulshoup)(t.v, b.v, w, w + NL);
+  b = sub30_16(a, t);
+  a = add30(a, t);
+}
+template <bool SHOUP>
+__device__ __forceinline__ void butterfly_t(Fr30& a, Fr30& b, const u32* w) {
+  if (SHOUP) butterfly_shoup(a, b, w); else butterfly(a, b, w);
+}
+
 // ---- tile in LDS: limb-major, 4 words of padding per 32 -------------------------------------------------------------
 // PAD: log2 of the words of padding inserted after every 32 words of a limb array (-1: none)
 template <int PAD>
@@ -169,10 +196,46 @@ __global__ __launch_bounds__(256) void build_twiddles30(u32* __restrict__ tw30, 
   for (int l = 0; l < NL; l++) tw30[9 * i + l] = w.v[l];
 }
 
+// the Shoup form of the table: tw30s[18 i + l] = limb l of the plain w_i, tw30s[18 i + 9 + l] = limb l of floor(w_i R' / r).
+// With rho = w R' mod r (the entry of tw30): w R' - rho is divisible by r and the quotient is below R', so it is
+// (R' - rho) r^-1 mod R' -- the low nine limbs of one product with a constant.
+__global__ __launch_bounds__(256) void build_twiddles30s(u32* __restrict__ tw30s, const Fr* __restrict__ tw, u64 n) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr c, one;
+#pragma unroll
+  for (int k = 0; k < Fr::N; k++) { c.v[k] = RP::TO30[k]; one.v[k] = k == 0 ? 1u : 0u; }
+  const Fr wm = ff_load(tw + i);
+  const Fr30 w = slice30(ff_mul(wm, one));                   // w R / R = w, canonical
+  const Fr30 rho = slice30(ff_mul(wm, c));                   // w R' mod r, canonical and non-zero (w != 0)
+  u32 d[NL];                                                 // R' - rho
+  int br = 0;
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const int sdig = -(int)rho.v[l] + br;
+    d[l] = (u32)sdig & M30;
+    br = sdig >> 30;
+  }
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    u64 lo = acc & M30, hi = acc >> 30;                      // two accumulators: nine 60-bit products overflow one
+    for (int a = 0; a <= k; a++) {
+      const u64 pr = (u64)d[a] * RP::PINV_FULL[k - a];
+      lo += pr & M30; hi += pr >> 30;
+    }
+    hi += lo >> 30;
+    tw30s[18 * i + NL + k] = (u32)lo & M30;
+    acc = hi;
+  }
+#pragma unroll
+  for (int l = 0; l < NL; l++) tw30s[18 * i + l] = w.v[l];
+}
+
 // NS stages (t .. t + NS - 1) of the tile's B on 2^NS elements per work item.  Element j of an item is row
 // u0 + j m (m = 2^t) of column c; stage t + s pairs j with j + 2^s (bit s of j clear) under the twiddle of index
 // i + (j mod 2^s) m at that stage.  TWL: twiddles from the LDS copy of tw30[1 .. R) (first pass) or from global memory.
-template <int NS, int LOGC, bool TWL, int THREADS, int PAD>
+template <int NS, int LOGC, bool TWL, int THREADS, int PAD, bool SHOUP = false>
 __device__ __forceinline__ void round_stages(u32* tile, u32 tw_words, const u32* __restrict__ twsrc, u32 B, u32 t, u32 logP,
                                              u64 jbase) {
   constexpr int C = 1 << LOGC;
@@ -192,17 +255,18 @@ __device__ __forceinline__ void round_stages(u32* tile, u32 tw_words, const u32*
 #pragma unroll
       for (int g = 0; g < (1 << s); g++) {            // g = j mod 2^s: one twiddle for all pairs of this residue
         const u64 ti = (P << (t + s)) + k + ((u64)(i + g * m) << logP);
-        u32 w[NL];
+        constexpr int TWW = SHOUP ? 2 * NL : NL;         // words per twiddle
+        u32 w[TWW];
         if (TWL) {
 #pragma unroll
-          for (int l = 0; l < NL; l++) w[l] = twsrc[9 * (u32)ti + l];
+          for (int l = 0; l < TWW; l++) w[l] = twsrc[TWW * (u32)ti + l];
         } else {
-          const u32* p = twsrc + 9 * ti;
+          const u32* p = twsrc + TWW * ti;
 #pragma unroll
-          for (int l = 0; l < NL; l++) w[l] = p[l];
+          for (int l = 0; l < TWW; l++) w[l] = p[l];
         }
 #pragma unroll
-        for (int j = g; j < E; j += (2 << s)) butterfly(e[j], e[j + (1 << s)], w);
+        for (int j = g; j < E; j += (2 << s)) butterfly_t<SHOUP>(e[j], e[j + (1 << s)], w);
       }
     }
 #pragma unroll
@@ -211,10 +275,11 @@ __device__ __forceinline__ void round_stages(u32* tile, u32 tw_words, const u32*
 }
 
 // One Stockham pass (arguments as ntt::pass_kernel; tw30 instead of tw).
-template <int LOGC, int MAXNS, int THREADS, int WAVES, int PAD, bool TWLDS>
+template <int LOGC, int MAXNS, int THREADS, int WAVES, int PAD, bool TWLDS, bool SHOUP = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pass30_kernel(const void* __restrict__ x, void* __restrict__ y, const u32* __restrict__ tw30,
                                                          u32 log_n, u32 B, u32 logP, u32 flags, Fr ninv, u64 in_len) {
   extern __shared__ __attribute__((aligned(16))) u32 lds30[];
+  static_assert(!(TWLDS && SHOUP), "the LDS copy of the first pass's twiddles holds the 9-word form");
   constexpr int C = 1 << LOGC;
   const u32 R = 1u << B;
   const u64 n = 1ull << log_n;
@@ -258,11 +323,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
         a = add30(a, b);
         b = d;
       } else {
-        const u32* w = tw30 + 9 * ((1ull << logP) + ((jbase + c) & Pm));
-        u32 wl[NL];
+        constexpr int TWW = SHOUP ? 2 * NL : NL;
+        const u32* w = tw30 + TWW * ((1ull << logP) + ((jbase + c) & Pm));
+        u32 wl[TWW];
 #pragma unroll
-        for (int l = 0; l < NL; l++) wl[l] = w[l];
-        butterfly(a, b, wl);
+        for (int l = 0; l < TWW; l++) wl[l] = w[l];
+        butterfly_t<SHOUP>(a, b, wl);
       }
       const u32 rr = __brev(r) >> (32 - B);            // even: r < R / 2
       tile_store<PAD>(tile, tw_words, (rr << LOGC) + c, a);
@@ -279,9 +345,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
       else if (ns == 2) round_stages<2, LOGC, true, THREADS, PAD>(tile, tw_words, twl, B, t, 0, jbase);
       else round_stages<1, LOGC, true, THREADS, PAD>(tile, tw_words, twl, B, t, 0, jbase);
     } else {
-      if (MAXNS >= 3 && ns == 3) round_stages<MAXNS >= 3 ? 3 : 1, LOGC, false, THREADS, PAD>(tile, tw_words, tw30, B, t, logP, jbase);
-      else if (ns == 2) round_stages<2, LOGC, false, THREADS, PAD>(tile, tw_words, tw30, B, t, logP, jbase);
-      else round_stages<1, LOGC, false, THREADS, PAD>(tile, tw_words, tw30, B, t, logP, jbase);
+      if (MAXNS >= 3 && ns == 3) round_stages<MAXNS >= 3 ? 3 : 1, LOGC, false, THREADS, PAD, SHOUP>(tile, tw_words, tw30, B, t, logP, jbase);
+      else if (ns == 2) round_stages<2, LOGC, false, THREADS, PAD, SHOUP>(tile, tw_words, tw30, B, t, logP, jbase);
+      else round_stages<1, LOGC, false, THREADS, PAD, SHOUP>(tile, tw_words, tw30, B, t, logP, jbase);
     }
     __syncthreads();
     t += ns;

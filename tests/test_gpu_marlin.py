@@ -213,11 +213,12 @@ sys.stdout.write(pk.vk_bytes().hex() + " " + GM.prove(pk, inst, wit, bytes(range
 @pytest.mark.parametrize("env,pc", [({"MH_FB": "0"}, "marlin"), ({"MH_FB": "0"}, "sonic"), ({"MH_NTT": "32"}, "marlin"),
                                     ({"MH_FB_ALIAS": "0"}, "marlin"), ({"MH_FB_SEG_THREADS": "8192"}, "marlin"),
                                     ({"MH_FB_QUAD": "2"}, "marlin"), ({"MH_FB_QUAD": "2"}, "sonic"), ({"MH_FB_QUAD": "0"}, "marlin"),
-                                    ({"MH_FB_ILP": "0"}, "marlin"), ({"MH_SIDE_NTT": "0", "MH_FB_PTOT_OVERLAP": "0"}, "sonic")],
+                                    ({"MH_FB_ILP": "0"}, "marlin"), ({"MH_SIDE_NTT": "0", "MH_FB_PTOT_OVERLAP": "0"}, "sonic"),
+                                    ({"MH_NTT": "shoup"}, "marlin")],
                          ids=lambda v: v if isinstance(v, str) else ",".join("%s=%s" % kv for kv in v.items()))
 def test_alternative_paths_give_the_same_bytes(gpu, env, pc):
     """The paths the library keeps behind switches -- variable-base MSM for every commitment (what serves a key whose window
-    table does not fit), the 32-bit-limb NTT kernel, separate sorts for jobs that share a scalar vector, another
+    table does not fit), the 32-bit-limb NTT kernel, the 30-bit one with Shoup twiddle products, separate sorts for jobs that share a scalar vector, another
     segmentation of the bucket reduction, the bucket reduction with one point per quad of lanes in both stages or in
     neither, the one-chain group law, round 2's early transforms and the partition totals in their round-3 places -- produce the
     same index commitments and the same proof, byte for byte.  (2^13 constraints: the bucket sets have empty buckets, so the
