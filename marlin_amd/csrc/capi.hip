@@ -654,22 +654,23 @@ struct FbRun {
         const u64 per_simd = (active / 64 + (u64)c.num_simds - 1) / (u64)c.num_simds;
         if (per_simd <= 6) acc_waves = 2;
       }
-#define FB_ACCUM(K) hipLaunchKernelGGL(K, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table, \
-                           (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr, \
-                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit)
-      if (bs.tab_shoup) {             // table of G1Aff30S (MH_FB_SHOUP=1 at mh_bases_precompute)
-        if (acc_waves == 2) FB_ACCUM((F::accum30_kernel<2, true>)); else FB_ACCUM((F::accum30_kernel<3, true>));
-      } else if (acc_waves == 2) FB_ACCUM((F::accum30_kernel<2>));
-      else if (acc_waves == 4) FB_ACCUM((F::accum30_kernel<4>));
-      else FB_ACCUM((F::accum30_kernel<3>));
-#undef FB_ACCUM
+      if (acc_waves == 2)
+        hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
+                           (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
+      else if (acc_waves == 4)
+        hipLaunchKernelGGL(F::accum30_kernel<4>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
+                           (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
+      else
+        hipLaunchKernelGGL(F::accum30_kernel<3>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
+                           (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
     }
     ProfScope ps(c, PF_MSM_STAGES, s);
-#define FB_FIXUP(K) hipLaunchKernelGGL(K, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw, \
-                       (const F::G1Aff30*)bs.d_table, (const u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, \
-                       (const u32*)ws.pend.ptr, (const u32*)(d_max + 1), (F::G1Xyzz30*)ws.buckets.ptr, nb, (u64)WB)
-    if (bs.tab_shoup) FB_FIXUP(F::fixup30_kernel<true>); else FB_FIXUP(F::fixup30_kernel<false>);
-#undef FB_FIXUP
+    hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw,
+                       (const F::G1Aff30*)bs.d_table, (const u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr,
+                       (const u32*)ws.pend.ptr, (const u32*)(d_max + 1), (F::G1Xyzz30*)ws.buckets.ptr, nb, (u64)WB);
     MH_HIP(hipGetLastError());
     // the caller's independent work (Context::side_job) goes to stream2 behind the accumulation: beside the reduction that follows
     if (c.side_job && s == c.stream && c.stream2 && c.side_ev[0] && c.side_ev[1]) {
@@ -869,11 +870,7 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   const u32 W = msm::make_windows(cbits, win);
   if ((u64)W * bs.n >= (1ull << 31)) return fail(MH_EINVAL, "mh_bases_precompute: table too large for 31-bit entry indices");
   void* tab = nullptr;
-  // MH_FB_SHOUP=1 (opt-in): plain coordinates + Shoup quotients, 2 x the bytes, 65 limb products less in each of the two
-  // table-coordinate products of a bucket addition (msm_fb.cuh: G1Aff30S)
-  static const bool env_shoup = [] { const char* e = getenv("MH_FB_SHOUP"); return e && atoi(e) == 1; }();
-  bs.tab_shoup = env_shoup;
-  const size_t pt30 = bs.tab_shoup ? sizeof(msmfb::G1Aff30S) : sizeof(msmfb::G1Aff30);
+  const size_t pt30 = sizeof(msmfb::G1Aff30);
   hipError_t e = hipMalloc(&tab, (size_t)W * bs.n * pt30);
   if (e != hipSuccess) return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the window table failed");
   // two standard-form levels ping-pong through scratch while the chain of doublings runs
@@ -894,11 +891,8 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   }
   for (u32 j = 0; j < W; j++) {
     G1Affine* next_std = (G1Affine*)((char*)tmp + (size_t)(j & 1) * bs.n * PT_B);
-    void* lvl = (char*)tab + (size_t)j * bs.n * pt30;
-    if (bs.tab_shoup)
-      hipLaunchKernelGGL(msmfb::table_level_kernel<true>, dim3(grid), dim3(128), 0, s, prev, next_std, lvl, xyzz_scratch, (u64)bs.n, j ? (u32)win.bits[j - 1] : 0u, kinv);
-    else
-      hipLaunchKernelGGL(msmfb::table_level_kernel<false>, dim3(grid), dim3(128), 0, s, prev, next_std, lvl, xyzz_scratch, (u64)bs.n, j ? (u32)win.bits[j - 1] : 0u, kinv);
+    hipLaunchKernelGGL(msmfb::table_level_kernel, dim3(grid), dim3(128), 0, s, prev, next_std,
+                       (msmfb::G1Aff30*)((char*)tab + (size_t)j * bs.n * pt30), xyzz_scratch, (u64)bs.n, j ? (u32)win.bits[j - 1] : 0u, kinv);
     prev = next_std;
   }
   hipError_t le = hipGetLastError();
@@ -1571,7 +1565,7 @@ int mh_bases_table_info(uint64_t handle, uint32_t* window_bits, uint32_t* window
   const BaseSet& bs = it->second;
   if (window_bits) *window_bits = bs.d_table ? bs.tab_c : 0;
   if (windows) *windows = bs.d_table ? bs.tab_W : 0;
-  if (table_bytes) *table_bytes = bs.d_table ? (uint64_t)bs.tab_W * bs.n * (bs.tab_shoup ? sizeof(msmfb::G1Aff30S) : sizeof(msmfb::G1Aff30)) : 0;
+  if (table_bytes) *table_bytes = bs.d_table ? (uint64_t)bs.tab_W * bs.n * sizeof(msmfb::G1Aff30) : 0;
   return MH_OK;
 }
 

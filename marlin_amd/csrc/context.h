@@ -78,7 +78,6 @@ struct BaseSet {
   void* d_table = nullptr;
   uint32_t tab_c = 0, tab_W = 0;
   bool tab_auto = false;     // width chosen by the library (re-chosen when the shard count changes)
-  bool tab_shoup = false;    // MH_FB_SHOUP=1 at mh_bases_precompute: entries are msmfb::G1Aff30S (plain coordinates + Shoup quotients)
 };
 
 struct G2Set { void* d_points = nullptr; size_t n = 0; };   // G2Affine[n] (x.c0 | x.c1 | y.c0 | y.c1, Montgomery)

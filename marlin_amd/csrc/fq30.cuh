@@ -173,43 +173,6 @@ __device__ __forceinline__ void f30_mul2_mul(Fq30& r0, const Fq30& a0, const Fq3
   r0 = t0; r1 = t1;
 }
 
-// Multiplication by a CONSTANT held as the plain integer w < p with its quotient wq = floor(w R' / p) (Shoup): a w mod p for any
-// a < R' with normalised limbs, in [0, (2 + NL) p) -- no Montgomery factor, so a in the R' form gives a w in the R' form.
-// 3 NL (NL + 1) / 2 limb products (273 / 135) against the 2 NL^2 (338 / 162) of f30_mul: gen_fq30.py `shoup`.
-__device__ __forceinline__ Fq30 f30_mulshoup(const Fq30& a, const u32* w, const u32* wq) {
-  Fq30 r;
-  F30_GEN(f30_mulshoup)(r.v, a.v, w, wq);
-  return r;
-}
-// wq for the constant whose R' form (w R' mod p, canonical) is rho: w R' - rho is divisible by p and the quotient is below R', so
-// it is (R' - rho) p^-1 mod R' -- the low NL limbs of one product with a constant.  Not a hot path (table builds).
-__device__ __forceinline__ Fq30 f30_shoup_quotient(const Fq30& rho) {
-  constexpr int NL = Fq30::NL;
-  u32 d[NL];
-  int br = 0;
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    const int sdig = -(int)rho.v[l] + br;
-    d[l] = (u32)sdig & M30;
-    br = sdig >> 30;
-  }
-  Fq30 r;
-  u64 acc = 0;
-#pragma unroll
-  for (int k = 0; k < NL; k++) {
-    u64 lo = acc & M30, hi = acc >> 30;              // two accumulators: NL products of 2^60 overflow one
-#pragma unroll
-    for (int a = 0; a <= k; a++) {
-      const u64 pr = (u64)d[a] * Fq30Params::PINV_FULL[k - a];
-      lo += pr & M30; hi += pr >> 30;
-    }
-    hi += lo >> 30;
-    r.v[k] = (u32)lo & M30;
-    acc = hi;
-  }
-  return r;
-}
-
 // a + b (no reduction)
 __device__ __forceinline__ Fq30 f30_add(const Fq30& a, const Fq30& b) {
   Fq30 r;
@@ -221,16 +184,15 @@ __device__ __forceinline__ Fq30 f30_add(const Fq30& a, const Fq30& b) {
   }
   return r;
 }
-// a - b + K p for the generated multiples K in {2, 3, 4, 8, 16}; requires b <= K p
+// a - b + K p for the generated multiples K in {2, 3, 4, 8}; requires b <= K p
 template <int K>
 __device__ __forceinline__ Fq30 f30_sub(const Fq30& a, const Fq30& b) {
   using PP = Fq30Params;
-  static_assert(K == 2 || K == 3 || K == 4 || K == 8 || K == 16, "no such multiple of p");
   Fq30 r;
   int c = 0;
 #pragma unroll
   for (int i = 0; i < Fq30::NL; i++) {
-    const u32 kp = K == 2 ? PP::P2[i] : (K == 3 ? PP::P3[i] : (K == 4 ? PP::P4[i] : (K == 8 ? PP::P8[i] : PP::P16[i])));
+    const u32 kp = K == 2 ? PP::P2[i] : (K == 3 ? PP::P3[i] : (K == 4 ? PP::P4[i] : PP::P8[i]));
     int s = (int)(a.v[i] - b.v[i]) + (int)kp + c;        // in (-2^30, 2^31)
     if (i < Fq30::NL - 1) { r.v[i] = (u32)s & M30; c = s >> 30; } else r.v[i] = (u32)s;
   }
@@ -255,10 +217,9 @@ __device__ __forceinline__ Fq30 f30_sub2(const Fq30& a, const Fq30& b) {
 // a == 0 mod p for a normalised value below 16 p: a = j p implies a * p^-1 = j mod 2^30, so one multiplication rejects
 // all but ~2^-26 of the non-zero values, and those are compared with j p limb by limb (exact: a collision-free proof
 // leaves the accumulate kernel's deferred list empty and the fix-up pass returns at once).
-template <u32 LIM = 16u>                                         // LIM: the value is known to be below LIM p
 __device__ __forceinline__ bool f30_is_zero(const Fq30& a) {
   const u32 j = (a.v[0] * Fq30Params::PINV_POS) & M30;
-  if (__builtin_expect(j >= LIM, 1)) return false;
+  if (__builtin_expect(j >= 16u, 1)) return false;
   u64 c = 0;
   bool eq = true;
 #pragma unroll

@@ -42,10 +42,6 @@ struct FbWin { u64 off; u64 bh_off; u32 cnt; u32 ntiles; u32 delta; u32 pad; };
 // multiple of four words (BLS12-381: 2 x 64 B, one cache line per coordinate)
 constexpr int LIMB_SLOTS = (Fq30::NL + 3) & ~3;
 struct G1Aff30 { u32 x[LIMB_SLOTS]; u32 y[LIMB_SLOTS]; };
-// MH_FB_SHOUP=1 (opt-in): the coordinates as PLAIN integers with their Shoup quotients floor(x R' / p), floor(y R' / p) -- the two
-// products of a bucket addition that have a table coordinate as one factor (U2 = x2 ZZ1, S2 = y2 ZZZ1) then cost 273 limb products
-// instead of 338 each (fq30.cuh: f30_mulshoup), for twice the table bytes (BLS12-381: 4 x 64 B per point)
-struct G1Aff30S { u32 x[LIMB_SLOTS]; u32 xq[LIMB_SLOTS]; u32 y[LIMB_SLOTS]; u32 yq[LIMB_SLOTS]; };
 
 __device__ __forceinline__ Fq30 load30(const u32* __restrict__ p) {
   u32 w[LIMB_SLOTS];
@@ -129,12 +125,9 @@ struct FbJobs {
 // inversion instead of a whole one (~570 multiplications), which was three quarters of the table build.
 constexpr int TAB_BATCH = 8;
 struct G1XyzzStd { Fq x, y, zz, zzz; };
-template <bool SHOUP>
 __global__ __launch_bounds__(128) void table_level_kernel(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next_std,
-                                                          void* __restrict__ next30_, G1XyzzStd* __restrict__ scratch, u64 n,
+                                                          G1Aff30* __restrict__ next30, G1XyzzStd* __restrict__ scratch, u64 n,
                                                           u32 bits, Fr kinv) {
-  G1Aff30* next30 = reinterpret_cast<G1Aff30*>(next30_);
-  G1Aff30S* next30s = reinterpret_cast<G1Aff30S*>(next30_);
   const u64 T = (n + TAB_BATCH - 1) / TAB_BATCH;
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
@@ -172,18 +165,8 @@ __global__ __launch_bounds__(128) void table_level_kernel(const G1Affine* __rest
     const Fq x = ff_mul(ff_load(&scratch[i].x), izz), y = ff_mul(ff_load(&scratch[i].y), iz);
     ff_store(&next_std[i].x, x);
     ff_store(&next_std[i].y, y);
-    if (SHOUP) {
-      Fq one;                                              // the integer 1: a Montgomery product with it takes the factor R off
-#pragma unroll
-      for (int k = 0; k < Fq::N; k++) one.v[k] = k == 0 ? 1u : 0u;
-      store30(next30s[i].x, f30_split(ff_mul(x, one)));
-      store30(next30s[i].xq, f30_shoup_quotient(f30_from_fq(x)));
-      store30(next30s[i].y, f30_split(ff_mul(y, one)));
-      store30(next30s[i].yq, f30_shoup_quotient(f30_from_fq(y)));
-    } else {
-      store30(next30[i].x, f30_from_fq(x));
-      store30(next30[i].y, f30_from_fq(y));
-    }
+    store30(next30[i].x, f30_from_fq(x));
+    store30(next30[i].y, f30_from_fq(y));
   }
 }
 
@@ -598,11 +581,7 @@ __global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__
 // p (a product of u and v is below 1 + u v / 630): table x < 1, +-y <= 2, zz, zzz <= 1.1; X1 <= 6.2, Y1 <= 2 are
 // loop invariants: P = U2 - X1 + 8p <= 9.1, R = S2 - Y1 + 4p <= 5.1, PP, PPP, Q, R^2 <= 1.2,
 // X3 = (R^2 - PPP + 2p) - 2Q + 3p <= 6.2, Y3 = (R (Q - X3 + 8p) + (4p - Y1) PPP) / R' <= 1 + (5.1 x 9.2 + 4 x 1.2) / 630 < 1.1.
-// SHOUP (MH_FB_SHOUP=1, table of G1Aff30S): U2 = x2 ZZ1 and S2 = y2 ZZZ1 as Shoup products by the table's constants, in [0, 15 p)
-// (BN254: 11 p) instead of below 1.1 p: P = U2 - X1 + 8p <= 23, R = +-S2 - Y1 + 4p <= 20 (the sign of the digit turns S2 into
-// 16p - S2), PP <= 1.9, PPP, Q, ZZ, ZZZ <= 1.1, R^2 <= 1.7, X3 <= 6.7 (<= 8: P stays non-negative), Y3 <= 1 + (20 x 9.1 + 4 x 1.1) /
-// 630 < 1.3.  The first entry of a list seeds X1, Y1 with the R' form through one Montgomery product with R'^2 mod p.
-template <int WAVES, bool SHOUP = false>
+template <int WAVES>
 __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                                const u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                                const u32* __restrict__ tot, const u32* __restrict__ perm,
@@ -618,7 +597,6 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
   const FbWin d = fbw[gid / nb];
   const u32* lst = sorted_all + d.off + base[gid];
   const G1Aff30* tab = table + d.delta;
-  const G1Aff30S* tabs = reinterpret_cast<const G1Aff30S*>(table) + d.delta;
   const u32 cnt = tot[gid];
   if (cnt == 0) {
     const u32 v = (u32)(gid / nb) % nparts;         // another rank's buckets are never read: nothing to store
@@ -631,18 +609,9 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
   Fq30 X1, Y1, ZZ, ZZZ;
   {
     const u32 e = lst[0];
-    if (SHOUP) {
-      const G1Aff30S* q = tabs + (e & 0x7fffffffu);
-      Fq30 rr;
-#pragma unroll
-      for (int i = 0; i < Fq30::NL; i++) rr.v[i] = Fq30Params::RR[i];
-      X1 = f30_mul(load30(q->x), rr);                 // x R'^2 / R' = x R'
-      Y1 = f30_mul(load30(q->y), rr);
-    } else {
-      const G1Aff30* q = tab + (e & 0x7fffffffu);
-      X1 = load30(q->x);
-      Y1 = load30(q->y);
-    }
+    const G1Aff30* q = tab + (e & 0x7fffffffu);
+    X1 = load30(q->x);
+    Y1 = load30(q->y);
     if (e & 0x80000000u) Y1 = f30_sub<2>(zero, Y1);
 #pragma unroll
     for (int i = 0; i < Fq30::NL; i++) { ZZ.v[i] = Fq30Params::ONE[i]; ZZZ.v[i] = Fq30Params::ONE[i]; }
@@ -651,36 +620,15 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
   for (u32 k = 1; k < cnt; k++) {
     const u32 e = e_next;
     if (k + 1 < cnt) e_next = lst[k + 1];           // one iteration ahead: takes the list load off the critical path
-    Fq30 P, R;
-    if (SHOUP) {
-      const G1Aff30S* q = tabs + (e & 0x7fffffffu);
-      u32 cx[LIMB_SLOTS], cq[LIMB_SLOTS];
-#pragma unroll
-      for (int i = 0; i < LIMB_SLOTS; i += 4) {
-        const uint4 a = *reinterpret_cast<const uint4*>(q->x + i), b = *reinterpret_cast<const uint4*>(q->xq + i);
-        cx[i] = a.x; cx[i + 1] = a.y; cx[i + 2] = a.z; cx[i + 3] = a.w; cq[i] = b.x; cq[i + 1] = b.y; cq[i + 2] = b.z; cq[i + 3] = b.w;
-      }
-      P = f30_sub<8>(f30_mulshoup(ZZ, cx, cq), X1);
-      if (__builtin_expect(f30_is_zero<32u>(P), 0)) { pend[gid] = 1; atomicAdd(n_deferred, 1u); return; }
-#pragma unroll
-      for (int i = 0; i < LIMB_SLOTS; i += 4) {
-        const uint4 a = *reinterpret_cast<const uint4*>(q->y + i), b = *reinterpret_cast<const uint4*>(q->yq + i);
-        cx[i] = a.x; cx[i + 1] = a.y; cx[i + 2] = a.z; cx[i + 3] = a.w; cq[i] = b.x; cq[i + 1] = b.y; cq[i + 2] = b.z; cq[i + 3] = b.w;
-      }
-      Fq30 S2 = f30_mulshoup(ZZZ, cx, cq);
-      if (e & 0x80000000u) S2 = f30_sub<16>(zero, S2);
-      R = f30_sub<4>(S2, Y1);
-    } else {
     const G1Aff30* q = tab + (e & 0x7fffffffu);
     const Fq30 x2 = load30(q->x);
     Fq30 y2 = load30(q->y);
     if (e & 0x80000000u) y2 = f30_sub<2>(zero, y2);
-    P = f30_sub<8>(f30_mul(x2, ZZ), X1);
+    const Fq30 P = f30_sub<8>(f30_mul(x2, ZZ), X1);
     // equal x (the same point twice, or P and -P): leave the whole bucket to the fix-up pass, which recomputes it with the
     // complete addition law.  The lists are read-only here because two jobs may share them (FbWin::delta).
     if (__builtin_expect(f30_is_zero(P), 0)) { pend[gid] = 1; atomicAdd(n_deferred, 1u); return; }
-    R = f30_sub<4>(f30_mul(y2, ZZZ), Y1);
-    }
+    const Fq30 R = f30_sub<4>(f30_mul(y2, ZZZ), Y1);
     Fq30 PP = f30_sqr(P);
     ZZ = f30_mul(ZZ, PP);
     const Fq30 Q = f30_mul(X1, PP);
@@ -697,7 +645,6 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
 // buckets that met an equal-x pair (pend != 0): recomputed from their whole list with the complete group law in the
 // standard representation, one thread per such bucket (a small grid-stride launch that returns at once in the usual case
 // of no deferred bucket at all)
-template <bool SHOUP>
 __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                      const u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                      const u32* __restrict__ tot, const u32* __restrict__ pend,
@@ -712,16 +659,8 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
   G1Xyzz acc = G1Xyzz::identity();
   for (u32 k = 0; k < cnt; k++) {
     const u32 e = lst[k];
-    Fq x, y;
-    if (SHOUP) {                                         // plain integers below p -> the standard Montgomery form
-      const G1Aff30S* qs = reinterpret_cast<const G1Aff30S*>(table) + d.delta + (e & 0x7fffffffu);
-      x = ff_to_mont(f30_pack(load30(qs->x)));
-      y = ff_to_mont(f30_pack(load30(qs->y)));
-    } else {
-      const G1Aff30* q = tab + (e & 0x7fffffffu);
-      x = f30_to_fq(load30(q->x));
-      y = f30_to_fq(load30(q->y));
-    }
+    const G1Aff30* q = tab + (e & 0x7fffffffu);
+    Fq x = f30_to_fq(load30(q->x)), y = f30_to_fq(load30(q->y));
     if (e & 0x80000000u) y = ff_neg(y);
     g1_madd(acc, x, y);
   }
@@ -842,29 +781,6 @@ __global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ 
     f30_mul2_mul(r0, a30, b30, wa, wb, r1, wb, b30); same30(r0, f30_mul2(a30, b30, wa, wb)); same30(r1, f30_mul(wb, b30));
     r0 = a30; r1 = b30;
     f30_mul_x2(r0, r0, r1, r1, r1, r0); same30(r0, c30); same30(r1, c30);           // outputs alias inputs
-  }
-  {
-    // Shoup product by a constant (MH_FB_SHOUP=1): b as the table would hold it -- the plain integer and its quotient, derived
-    // exactly as table_level_kernel<true> derives them -- against the Montgomery product, reduced and lazily reduced multiplicand;
-    // the seed of a bucket (plain x times R'^2 mod p); the zero filter up to 32 p
-    Fq one;
-#pragma unroll
-    for (int k = 0; k < Fq::N; k++) one.v[k] = k == 0 ? 1u : 0u;
-    const Fq30 bp = f30_split(ff_mul(b, one)), bq = f30_shoup_quotient(b30);
-    u32 cw[LIMB_SLOTS], cq[LIMB_SLOTS];
-#pragma unroll
-    for (int k = 0; k < LIMB_SLOTS; k++) { cw[k] = k < Fq30::NL ? bp.v[k] : 0; cq[k] = k < Fq30::NL ? bq.v[k] : 0; }
-    same(f30_to_fq(f30_mulshoup(a30, cw, cq)), ff_mul(a, b));
-    const Fq30 wa = f30_add(f30_add(f30_dbl(f30_dbl(a30)), f30_dbl(f30_dbl(b30))), a30);
-    same(f30_to_fq(f30_mulshoup(wa, cw, cq)), f30_to_fq(f30_mul(wa, b30)));
-    Fq30 rr;
-#pragma unroll
-    for (int k = 0; k < Fq30::NL; k++) rr.v[k] = Fq30Params::RR[k];
-    same(f30_to_fq(f30_mul(bp, rr)), b);
-    Fq30 zero30;
-#pragma unroll
-    for (int k = 0; k < Fq30::NL; k++) zero30.v[k] = 0;
-    ok = ok && f30_is_zero<32u>(f30_sub<16>(a30, a30)) && f30_is_zero<32u>(f30_sub<16>(zero30, f30_sub<16>(zero30, f30_sub<2>(a30, a30))));
   }
   same(f30_to_fq(f30_sub<2>(f30_add(c30, a30), a30)), ff_mul(a, b));
   same(f30_to_fq(f30_mul(f30_sub<2>(a30, b30), f30_add(a30, b30))), f30_to_fq(f30_sub<2>(f30_sqr(a30), f30_sqr(b30))));
