@@ -12,6 +12,7 @@
 #include "ntt30.cuh"
 #include "srs.cuh"
 #include "host_ff.h"
+#include "host_pool.h"
 
 using namespace mh;
 using hostff::HFq;
@@ -71,10 +72,12 @@ static void plan_passes(uint32_t log_n, uint32_t* bits, int* npass) {
   *npass = np;
 }
 
-// MH_NTT=32 selects the 32-bit-limb radix-2 kernel of ntt.cuh (the cross-check of the 30-bit radix-8 kernel of ntt30.cuh);
-// MH_NTT=shoup the 30-bit kernel with the twiddle products as Shoup multiplications (opt-in, ntt30.cuh: butterfly_shoup)
+// MH_NTT=32 selects the 32-bit-limb radix-2 kernel of ntt.cuh (the cross-check of the 30-bit radix-8 kernel of ntt30.cuh).  The
+// 30-bit kernel takes its twiddle products as Shoup multiplications (ntt30.cuh: butterfly_shoup) in the one-stage rounds -- round 4
+// measured it behind a switch (-0.2 ... -0.35 ms per proof at 2^20, profiles/r04zh_*), round 5 ran the whole suite on it and made it
+// the default -- and as Montgomery products in the two-stage rounds of the >= 2^23-point transforms (wider twiddles cost registers there).
 static bool ntt_use30() { static const bool v = [] { const char* e = getenv("MH_NTT"); return !(e && atoi(e) == 32); }(); return v; }
-static bool ntt_shoup() { static const bool v = [] { const char* e = getenv("MH_NTT"); return e && !strcmp(e, "shoup"); }(); return v; }
+static bool ntt_shoup() { return ntt_use30(); }
 
 static int launch_pass(Context& c, const Fr* x, Fr* y, uint32_t log_n, uint32_t B, uint32_t logP, uint32_t flags,
                        const Fr& ninv, uint64_t in_len) {
@@ -83,9 +86,8 @@ static int launch_pass(Context& c, const Fr* x, Fr* y, uint32_t log_n, uint32_t 
   if (ntt_use30()) {
     const uint64_t blocks30 = (1ull << (log_n - B)) >> logc;
     const u32* tw30 = (const u32*)c.tw30;
-    // stages per register round: 2 from 2^23 points on, 1 below (measured, see ntt30.cuh); MH_NTT_NS overrides
-    static const int env_ns = [] { const char* e = getenv("MH_NTT_NS"); return e ? atoi(e) : 0; }();
-    const int ns = env_ns ? env_ns : (log_n >= 23 ? 2 : 1);
+    // stages per register round: 2 from 2^23 points on, 1 below (measured, see ntt30.cuh)
+    const int ns = log_n >= 23 ? 2 : 1;
 #define NTT30_LAUNCH_T(LC, NS, SH, TW) hipLaunchKernelGGL((ntt30::pass30_kernel<LC, NS, 256, 4, 0, false, SH>), dim3((unsigned)blocks30), dim3(256), \
     ntt30::pass_lds_bytes(B, (int)logc, logP == 0, 0, false), c.stream, x, y, TW, log_n, B, logP, flags, ninv, (u64)in_len)
 #define NTT30_LAUNCH(LC, NS) NTT30_LAUNCH_T(LC, NS, false, tw30)
@@ -321,8 +323,8 @@ static int msm_set_attrs() {
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::reduce2_30_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::reduce2_30_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(msmfb::PLANE_THREADS * sizeof(msmfb::G1Xyzz30))));
   g_msm_attr_done = true;
   return MH_OK;
 }
@@ -433,9 +435,10 @@ struct FbRun {
   msm::Windows win; u32 W = 0, nbt = 0, pshift = 0, nb = 0, nparts = 0, WT = 0; size_t WB = 0;
   msmfb::Own own{0, 1}; bool partial = false; u32 nbown = 0, S = 0;
   msmfb::FbJobs jobs; std::vector<int> alias;
-  u64 ent = 0, pco = 0, tile = 0, max_tiles_total = 0; u32 max_blk = 0, seg = 0, nseg = 0, chunks = 1;
+  u64 ent = 0, pco = 0, tile = 0, max_tiles_total = 0; u32 max_blk = 0;
+  msmfb::RsPlan rs; std::vector<u64> coef;        // bucket reduction: matrix shape, chunking, planes; the host's coefficient of each plane
   std::vector<msmfb::FbWin> desc; std::vector<msmfb::FbBlk> blk; std::vector<u32> ptot;
-  bool skewed = false, quad1 = false, quad2 = false;
+  bool skewed = false;
   u32 skew_limit = 0xffffffffu;
   FbRun(Context& c_, const BaseSet& bs_, Context::FbWs& ws_) : c(c_), bs(bs_), ws(ws_) {}
 
@@ -461,8 +464,7 @@ struct FbRun {
     // hence the same sorted bucket lists: it skips the sort stages and reads the other job's lists with its table indices
     // shifted by the distance of the base ranges (FbWin::delta).  Accumulation and reduction stay per job.
     alias.assign(nj, -1);
-    static const bool alias_on = [] { const char* e = getenv("MH_FB_ALIAS"); return !(e && atoi(e) == 0); }();
-    for (int k = 1; k < nj && alias_on; k++)
+    for (int k = 1; k < nj; k++)
       for (int j = 0; j < k; j++)
         if (alias[j] < 0 && sc[j] == sc[k] && ns[j] == ns[k] && offs[k] >= offs[j] && strides[j] == strides[k]) { alias[k] = j; break; }
     ent = 0; pco = 0; max_blk = 0;
@@ -486,29 +488,38 @@ struct FbRun {
     MH_TRY(ws.bh.ensure(max_tiles_total * nb * 4));
     MH_TRY(ws.tot.ensure(WB * 4)); MH_TRY(ws.base.ensure(WB * 4)); MH_TRY(ws.pend.ensure(WB * 4));
     MH_TRY(ws.buckets.ensure(WB * sizeof(F::G1Xyzz30)));
-    // segment length of the bucket reduction: >= 49152 threads per launch (measured best: 31.2 ms vs 36.1 ms with SEG fixed,
-    // 32.7 ms at 65536, per 3 proofs), at most SEG buckets each; MH_FB_SEG_THREADS overrides
-    seg = msm::SEG;
-    static const u64 seg_threads_env = [] { const char* e = getenv("MH_FB_SEG_THREADS"); return e ? (u64)atoll(e) : 0ull; }();
-    // One point per quad of lanes (msm_fb_quad.cuh): an addition is 4 dependent multiplications instead of 14 (2,807
-    // instructions instead of 7,099), but a lone wave then has no second multiplication to interleave and issues an
-    // instruction every ~11 cycles instead of every ~6: 13 us per addition against 17 us.  Measured (profiles/r03p_*): the
-    // tree stage (reduce2, a pure chain) of a bucket-range shard of 8 gains 0.5 ms per proof (6.39 -> 5.88 ms of sort +
-    // reduce stages), on one GPU it loses 0.2 ms; the segment stage loses everywhere (its chains get longer at the same
-    // lane count: +0.6 ms on a rank of 8, +5 ms on one GPU).  So: reduce2 only, and only for the small launches of a
-    // shard.  MH_FB_QUAD = 0 (off) | 1 (reduce2) | 2 (both stages) overrides.
-    static const int quad_env = [] { const char* e = getenv("MH_FB_QUAD"); return e ? atoi(e) : -1; }();
-    static const u64 quad_max = [] { const char* e = getenv("MH_FB_QUAD_MAX"); return e ? (u64)atoll(e) : (1ull << 19); }();
-    quad2 = quad_env < 0 ? (partial && (u64)nj * nbown <= quad_max) : quad_env >= 1;
-    quad1 = quad_env >= 2;
-    const u64 seg_threads = seg_threads_env ? seg_threads_env : (quad1 ? 65536ull : 49152ull);
-    const u64 lanes = quad1 ? 4 : 1;
-    if (seg > nb) seg = nb;                                              // a segment stays inside one partition
-    while (seg > 4 && (u64)nj * (nbown / seg) * lanes < seg_threads) seg >>= 1;
-    nseg = nbown / seg;
-    chunks = nseg >= 4096 ? nseg / 256 : 1;                              // reduce2 in two launches when nseg is large
-    MH_TRY(ws.seg.ensure((size_t)nj * (nseg + chunks) * sizeof(F::G1Xyzz30)));
-    MH_TRY(ws.win.ensure((size_t)nj * sizeof(G1Xyzz)));
+    // Bucket reduction (msm_fb.cuh: rsum / plane kernels): the owned buckets as R_own rows of C, every row and every column summed
+    // by a group of lanes -- as many lanes that the launch has about two waves per SIMD (the kernel holds 214 registers), at
+    // most a wave's 64 --, then the bit planes of the row and column indices.  With a rank's partitions interleaved (v = first, first + stride, ...) the
+    // global row of local row m is r(m) = first rpp + stride rpp (m / rpp) + m % rpp: the planes run over the bits of m and
+    // the constants go into the host's coefficients.
+    {
+      memset(&rs, 0, sizeof(rs));
+      u32 lgown = 0;
+      while ((1ull << lgown) < nbown) lgown++;
+      rs.lgC = std::min<u32>(pshift, (lgown + 1) / 2);
+      if (rs.lgC < 1) rs.lgC = 1;
+      rs.C = 1u << rs.lgC;
+      rs.lgrpp = pshift - rs.lgC;
+      rs.R_own = nbown >> rs.lgC;
+      rs.lgM = 0;
+      while ((1u << rs.lgM) < rs.R_own) rs.lgM++;
+      const u64 target = 128ull * (u64)c.num_simds;                                  // threads of the launch: two waves per SIMD
+      const u64 Lt = std::max<u64>(1, (2ull * nj * nbown + target - 1) / target);   // buckets per thread that would give them
+      auto lanes = [&](u64 len) { u32 lg = 0; while (lg < 6 && (2ull << lg) * Lt <= len) lg++; return lg; };
+      rs.lgJ = lanes(rs.C); rs.J = 1u << rs.lgJ; rs.Lr = rs.C >> rs.lgJ;
+      rs.lgI = lanes(1ull << rs.lgM); rs.I = 1u << rs.lgI; rs.Lc = (rs.R_own + rs.I - 1) / rs.I;
+      rs.NTr = (u32)(((u64)rs.R_own * rs.J + 63) & ~63ull);
+      rs.NT = rs.NTr + (u32)(((u64)rs.C * rs.I + 63) & ~63ull);
+      rs.NS = rs.R_own + rs.C;
+      rs.nplanes = rs.lgC + rs.lgM + 1;
+      coef.assign(rs.nplanes, 0);
+      for (u32 p = 0; p < rs.lgC; p++) coef[p] = 1ull << p;
+      for (u32 p = 0; p < rs.lgM; p++) coef[rs.lgC + p] = ((u64)rs.C << p) * (p < rs.lgrpp ? 1ull : (u64)own.stride);
+      coef[rs.nplanes - 1] = (((u64)rs.C * own.first) << rs.lgrpp) + 1;
+    }
+    MH_TRY(ws.seg.ensure((size_t)nj * rs.NS * sizeof(F::G1Xyzz30)));
+    MH_TRY(ws.win.ensure((size_t)nj * rs.nplanes * sizeof(G1Xyzz)));
     MH_TRY(ws.sums.ensure(64 + F::SIZE_BINS * 4));
     MH_TRY(ws.perm.ensure(WB * 4));
     desc.assign(WT, msmfb::FbWin{});
@@ -529,11 +540,9 @@ struct FbRun {
     hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
     // The partition totals are final once pscan has run, BEFORE the split kernel: they go to the host on the copy stream while
     // the split runs on `s`, so the host's round trip (descriptors, block list) hides behind a kernel instead of idling the GPU
-    // (one of the two host synchronisations per MSM batch; the other one carries the results).  MH_FB_PTOT_OVERLAP=0: the copy
-    // queued behind the split on `s`, as before.
-    static const bool ptot_overlap = [] { const char* e = getenv("MH_FB_PTOT_OVERLAP"); return !(e && atoi(e) == 0); }();
+    // (one of the two host synchronisations per MSM batch; the other one carries the results).
     MH_TRY(ws.h_ptot.ensure((size_t)WT * 4));
-    const bool side_copy = ptot_overlap && c.copy_stream && c.copy_ev;
+    const bool side_copy = c.copy_stream && c.copy_ev;
     if (side_copy) {
       MH_HIP(hipEventRecord(c.copy_ev, s));
       MH_HIP(hipStreamWaitEvent(c.copy_stream, c.copy_ev, 0));
@@ -638,28 +647,19 @@ struct FbRun {
     {
       ProfScope pa(c, PF_MSM_ACCUM, s);
       const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
-      // resident waves per SIMD of the accumulate kernel (register budget 512 / waves): MH_ACC_WAVES = 3 | 4
-      // Resident waves per SIMD.  With the chip full (one GPU: ~32 equally long waves per SIMD and launch) 2 and 3 run the
+      // Resident waves per SIMD of the accumulate kernel (register budget 512 / waves).  With the chip full (one GPU: ~32 equally long waves per SIMD and launch) 2 and 3 run the
       // kernel at the same rate -- it is bound by VALU issue -- and 3 is the default.  A bucket-range shard of 8 ranks leaves
       // only ~4 waves per SIMD: at 3 resident the fourth runs ALONE, and one wave issues at ~2/3 of the rate two or three
       // reach together; at 4 resident (128 VGPRs, 224 B of scratch) every wave pays for its spills.  Measured on a simulated
       // rank of 8 (profiles/r03j_sim_*): 8.2 / 9.1 / 10.5 ms of accumulation per proof at 2 / 3 / 4 waves at 2^20, 32.5 / 36.6 /
       // 41.5 ms at 2^22 -- 2 also wins where 3 would leave no lone wave (round 3: 3 waves per SIMD), so part of it is the 3-wave
       // build's 28 B of scratch, which a full chip hides and a thin launch does not --; rank of 4 (8 waves per SIMD): 14.9 /
-      // 14.5 / 16.9.  So: 2 when a launch has at most 6 waves per SIMD, else 3.  MH_ACC_WAVES = 2 | 3 | 4 overrides.
-      static const int env_waves = [] { const char* e = getenv("MH_ACC_WAVES"); int w = e ? atoi(e) : 0; return (w >= 2 && w <= 4) ? w : 0; }();
-      int acc_waves = env_waves ? env_waves : 3;
-      if (!env_waves) {
-        const u64 active = (u64)nj * nbown;                                   // buckets that do work on this rank
-        const u64 per_simd = (active / 64 + (u64)c.num_simds - 1) / (u64)c.num_simds;
-        if (per_simd <= 6) acc_waves = 2;
-      }
+      // 14.5 / 16.9.  So: 2 when a launch has at most 6 waves per SIMD, else 3.
+      const u64 active = (u64)nj * nbown;                                     // buckets that do work on this rank
+      const u64 per_simd = (active / 64 + (u64)c.num_simds - 1) / (u64)c.num_simds;
+      const int acc_waves = per_simd <= 6 ? 2 : 3;
       if (acc_waves == 2)
         hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
-                           (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
-                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
-      else if (acc_waves == 4)
-        hipLaunchKernelGGL(F::accum30_kernel<4>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
                            (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
       else
@@ -691,153 +691,83 @@ struct FbRun {
     return MH_OK;
   }
 
-  // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1
+  // one bucket set of nbt buckets per job: bucket b (0-based, across the virtual windows) weighs b + 1.  Row / column sums, then the
+  // bit planes of the row and column indices (msm_fb.cuh); finish() combines the planes on the host.
   int reduce(hipStream_t s) {
     namespace F = msmfb;
     ProfScope ps(c, PF_MSM_STAGES, s);
-    // the group law with its independent multiplications as interleaved chains (msm_fb.cuh x30_add_ilp): one wave per SIMD
-    // issues ~1.4 x faster through the same chain of additions.  MH_FB_ILP=0: the one-chain group law.
-    static const bool ilp = [] { const char* e = getenv("MH_FB_ILP"); return !(e && atoi(e) == 0); }();
-    F::G1Xyzz30* seg30 = (F::G1Xyzz30*)ws.seg.ptr;
-    if (quad1)
-      hipLaunchKernelGGL(F::reduce1_q_kernel, dim3((unsigned)(((u64)nj * nseg * 4 + 255) / 256)), dim3(256), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
-                         seg30, nbt, nseg, (u32)nj, seg, nb, own, (const u32*)ws.sums.ptr, skew_limit);
-    else if (ilp)
-      hipLaunchKernelGGL(F::reduce1_30_kernel<true>, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
-                         seg30, nbt, nseg, (u32)nj, seg, nb, own, (const u32*)ws.sums.ptr, skew_limit);
-    else
-      hipLaunchKernelGGL(F::reduce1_30_kernel<false>, dim3(((u32)nj * nseg + 63) / 64), dim3(64), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr,
-                         seg30, nbt, nseg, (u32)nj, seg, nb, own, (const u32*)ws.sums.ptr, skew_limit);
-    const size_t r2lds = (quad2 ? 64 : 256) * sizeof(F::G1Xyzz30);
-    auto r2 = quad2 ? F::reduce2_q_kernel : (ilp ? F::reduce2_30_kernel<true> : F::reduce2_30_kernel<false>);
-    if (chunks > 1) {
-      F::G1Xyzz30* mid = seg30 + (size_t)nj * nseg;
-      hipLaunchKernelGGL(r2, dim3(chunks, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, mid, (G1Xyzz*)nullptr, nseg, 0);
-      hipLaunchKernelGGL(r2, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)mid, (F::G1Xyzz30*)nullptr,
-                         (G1Xyzz*)ws.win.ptr, chunks, 1);
-    } else {
-      hipLaunchKernelGGL(r2, dim3(1, nj), dim3(256), r2lds, s, (const F::G1Xyzz30*)seg30, (F::G1Xyzz30*)nullptr,
-                         (G1Xyzz*)ws.win.ptr, nseg, 1);
-    }
+    F::G1Xyzz30* sums = (F::G1Xyzz30*)ws.seg.ptr;
+    const u32* d_max = (const u32*)ws.sums.ptr;
+    const u64 threads = (u64)nj * rs.NT;
+    hipLaunchKernelGGL(F::rsum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr, sums, nbt,
+                       (u32)nj, rs, own, d_max, skew_limit);
+    hipLaunchKernelGGL(F::plane_kernel, dim3(rs.nplanes, (unsigned)nj), dim3(F::PLANE_THREADS), F::PLANE_THREADS * sizeof(F::G1Xyzz30), s,
+                       (const F::G1Xyzz30*)sums, (G1Xyzz*)ws.win.ptr, rs, d_max, skew_limit);
     MH_HIP(hipGetLastError());
     return MH_OK;
   }
 
-  // the nj sums to the host (synchronises `s`)
+  // the planes of every job to the host (synchronises `s`), then sum_planes coef[p] x plane[p] per job: one shared chain of
+  // doublings with the planes added where their coefficient has the bit -- ~20 doublings and ~20 additions of a CPU core, the
+  // jobs side by side on the host pool
   int finish(hipStream_t s, HG1* out) {
-    const size_t sums_n = (size_t)nj * XYZZ_L;
+    const size_t npl = rs.nplanes, sums_n = (size_t)nj * npl * XYZZ_L;
     MH_TRY(ws.h_out.ensure(sums_n * 8 + 8));
     uint64_t* sums_h = (uint64_t*)ws.h_out.ptr;
     MH_HIP(hipMemcpyAsync(sums_h, ws.win.ptr, sums_n * 8, hipMemcpyDeviceToHost, s));
     MH_HIP(hipMemcpyAsync(sums_h + sums_n, ws.sums.ptr, 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     const u32 mx = *(const u32*)(sums_h + sums_n);
-    std::vector<uint64_t> sums(sums_h, sums_h + sums_n);
     skewed = mx > skew_limit;                      // the kernels returned at once: `out` is not a result
     if (skewed) return MH_OK;
-    for (int k = 0; k < nj; k++) {
-      const uint64_t* p = sums.data() + (size_t)k * XYZZ_L;
-      HFq X, Y, ZZ, ZZZ;
-      memcpy(X.v, p, FQ_B); memcpy(Y.v, p + FQ_L, FQ_B); memcpy(ZZ.v, p + 2 * FQ_L, FQ_B); memcpy(ZZZ.v, p + 3 * FQ_L, FQ_B);
-      out[k] = HG1::from_xyzz(X, Y, ZZ, ZZZ);
-    }
+    int top = 0;
+    for (u64 cf : coef) while ((cf >> top) > 1) top++;
+    const std::vector<u64>* cfs = &coef;
+    auto combine = [sums_h, npl, top, cfs](int k) {
+      std::vector<HG1> pl(npl);
+      for (size_t i = 0; i < npl; i++) {
+        const uint64_t* p = sums_h + ((size_t)k * npl + i) * XYZZ_L;
+        HFq X, Y, ZZ, ZZZ;
+        memcpy(X.v, p, FQ_B); memcpy(Y.v, p + FQ_L, FQ_B); memcpy(ZZ.v, p + 2 * FQ_L, FQ_B); memcpy(ZZZ.v, p + 3 * FQ_L, FQ_B);
+        pl[i] = HG1::from_xyzz(X, Y, ZZ, ZZZ);
+      }
+      HG1 acc = HG1::identity();
+      for (int bit = top; bit >= 0; bit--) {
+        acc = acc.dbl();
+        for (size_t i = 0; i < npl; i++) if (((*cfs)[i] >> bit) & 1) acc = acc.add(pl[i]);
+      }
+      return acc;
+    };
+    std::vector<std::future<HG1>> fut(nj);
+    WaitAll wait; 
+    for (int k = 1; k < nj; k++) fut[k] = host_pool().submit([combine, k] { return combine(k); });
+    wait.add(fut);
+    out[0] = combine(0);
+    for (int k = 1; k < nj; k++) out[k] = fut[k].get();
     return MH_OK;
   }
 };
 
-// One group of <= MAX_JOBS jobs on the fixed-base path.  skewed = true (and nothing written) when a bucket is so overfull
-// that the caller should take the variable-base path with its pair-tree accumulation instead.
-//
-// DEFAULT: the whole group on the main stream, sort -> accumulate -> reduce.  OPT-IN (MH_FB_SPLIT=1), measured slower and kept
-// only as a switch (80.8 vs 78.1 ms per proof, profiles/r03a_*: the accumulate kernel fills every SIMD's registers, so a
-// second stream only ever runs in its tail): the group as TWO sub-batches A, B (jobs that share sorted lists stay together) in
-// a software pipeline over two streams --
-//     main stream :  sort(A)  accum(A)             accum(B)   reduce(B)
-//     side stream :                    sort(B)                reduce(A)
-// sort(B) fills the issue slots accum(A) leaves free and reduce(A) those of accum(B); only sort(A) and reduce(B) stay
-// exposed.  The split minimises the modelled makespan over all 2-partitions of the jobs (<= 2^8): the exposed sort wants
-// few entries in A, the exposed reduction few jobs in B (its cost is per bucket set, not per scalar).
+// One group of <= MAX_JOBS jobs on the fixed-base path, on the main stream: sort -> accumulate -> reduce -> combine on the host.
+// skewed = true (and nothing written) when a bucket is so overfull that the caller should take the variable-base path with its
+// pair-tree accumulation instead.  (Rounds 3-4 carried an opt-in two-stream software pipeline over two sub-batches here; it
+// measured slower -- 80.8 vs 78.1 ms per proof, profiles/r03a_*: the accumulate kernel fills every SIMD's registers, so a
+// second stream only ever ran in its tail -- and is gone; `git show 3c10b42:marlin_amd/csrc/capi.hip` has it.)
 static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* offs, const void* const* d_scalars, const size_t* ns,
                            int is_mont, HG1* out, bool& skewed, const int* shard, bool& partial, const size_t* strides = nullptr) {
   skewed = false;
-  hipStream_t s0 = c.stream, s1 = c.stream2;
+  hipStream_t s0 = c.stream;
   ProfScope wall(c, PF_MSM, s0);
-  msm::Windows win;
-  const u32 W = msm::make_windows(bs.tab_c, win);
-  // atoms: a job plus the jobs that would alias it (same scalars, same length, bases further into the set)
-  std::vector<int> atom_of(nj, -1);
-  std::vector<std::vector<int>> atoms;
+  FbRun A(c, bs, c.fbws);
   for (int k = 0; k < nj; k++) {
-    if (atom_of[k] >= 0) continue;
-    atom_of[k] = (int)atoms.size(); atoms.push_back({k});
-    for (int j = k + 1; j < nj; j++)
-      if (atom_of[j] < 0 && d_scalars[j] == d_scalars[k] && ns[j] == ns[k] && (!strides || strides[j] == strides[k])) { atom_of[j] = atom_of[k]; atoms.back().push_back(j); }
-  }
-  static const int split_on = [] { const char* e = getenv("MH_FB_SPLIT"); return e ? atoi(e) : 0; }();
-  u64 tot_ent = 0;
-  for (int k = 0; k < nj; k++) tot_ent += (u64)W * ns[k];
-  uint32_t best_mask = 0;
-  if (split_on && s1 && atoms.size() >= 2 && tot_ent >= (16ull << 20)) {
-    // modelled times in picoseconds (2^20-constraint proof on MI355X: sort 16 ps per entry, accumulate 132 ps per entry,
-    // bucket reduction 0.52 ms per set of 2^19 buckets)
-    const double nbown_frac = (double)(1u << (bs.tab_c - 1)) / (double)(1u << 19) / ((shard && shard[1] > 1) ? (double)shard[1] : 1.0);
-    const double shard_frac = (shard && shard[1] > 1) ? 1.0 / (double)shard[1] : 1.0;
-    double best = 1e300;
-    const int na = (int)atoms.size();
-    for (uint32_t m = 1; m + 1 < (1u << na); m++) {            // m = atoms of A; both sides non-empty
-      double sortA = 0, sortB = 0, accA = 0, accB = 0, redA = 0, redB = 0;
-      for (int a = 0; a < na; a++) {
-        const double e = (double)W * (double)ns[atoms[a][0]];
-        const double srt = 16.0 * e * (0.3 + 0.7 * shard_frac);          // count / split recode every scalar on every rank
-        const double acc = 132.0 * e * (double)atoms[a].size() * shard_frac;
-        const double red = 0.52e9 * nbown_frac * (double)atoms[a].size();
-        if (m & (1u << a)) { sortA += srt; accA += acc; redA += red; } else { sortB += srt; accB += acc; redB += red; }
-      }
-      // concurrent kernels share the VALU: what runs beside an accumulation is modelled as half hidden
-      const double t = sortA + std::max(accA, sortB) + 0.5 * std::min(accA, sortB) + std::max(accB, redA) + 0.5 * std::min(accB, redA) + redB;
-      if (t < best) { best = t; best_mask = m; }
-    }
-  }
-  FbRun A(c, bs, c.fbws[0]), B(c, bs, c.fbws[1]);
-  std::vector<int> idxA, idxB;
-  for (int k = 0; k < nj; k++) {
-    const bool inA = best_mask == 0 || (best_mask & (1u << atom_of[k]));
-    FbRun& r = inA ? A : B;
-    (inA ? idxA : idxB).push_back(k);
-    r.offs.push_back(offs[k]); r.sc.push_back(d_scalars[k]); r.ns.push_back(ns[k]); r.strides.push_back(strides ? strides[k] : 1);
+    A.offs.push_back(offs[k]); A.sc.push_back(d_scalars[k]); A.ns.push_back(ns[k]); A.strides.push_back(strides ? strides[k] : 1);
   }
   MH_TRY(A.prepare(is_mont, shard));
   partial = A.partial;
-  if (idxB.empty()) {
-    MH_TRY(A.sort(s0));
-    MH_TRY(A.accum(s0)); MH_TRY(A.reduce(s0));
-    MH_TRY(A.finish(s0, out));
-    if (A.skewed) { skewed = true; partial = false; }
-    return MH_OK;
-  }
-  MH_TRY(B.prepare(is_mont, shard));
-  hipEvent_t* ev = c.fb_ev;
-  // the side stream starts behind everything already queued on the main stream (the scalars are produced there)
-  MH_HIP(hipEventRecord(ev[0], s0)); MH_HIP(hipStreamWaitEvent(s1, ev[0], 0));
-  auto bail = [&](int rc) { (void)hipStreamSynchronize(s1); (void)hipStreamSynchronize(s0); return rc; };
-  int rc = A.sort(s0);
-  if (rc != MH_OK) return bail(rc);
-  if ((rc = A.accum(s0)) != MH_OK) return bail(rc);
-  MH_HIP(hipEventRecord(ev[1], s0));                                   // accum(A) done
-  if ((rc = B.sort(s1)) != MH_OK) return bail(rc);                     // beside accum(A)
-  MH_HIP(hipEventRecord(ev[2], s1)); MH_HIP(hipStreamWaitEvent(s0, ev[2], 0));
-  if ((rc = B.accum(s0)) != MH_OK) return bail(rc);
-  MH_HIP(hipStreamWaitEvent(s1, ev[1], 0));
-  if ((rc = A.reduce(s1)) != MH_OK) return bail(rc);                   // beside accum(B)
-  MH_HIP(hipEventRecord(ev[3], s1));
-  if ((rc = B.reduce(s0)) != MH_OK) return bail(rc);
-  MH_HIP(hipStreamWaitEvent(s0, ev[3], 0));                            // main stream is again behind everything
-  std::vector<HG1> ra(idxA.size()), rb(idxB.size());
-  if ((rc = A.finish(s0, ra.data())) != MH_OK) return bail(rc);
-  if ((rc = B.finish(s0, rb.data())) != MH_OK) return bail(rc);
-  if (A.skewed || B.skewed) { skewed = true; partial = false; return bail(MH_OK); }
-  for (size_t i = 0; i < idxA.size(); i++) out[idxA[i]] = ra[i];
-  for (size_t i = 0; i < idxB.size(); i++) out[idxB[i]] = rb[i];
+  MH_TRY(A.sort(s0));
+  MH_TRY(A.accum(s0)); MH_TRY(A.reduce(s0));
+  MH_TRY(A.finish(s0, out));
+  if (A.skewed) { skewed = true; partial = false; }
   return MH_OK;
 }
 
@@ -1254,7 +1184,6 @@ int mh_init(int device_id) {
   MH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   c.own_stream = true;
   MH_HIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
-  for (auto& e : c.fb_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   MH_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
   MH_HIP(hipEventCreateWithFlags(&c.copy_ev, hipEventDisableTiming));
   for (auto& e : c.side_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1290,12 +1219,11 @@ int mh_shutdown(void) {
   c.bases.clear();
   for (auto& kv : c.g2_bases) if (kv.second.d_points) (void)hipFree(kv.second.d_points);
   c.g2_bases.clear();
-  c.fbws[0].release_all(); c.fbws[1].release_all();
+  c.fbws.release_all();
   for (auto& kv : c.ntt_dist_tabs) kv.second.release();
   c.ntt_dist_tabs.clear();
   c.ntt_dist_buf[0].release(); c.ntt_dist_buf[1].release(); c.sl_send.release(); c.sl_recv.release();
   if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
-  for (auto& e : c.fb_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (c.copy_stream) { (void)hipStreamSynchronize(c.copy_stream); (void)hipStreamDestroy(c.copy_stream); c.copy_stream = nullptr; }
   if (c.copy_ev) { (void)hipEventDestroy(c.copy_ev); c.copy_ev = nullptr; }
   for (auto& e : c.side_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -1813,8 +1741,6 @@ int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out) {
   MH_HIP(hipMemcpyAsync(c.io.ptr, h.data(), h.size() * 4, hipMemcpyHostToDevice, c.stream));
   MH_HIP(hipMemsetAsync(d_bad, 0, 4, c.stream));
   hipLaunchKernelGGL(msmfb::selftest30_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c.stream, (const Fq*)c.io.ptr, (u64)n, d_bad);
-  // the one-point-per-quad group law of the bucket reduction against the one-lane form (msm_fb_quad.cuh)
-  hipLaunchKernelGGL(msmfb::selftest30_quad_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, (const Fq*)c.io.ptr, (u64)n, d_bad);
   MH_HIP(hipGetLastError());
   u32 bad = 0;
   MH_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c.stream));

@@ -103,7 +103,7 @@ struct Context {
   // NTT
   void* tw = nullptr;        // Fr[2^tw_log]
   void* tw30 = nullptr;      // the same table as 9 x 30-bit limbs of w R' mod r (ntt30.cuh), 36 B per entry
-  void* tw30s = nullptr;     // MH_NTT=shoup only: plain w and floor(w R' / r), 72 B per entry (ntt30.cuh: butterfly_shoup)
+  void* tw30s = nullptr;     // plain w and floor(w R' / r) for the Shoup twiddle products, 72 B per entry (ntt30.cuh: butterfly_shoup)
   uint32_t tw_log = 0;
   Scratch ntt_tmp[2];
   Scratch ntt_dist_buf[2], sl_send, sl_recv;
@@ -115,8 +115,7 @@ struct Context {
   std::map<uint64_t, G2Set> g2_bases;
   uint64_t next_handle = 1;
   Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win, msm_pend;
-  // fixed-base path (msm_fb.cuh): two workspaces; the second one, stream2 and fb_ev serve only the opt-in two-stream pipeline
-  // (MH_FB_SPLIT=1, measured slower and off by default: capi.hip: msm_fb_pipeline)
+  // fixed-base path (msm_fb.cuh): the workspace of one job group
   struct FbWs {
     Scratch dig, val, sorted, pc, ptot, desc, blk, bh, tot, base, pend, buckets, seg, win, sums, perm;
     Pinned h_ptot, h_desc, h_blk, h_out;      // host side of the partition totals, the descriptors, the block list, the results
@@ -124,9 +123,8 @@ struct Context {
       for (Scratch* b : {&dig, &val, &sorted, &pc, &ptot, &desc, &blk, &bh, &tot, &base, &pend, &buckets, &seg, &win, &sums, &perm}) b->release();
       for (Pinned* b : {&h_ptot, &h_desc, &h_blk, &h_out}) b->release();
     }
-  } fbws[2];
-  hipStream_t stream2 = nullptr;     // library-owned side stream of the fixed-base pipeline
-  hipEvent_t fb_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  } fbws;
+  hipStream_t stream2 = nullptr;     // library-owned side stream: the caller's independent work beside a bucket reduction (side_job)
   // a library-owned stream for small device-to-host copies that must not wait behind the kernels queued on `stream` (the partition
   // totals of the fixed-base sort travel to the host while the split kernel runs), and the event that orders it
   hipStream_t copy_stream = nullptr;

@@ -668,82 +668,122 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
   }
 }
 
-// ---- reduce1: thread per (job, segment of `seg` buckets), on 30-bit limbs ------------------------------------------
-// sum_b (b + 1) B_b over the job's single bucket set: running sums inside the segment plus (first bucket index) x
-// (segment total) by double-and-add; the result goes to msm::reduce2_kernel in the standard representation.
-// nseg segments cover the buckets of the owned partitions (pbuckets = 2^pshift buckets each, seg divides pbuckets, so
-// a segment never straddles two partitions): local segment s lies in owned partition number (s * seg) / pbuckets
-template <bool ILP>
-__global__ __launch_bounds__(64) void reduce1_30_kernel(const G1Xyzz30* __restrict__ buckets, G1Xyzz30* __restrict__ segsum, u32 nb,
-                                                        u32 nseg, u32 njobs, u32 seg, u32 pbuckets, Own own,
-                                                        const u32* __restrict__ largest, u32 skew_limit) {
-  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= njobs * nseg) return;
-  if (*largest > skew_limit) return;      // a skewed batch left this path in the accumulate kernel: the buckets hold nothing
-  const u32 w = gid / nseg, s = gid % nseg;
-  const u32 l = s * seg;                                          // index among the owned buckets
-  const u32 lo = (own.first + (l / pbuckets) * own.stride) * pbuckets + l % pbuckets;
-  const u32 hi = lo + seg;
-  X30 running = x30_identity(), acc = x30_identity();
-  const G1Xyzz30* B = buckets + (u64)w * nb;
-  static_assert(true, "");
-  for (u32 b = hi; b-- > lo;) {
-    X30 t = x30_load(B + b);
-    if (ILP) { x30_add_ilp(running, t); x30_add_ilp(acc, running); }
-    else { x30_add(running, t); x30_add(acc, running); }
-  }
-  if (lo) {
-    X30 m = x30_identity();
-    const int top = 31 - __clz(lo);
-    for (int bit = top; bit >= 0; bit--) {
-      if (ILP) x30_dbl_ilp(m); else x30_dbl(m);
-      if ((lo >> bit) & 1) { if (ILP) x30_add_ilp(m, running); else x30_add(m, running); }
-    }
-    if (ILP) x30_add_ilp(acc, m); else x30_add(acc, m);
-  }
-  x30_store(segsum + gid, acc);
+// ---- bucket reduction: row / column sums of the bucket matrix, then bit-plane sums of those ------------------------------
+// sum_b (b + 1) B_b over the job's single bucket set (b = 0-based bucket index across the virtual windows).  Rounds 1-4 ran the
+// classical form -- a thread per segment of `seg` buckets: 2 seg running-sum additions plus (segment offset) x (segment total)
+// by a ~19-bit double-and-add, then a tree over the segment results -- a chain of 2 seg + ~25 + ~14 dependent group
+// operations of ~15 us each at one wave per SIMD (profiles/r04o_last_prove_kernels_2p20.txt: 6.83 ms per proof at 2^20), a
+// third of it the offset multiplication that every thread repeats.  Here no point is ever multiplied on the device:
+//   * the owned buckets of a job are a matrix S[m][c] (m < R_own rows of C = 2^lgC buckets; a partition is rpp whole rows, so
+//     a rank's rows are its partitions' rows), bucket index b = r(m) C + c with r(m) = (first + (m / rpp) stride) rpp + m % rpp;
+//   * rsum_kernel: Row_m = sum_c S[m][c] and Col_c = sum_m S[m][c].  A group of J (rows) or I (columns) adjacent lanes shares
+//     one sum: every lane adds its strided share of <= Lr or Lc buckets, then the group's lanes are summed by an xor butterfly
+//     of lg J (lg I) shuffled additions -- 2 additions per bucket in all, a chain of L + lg G per thread, any number of
+//     threads (two waves per SIMD: the loop has ONE inlined copy of the group law, 214 registers);
+//   * plane_kernel: sum_m m Row_m and sum_c c Col_c as BIT PLANES -- Y_p = sum of the Col_c whose c has bit p, M_p likewise
+//     over the bits of m, T = sum of all rows: one block per (job, plane), members enumerated directly from the bit layout, a
+//     tree through LDS -- lg(owned buckets) + 1 points per job go to the host;
+//   * the host (capi.hip: FbRun::finish) combines them with the coefficients 2^p (Y_p), C 2^p or C stride 2^p (M_p: r(m) =
+//     first rpp + stride rpp (m / rpp) + m % rpp) and C first rpp + 1 (T): one shared chain of ~20 doublings on a CPU core,
+//     ~50 us per job, jobs side by side on the host pool.
+// Depth per batch: L + lg G + 2 + 8 additions instead of 2 seg + 25 + 14, and 2 additions per bucket instead of ~2.9.
+// (First form of round 5, profiles/r05a_*: plane sums over the per-thread partials instead of over whole rows and columns --
+// 16 x 20 x 4 blocks of LDS trees per batch, 1.0 ms per launch: slower than what it replaced.)
+struct RsPlan {
+  u32 lgC, C;        // columns per row (C divides the partition size)
+  u32 lgrpp;         // lg(rows per partition)
+  u32 R_own;         // owned rows
+  u32 lgJ, J, Lr;    // lanes per row sum, buckets per lane (J Lr = C)
+  u32 lgI, I, Lc;    // lanes per column sum, buckets per lane (I Lc >= R_own)
+  u32 NTr, NT;       // threads of the row sums (R_own J rounded up to whole waves), all threads per job (+ C I, likewise)
+  u32 NS;            // sums per job: R_own rows, then C columns
+  u32 lgM;           // bits of a row index m < R_own
+  u32 nplanes;       // lgC column planes, lgM row planes, the total
+};
+constexpr int PLANE_THREADS = 256;
+__device__ __forceinline__ u32 insert_one(u32 x, u32 p) { return ((x >> p) << (p + 1)) | (1u << p) | (x & ((1u << p) - 1)); }
+__device__ __forceinline__ Fq30 f30_shfl_xor(const Fq30& a, u32 mask) {
+  Fq30 r;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) r.v[i] = (u32)__shfl_xor((int)a.v[i], (int)mask);
+  return r;
 }
 
-// (Round 4 also built the segment loop around ONE inlined copy of the group law -- a step is "dst += src" with (dst, src) =
-// (running, bucket) on even and (acc, running) on odd steps, operands selected into one pair of register sets -- to spare the
-// called law its operands' round trip through scratch: 255 VGPRs + 75 AGPRs, and SLOWER, 12.75 vs 11.55 ms of sort + reduce
-// stages per proof at 2^20 (profiles/r04g_ab_reduce_single_inlined_site.txt).  Together with the called field operations
-// (slower too) that brackets the form in the tree: group law called, field operations inlined.)
-
-// ---- reduce2: tree sums of the segment results, still on 30-bit limbs ------------------------------------------------
-// grid (chunks, jobs): block (k, w) sums elements [k * per, (k + 1) * per) of job w's nseg points.  last = 0: writes a
-// 30-bit point to out30[w * chunks + k] (first of two launches when nseg is large); last = 1: converts the sum to the
-// standard representation for the host (out_std[w * chunks + k]).
-template <bool ILP>
-__global__ __launch_bounds__(256) void reduce2_30_kernel(const G1Xyzz30* __restrict__ in, G1Xyzz30* __restrict__ out30,
-                                                         G1Xyzz* __restrict__ out_std, u32 nseg, int last) {
-  extern __shared__ __attribute__((aligned(16))) u32 lds30[];
-  G1Xyzz30* sh = reinterpret_cast<G1Xyzz30*>(lds30);
-  const u32 w = blockIdx.y, chunks = gridDim.x;
-  const u32 per = (nseg + chunks - 1) / chunks;
-  const u32 lo = blockIdx.x * per;
-  u32 hi = lo + per; if (hi > nseg) hi = nseg;
+// thread q of job w: q < NTr: lane g = q % J of row m = q / J adds columns g, g + J, ...; else lane g = (q - NTr) % I of column
+// c = (q - NTr) / I adds rows g, g + I, ...  NTr and NT are whole waves, so a wave is all rows or all columns: its trip count
+// and its shuffles are uniform (threads past the last row / column carry the identity through them).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rsum_kernel(
+    const G1Xyzz30* __restrict__ buckets, G1Xyzz30* __restrict__ sums, u32 nbt, u32 njobs, RsPlan p, Own own,
+    const u32* __restrict__ largest, u32 skew_limit) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= njobs * p.NT) return;            // whole waves only (NT is a multiple of 64)
+  if (*largest > skew_limit) return;        // a skewed batch left this path in the accumulate kernel: the buckets hold nothing
+  const u32 w = t / p.NT, q = t % p.NT;
+  const G1Xyzz30* B = buckets + (u64)w * nbt;
+  const bool row = q < p.NTr;
+  u32 grp, g, lgG, L, m, c, dm, dc;
+  bool valid;
+  if (row) { grp = q >> p.lgJ; g = q & (p.J - 1); lgG = p.lgJ; L = p.Lr; m = grp; c = g; dm = 0; dc = p.J; valid = grp < p.R_own; }
+  else { const u32 q2 = q - p.NTr; grp = q2 >> p.lgI; g = q2 & (p.I - 1); lgG = p.lgI; L = p.Lc; m = g; c = grp; dm = p.I; dc = 0; valid = grp < p.C; }
   X30 acc = x30_identity();
-  for (u32 s = lo + threadIdx.x; s < hi; s += 256) {
-    X30 t = x30_load(in + (u64)w * nseg + s);
-    if (ILP) x30_add_ilp(acc, t); else x30_add(acc, t);
+  for (u32 step = 0; step < L + lgG; step++) {
+    X30 b;
+    if (step < L) {
+      if (valid && m < p.R_own && c < p.C) {
+        const u32 v = own.first + (m >> p.lgrpp) * own.stride;
+        const u32 r = (v << p.lgrpp) | (m & ((1u << p.lgrpp) - 1));
+        b = x30_load(B + (((u64)r << p.lgC) | c));
+      } else b = x30_identity();
+      m += dm; c += dc;
+    } else {
+      const u32 mask = 1u << (step - L);
+      b.x = f30_shfl_xor(acc.x, mask); b.y = f30_shfl_xor(acc.y, mask); b.zz = f30_shfl_xor(acc.zz, mask); b.zzz = f30_shfl_xor(acc.zzz, mask);
+    }
+    x30_add_ilp_inl(acc, b);
   }
-  x30_store(sh + threadIdx.x, acc);
+  if (valid && g == 0) x30_store(sums + (u64)w * p.NS + (row ? grp : p.R_own + grp), acc);
+}
+
+// tree sum of the block's first `nthreads` accumulators (a power of two) through LDS; the result is thread 0's `acc`
+__device__ __forceinline__ void block_tree_sum(X30& acc, G1Xyzz30* sh, u32 nthreads) {
+  if (threadIdx.x < nthreads) x30_store(sh + threadIdx.x, acc);
   __syncthreads();
-  for (u32 off = 128; off > 0; off >>= 1) {
+  for (u32 off = nthreads >> 1; off > 0; off >>= 1) {
     if (threadIdx.x < off) {
       X30 a = x30_load(sh + threadIdx.x);
-      X30 b = x30_load(sh + threadIdx.x + off);
-      if (ILP) x30_add_ilp(a, b); else x30_add(a, b);
-      x30_store(sh + threadIdx.x, a);
+      const X30 b = x30_load(sh + threadIdx.x + off);
+      x30_add_ilp(a, b);
+      if (off > 1) x30_store(sh + threadIdx.x, a); else acc = a;
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    X30 r = x30_load(sh);
-    if (last) g1_store_xyzz(out_std + (u64)w * chunks + blockIdx.x, x30_to_std(r));
-    else x30_store(out30 + (u64)w * chunks + blockIdx.x, r);
+}
+
+// grid (nplanes, njobs): block (plane, w) sums the members of one plane of job w -> out_std[w nplanes + plane], standard representation
+__global__ __launch_bounds__(PLANE_THREADS) void plane_kernel(const G1Xyzz30* __restrict__ sums, G1Xyzz* __restrict__ out_std, RsPlan p,
+                                                              const u32* __restrict__ largest, u32 skew_limit) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds_plane[];
+  G1Xyzz30* sh = reinterpret_cast<G1Xyzz30*>(lds_plane);
+  if (*largest > skew_limit) return;
+  const u32 plane = blockIdx.x, w = blockIdx.y;
+  const G1Xyzz30* S = sums + (u64)w * p.NS;
+  u32 count;                                               // members enumerated below (some row indices fall past R_own)
+  if (plane < p.lgC) count = p.C >> 1;
+  else if (plane < p.lgC + p.lgM) count = 1u << (p.lgM - 1);
+  else count = p.R_own;
+  X30 acc = x30_identity();
+  for (u32 k = threadIdx.x; k < count; k += PLANE_THREADS) {
+    u32 q;
+    if (plane < p.lgC) q = p.R_own + insert_one(k, plane);                 // columns c with bit `plane`
+    else if (plane < p.lgC + p.lgM) { q = insert_one(k, plane - p.lgC); if (q >= p.R_own) continue; }   // rows m with bit (plane - lgC)
+    else q = k;                                                            // every row: the rows cover every bucket once
+    const X30 t = x30_load(S + q);
+    x30_add_ilp(acc, t);
   }
+  u32 width = 1;
+  while (width < count && width < PLANE_THREADS) width <<= 1;
+  if (width > 1) block_tree_sum(acc, sh, width);
+  if (threadIdx.x == 0) g1_store_xyzz(out_std + (u64)w * p.nplanes + plane, x30_to_std(acc));
 }
 
 // ---- self-test of the 30-bit arithmetic against ff.cuh (mh_selftest_fq30) ----------------------------------------
@@ -826,4 +866,3 @@ __global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ 
 
 }  // namespace msmfb
 
-#include "msm_fb_quad.cuh"

@@ -138,7 +138,7 @@ __device__ __forceinline__ void butterfly(Fr30& a, Fr30& b, const u32* w) {
   a = add30(a, t);
 }
 
-// ---- the same butterfly with the twiddle product as a Shoup multiplication (MH_NTT=shoup; opt-in) -----------------------
+// ---- the same butterfly with the twiddle product as a Shoup multiplication (the default of the one-stage rounds) -----------------------
 // The twiddle is a constant: with w' = floor(w R' / r) stored beside the PLAIN w (18 words per entry, tw30s), w b mod r is
 // t = w b - q r, q ~ floor(b w' / R') -- 135 limb products (the high half of b w', the low halves of b w and q (R' - r)) instead
 // of the Montgomery product's 162, no m_k chain, 18 column carries instead of 27 (gen_fq30.py: shoup).  No Montgomery factor

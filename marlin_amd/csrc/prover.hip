@@ -22,6 +22,7 @@
 #include "fs_host.h"
 #include "g1.cuh"
 #include "host_ff.h"
+#include "host_pool.h"
 #include "poly.cuh"
 #include "ntt_dist.cuh"
 #include "rng.cuh"
@@ -368,55 +369,6 @@ int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<H
 
 // affine normalisation of an MSM result
 HG1 jac_from(const uint64_t* xyz) { HG1 p; memcpy(p.X.v, xyz, FQ_B); memcpy(p.Y.v, xyz + FQ_L, FQ_B); memcpy(p.Z.v, xyz + 2 * FQ_L, FQ_B); return p; }
-
-// A few persistent host threads for the small host-side group operations that run beside a device batch (the hiding parts of
-// the commitments).  std::async starts a thread per call: ~30 us each, four to eight of them in a row right before the round's
-// MSM is launched -- 0.13 ms of idle GPU per commit round in the kernel trace (profiles/r03x_dispatch_gaps_*).
-class HostPool {
- public:
-  template <class F>
-  auto submit(F f) -> std::future<decltype(f())> {
-    auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::move(f));
-    auto fut = task->get_future();
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      if (workers_.empty()) for (int i = 0; i < 8; i++) workers_.emplace_back([this] { run(); });
-      q_.emplace_back([task] { (*task)(); });
-    }
-    cv_.notify_one();
-    return fut;
-  }
-  ~HostPool() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-    cv_.notify_all();
-    for (auto& t : workers_) t.join();
-  }
- private:
-  void run() {
-    for (;;) {
-      std::function<void()> job;
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
-        if (q_.empty()) return;
-        job = std::move(q_.front()); q_.pop_front();
-      }
-      job();
-    }
-  }
-  std::mutex mu_; std::condition_variable cv_; std::deque<std::function<void()>> q_; std::vector<std::thread> workers_; bool stop_ = false;
-};
-HostPool& host_pool() { static HostPool p; return p; }
-// The pool's tasks read locals of the submitting frame through pointers (blinding vectors, witness quotients), and a
-// packaged_task's future does not block in its destructor the way std::async's did: every frame that submits registers its
-// futures here, so that ANY way out of it -- an MH_TRY in between included -- first waits for the tasks still running.
-struct WaitAll {
-  std::vector<std::future<hostff::HG1>*> fs;
-  WaitAll() = default;
-  WaitAll(std::initializer_list<std::future<hostff::HG1>*> l) : fs(l) {}
-  void add(std::vector<std::future<hostff::HG1>>& v) { for (auto& f : v) fs.push_back(&f); }
-  ~WaitAll() { for (auto* f : fs) if (f->valid()) f->wait(); }
-};
 
 // sum_i scalars[i] * bases[i] for the 3-coefficient hiding polynomials (host): Straus' interleaving -- one shared
 // doubling chain, a table of the 2^k - 1 subset sums of the k <= 3 bases
@@ -1501,11 +1453,10 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   // second stream behind the bucket accumulation, they run beside the bucket reduction -- one wave per SIMD, a third of the
   // issue slots idle -- and through the host round trip that brings the commitments back.  Same values, same buffers (S[0],
   // S[1], S[7] -> S[2]; nothing else touches them before round 2).  Not with sliced rounds (the transforms are distributed
-  // there).  MH_SIDE_NTT=0: in their place in round 2.
+  // there).
   const uint32_t lg4H = lgH + 2; const uint64_t H4 = 4 * H;
   const uint64_t z_len = w_len + X;
-  static const bool side_ntt_env = [] { const char* e = getenv("MH_SIDE_NTT"); return !(e && atoi(e) == 0); }();
-  const bool side_ntt = side_ntt_env && !sliced;
+  const bool side_ntt = !sliced;
   auto early_transforms = [&]() -> int {
     MH_TRY(ntt_device_len(c, pk.za.fr(), za_len, S[0], lg4H, 0));
     MH_TRY(ntt_device_len(c, pk.zb.fr(), za_len, S[1], lg4H, 0));

@@ -310,15 +310,3 @@ def test_fq30_device_selftest(gpu):
         assert bad.value == 0
 
 
-@pytest.mark.skipif(os.environ.get("MH_FB_QUAD") is not None, reason="already inside the re-run")
-def test_fixed_base_tests_with_the_quad_bucket_reduction_in_both_stages():
-    """The fixed-base tests above -- repeated bases (equal-x additions inside the bucket reduction: the complete-addition
-    path of msm_fb_quad.cuh), every window width, offsets, shared scalars -- once more with MH_FB_QUAD=2, which puts BOTH stages
-    of the bucket reduction on the one-point-per-quad kernels (the default uses them for the tree stage of sharded launches
-    only).  The switch is read once per process, hence the subprocess."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "tests/test_gpu_msm.py",
-                        "-k", "fixed_base or repeated_base or selftest"], cwd=root, env=dict(os.environ, MH_FB_QUAD="2"),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
