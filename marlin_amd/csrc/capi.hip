@@ -504,8 +504,15 @@ struct FbRun {
       rs.R_own = nbown >> rs.lgC;
       rs.lgM = 0;
       while ((1u << rs.lgM) < rs.R_own) rs.lgM++;
-      const u64 target = 128ull * (u64)c.num_simds;                                  // threads of the launch: two waves per SIMD
-      const u64 Lt = std::max<u64>(1, (2ull * nj * nbown + target - 1) / target);   // buckets per thread that would give them
+      // Buckets per lane: two waves per SIMD on the full launches of a 2^20 proof (sort + reduce 9.34 vs 9.64 ms per proof at one
+      // wave), one wave where two would leave a lane fewer than 16 buckets (2^16 + SonicKZG10: 2.63 vs 2.88 ms) -- either way the
+      // kernel is bound by VALU issue: one wave with its three interleaved multiplication chains already fills the SIMD
+      // (profiles/r05c_sweep_rsum_threads.txt).
+      const u64 per_simd = 2ull * nj * nbown;
+      const u64 simds = (u64)c.num_simds;
+      u64 Lt = (per_simd + 128 * simds - 1) / (128 * simds);
+      if (Lt < 16) Lt = std::min<u64>(16, (per_simd + 64 * simds - 1) / (64 * simds));
+      if (Lt < 1) Lt = 1;
       auto lanes = [&](u64 len) { u32 lg = 0; while (lg < 6 && (2ull << lg) * Lt <= len) lg++; return lg; };
       rs.lgJ = lanes(rs.C); rs.J = 1u << rs.lgJ; rs.Lr = rs.C >> rs.lgJ;
       rs.lgI = lanes(1ull << rs.lgM); rs.I = 1u << rs.lgI; rs.Lc = (rs.R_own + rs.I - 1) / rs.I;

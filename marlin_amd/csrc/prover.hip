@@ -631,8 +631,15 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
   if (world > 1 && !allgather) return fail(MH_EINVAL, "mh_marlin_set_shard: all_gather callback required for world > 1");
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);     // g_shard is read by a running mh_marlin_prove under this lock
+  // a callback transport replaces the native one (mh_marlin_set_rccl) as a whole: its all-to-all and device all-gather go with
+  // it and its communicator is destroyed -- the sliced rounds must never mix a callback all-gather with native all-to-alls
+  if (g_shard.native) {
+    if (c.inited && c.stream) (void)hipStreamSynchronize(c.stream);
+    g_shard.a2a = nullptr; g_shard.a2a_user = nullptr; g_shard.a2a_ordered = false;
+    (void)rcclnative::destroy();
+  }
   g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
-  g_shard.ag_dev = nullptr; g_shard.native = false;   // a callback transport replaces the native one (mh_marlin_set_rccl)
+  g_shard.ag_dev = nullptr; g_shard.ag_dev_user = nullptr; g_shard.native = false;
   return MH_OK;                                 // the window table does not depend on the number of ranks (bucket-range sharding)
 }
 

@@ -66,7 +66,10 @@ inline int load_api() {
     h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
     for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
   }
-  if (!h) return fail(MH_EINVAL, std::string("native RCCL transport: ") + (forced && *forced ? forced : "librccl.so.1") + " not found (" + (dlerror() ? dlerror() : "?") + ")");
+  if (!h) {
+    const char* why = dlerror();               // read ONCE: the call clears the message, a second one returns NULL
+    return fail(MH_EINVAL, std::string("native RCCL transport: ") + (forced && *forced ? forced : "librccl.so.1") + " not found (" + (why ? why : "?") + ")");
+  }
 #define RCCL_SYM(field, name, required)                                                                         \
   a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                                                \
   if (required && !a.field) { dlclose(h); return fail(MH_EINVAL, std::string("native RCCL transport: symbol missing: ") + name); }

@@ -194,12 +194,27 @@ _FS_U64_T = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
 
 def _fs_struct(fs):
     """The caller's `FS: FiatShamirRng` (an object with initialize(bytes), absorb(bytes), next_u64() -> int) as mh_fiat_shamir.
-    Returns (struct, keepalive)."""
-    init = _FS_BYTES_T(lambda _u, p, n: fs.initialize(bytes(p[:n])))
-    absorb = _FS_BYTES_T(lambda _u, p, n: fs.absorb(bytes(p[:n])))
-    nxt = _FS_U64_T(lambda _u: int(fs.next_u64()) & 0xffffffffffffffff)
+    Returns (struct, keepalive, errors).  The C callbacks have no error channel (ctypes prints an exception raised inside one and
+    returns 0 in its place): the FIRST exception of the caller's object is recorded in `errors` and every later callback becomes a
+    no-op, so that prove_fs / verify_fs can re-raise it once the library call is back instead of handing out a proof (or a
+    verdict) computed over a corrupted transcript."""
+    errors = []
+
+    def guard(f, default=None):
+        def g(*a):
+            if errors:
+                return default
+            try:
+                return f(*a)
+            except BaseException as e:          # noqa: BLE001 -- re-raised by the caller of the library
+                errors.append(e)
+                return default
+        return g
+    init = _FS_BYTES_T(guard(lambda _u, p, n: fs.initialize(bytes(p[:n]))))
+    absorb = _FS_BYTES_T(guard(lambda _u, p, n: fs.absorb(bytes(p[:n]))))
+    nxt = _FS_U64_T(guard(lambda _u: int(fs.next_u64()) & 0xffffffffffffffff, 0))
     st = _FiatShamirC(None, C.cast(init, C.c_void_p), C.cast(absorb, C.c_void_p), C.cast(nxt, C.c_void_p))
-    return st, (init, absorb, nxt)
+    return st, (init, absorb, nxt), errors
 
 
 def prove_fs(pk, instance_mont, witness_mont, zk_seed, fs, zk_rounds=20):
@@ -208,12 +223,15 @@ def prove_fs(pk, instance_mont, witness_mont, zk_seed, fs, zk_rounds=20):
     x = np.ascontiguousarray(instance_mont, dtype=np.uint64)
     w = np.ascontiguousarray(witness_mont, dtype=np.uint64)
     assert x.shape == (pk.num_instance, 4) and w.shape == (pk.num_constraints - pk.num_instance, 4), (x.shape, w.shape)
-    st, keep = _fs_struct(fs)
+    st, keep, errors = _fs_struct(fs)
     out = (C.c_uint8 * 4096)()
     n = C.c_size_t()
-    _lib.check(_lib.load().mh_marlin_prove_fs(pk.handle, x.ctypes.data, w.ctypes.data, bytes(zk_seed), int(zk_rounds), C.byref(st), out, 4096,
-                                              C.byref(n)), "mh_marlin_prove_fs")
+    rc = _lib.load().mh_marlin_prove_fs(pk.handle, x.ctypes.data, w.ctypes.data, bytes(zk_seed), int(zk_rounds), C.byref(st), out, 4096,
+                                        C.byref(n))
     del keep
+    if errors:
+        raise errors[0]
+    _lib.check(rc, "mh_marlin_prove_fs")
     return bytes(out[:n.value])
 
 
@@ -272,11 +290,14 @@ def verify_fs(vk_bytes, g_xy, gamma_g_xy, h_xy, beta_h_xy, shift_power_h_xy, shi
     arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (g_xy, gamma_g_xy, h_xy, beta_h_xy, shift_power_h_xy, shift_power_k_xy)]
     vk = _VerifierKeyC(*[a.ctypes.data for a in arrs])
     pub = np.ascontiguousarray(public_input_mont, dtype=np.uint64).reshape(-1, 4)
-    st, keep = _fs_struct(fs)
+    st, keep, errors = _fs_struct(fs)
     ok = C.c_int(0)
-    _lib.check(_lib.load().mh_marlin_verify_fs(bytes(vk_bytes), len(vk_bytes), C.byref(vk), {"marlin": 0, "sonic": 1}[pc], pub.ctypes.data,
-                                               pub.shape[0], bytes(flat_proof), len(flat_proof), C.byref(st), C.byref(ok)), "mh_marlin_verify_fs")
+    rc = _lib.load().mh_marlin_verify_fs(bytes(vk_bytes), len(vk_bytes), C.byref(vk), {"marlin": 0, "sonic": 1}[pc], pub.ctypes.data,
+                                         pub.shape[0], bytes(flat_proof), len(flat_proof), C.byref(st), C.byref(ok))
     del keep
+    if errors:
+        raise errors[0]
+    _lib.check(rc, "mh_marlin_verify_fs")
     return bool(ok.value)
 
 

@@ -181,18 +181,39 @@ impl GpuMarlin {
     ) -> Result<Proof<Fr, MultiPC>, HipError> {
         use core::ffi::c_void;
         use ark_std::rand::RngCore;
+        // The callbacks are `extern "C"`: a panic must not unwind through the library's C++ frames (undefined behaviour, an abort
+        // at best).  Every callback runs under `catch_unwind`; the first failure -- a panic in the caller's `FS2`, or a callback
+        // before `initialize` -- is recorded in the state, later callbacks become no-ops (`next_u64` returns 0), and
+        // `prove_with_fs` returns `Err` once `mh_marlin_prove_fs` is back instead of a proof over a corrupted transcript.
+        struct FsState<F> { fs: Option<F>, failed: bool }
         unsafe extern "C" fn init<F: ark_marlin::rng::FiatShamirRng>(user: *mut c_void, input: *const u8, len: usize) {
-            let slot = &mut *(user as *mut Option<F>);
+            let st = &mut *(user as *mut FsState<F>);
+            if st.failed { return; }
             // Vec<u8> is what upstream's own call sites pass (`to_bytes![..]`, src/lib.rs:161)
-            *slot = Some(F::initialize(&core::slice::from_raw_parts(input, len).to_vec()));
+            let bytes = core::slice::from_raw_parts(input, len).to_vec();
+            match std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| F::initialize(&bytes))) {
+                Ok(fs) => st.fs = Some(fs),
+                Err(_) => st.failed = true,
+            }
         }
         unsafe extern "C" fn absorb<F: ark_marlin::rng::FiatShamirRng>(user: *mut c_void, input: *const u8, len: usize) {
-            let slot = &mut *(user as *mut Option<F>);
-            slot.as_mut().expect("initialize first").absorb(&core::slice::from_raw_parts(input, len).to_vec());
+            let st = &mut *(user as *mut FsState<F>);
+            if st.failed { return; }
+            let bytes = core::slice::from_raw_parts(input, len).to_vec();
+            let ok = match st.fs.as_mut() {
+                Some(fs) => std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| fs.absorb(&bytes))).is_ok(),
+                None => false,
+            };
+            if !ok { st.failed = true; }
         }
         unsafe extern "C" fn next<F: ark_marlin::rng::FiatShamirRng>(user: *mut c_void) -> u64 {
-            let slot = &mut *(user as *mut Option<F>);
-            slot.as_mut().expect("initialize first").next_u64()
+            let st = &mut *(user as *mut FsState<F>);
+            if st.failed { return 0; }
+            let r = match st.fs.as_mut() {
+                Some(fs) => std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| fs.next_u64())).ok(),
+                None => None,
+            };
+            match r { Some(v) => v, None => { st.failed = true; 0 } }
         }
         let pcs = ConstraintSystem::<Fr>::new_ref();
         pcs.set_optimization_goal(OptimizationGoal::Weight);
@@ -202,18 +223,22 @@ impl GpuMarlin {
         let pcs = pcs.into_inner().unwrap();
         let instance = fr_slice_to_limbs(&pcs.instance_assignment);
         let witness = fr_slice_to_limbs(&pcs.witness_assignment);
-        let mut state: Option<FS2> = None;
+        let mut state: FsState<FS2> = FsState { fs: None, failed: false };
         let cb = ffi::mh_fiat_shamir {
-            user: &mut state as *mut Option<FS2> as *mut c_void,
+            user: &mut state as *mut FsState<FS2> as *mut c_void,
             initialize: Some(init::<FS2>),
             absorb: Some(absorb::<FS2>),
             next_u64: Some(next::<FS2>),
         };
         let mut flat = vec![0u8; 4096];
         let mut flat_len = 0usize;
-        check(unsafe {
+        let rc = unsafe {
             ffi::mh_marlin_prove_fs(pk.pk, instance.as_ptr(), witness.as_ptr(), zk_seed.as_ptr(), 20, &cb, flat.as_mut_ptr(), flat.len(), &mut flat_len)
-        })?;
+        };
+        if state.failed {
+            return Err(HipError::Unsupported("the caller's FiatShamirRng panicked (or was used before initialize) inside a transcript callback"));
+        }
+        check(rc)?;
         let mut wire = vec![0u8; 4096];
         let mut wire_len = 0usize;
         check(unsafe { ffi::mh_marlin_proof_serialize(flat.as_ptr(), flat_len, 0, wire.as_mut_ptr(), wire.len(), &mut wire_len) })?;

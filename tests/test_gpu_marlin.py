@@ -195,6 +195,22 @@ def test_prove_and_verify_with_the_callers_fiat_shamir(gpu, pc):
     assert not GM.verify(pk.vk_bytes(), *els, fr_to_np([c]), other, pc=pc)              # another transcript, other challenges
     assert GM.verify_fs(pk.vk_bytes(), *els, fr_to_np([c]), want, Ref(), pc=pc)          # and the built-in proof under the callbacks
 
+    # an exception inside the caller's FS must come out of prove_fs / verify_fs -- not be printed by ctypes and
+    # swallowed, with the library carrying on over a transcript of zeros
+    class Boom(Sha):
+        def __init__(self, fail_at):
+            self.n, self.fail_at = 0, fail_at
+        def absorb(self, data):
+            self.n += 1
+            if self.n == self.fail_at:
+                raise KeyError("transcript broke at absorb %d" % self.n)
+            Sha.absorb(self, data)
+    with pytest.raises(KeyError, match="absorb 2"):
+        GM.prove_fs(pk, inst, wit, SEED, Boom(2))
+    with pytest.raises(KeyError, match="absorb 1"):
+        GM.verify_fs(pk.vk_bytes(), *els, fr_to_np([c]), other, Boom(1), pc=pc)
+    assert GM.prove_fs(pk, inst, wit, SEED, Sha()) == other                               # the library is usable afterwards
+
 
 TOGGLE_WORKER = r'''
 import sys

@@ -156,3 +156,27 @@ def test_workload_inventories_are_consistent():
         assert len(big) == 15 and len(W.msm_executed(H)) == 13 and len(W.msm_executed(H, pc="sonic")) == 11
         assert sum(n for n, _ in W.msm_executed(H)) < sum(n for n, _ in big)
         assert W.executed_ntt_bytes(H) < W.algorithmic_bytes(H)[0]
+
+
+def test_native_transport_reports_a_missing_librccl_instead_of_crashing():
+    """with no librccl to be found (MH_RCCL_LIB names a file that does not exist) mh_rccl_unique_id must return
+    an error with the loader's message -- rccl_native.h used to call dlerror() twice and built a std::string from the NULL the
+    second call returns (SIGSEGV on exactly the path meant to degrade gracefully) -- and marlin_amd.dist.enable_native_rccl must
+    return False, which is what lets bench.py --transport auto fall back to the callback transport.  No GPU needed: the library
+    is looked up before anything touches the device."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from marlin_amd import _lib, dist as MD\n"
+        "lib = _lib.load()\n"
+        "ident = np.zeros(128, dtype=np.uint8)\n"
+        "rc = lib.mh_rccl_unique_id(ident.ctypes.data)\n"
+        "msg = (lib.mh_last_error() or b'').decode()\n"
+        "assert rc != 0 and 'not found' in msg and '/nonexistent/librccl.so' in msg, (rc, msg)\n"
+        "assert MD.enable_native_rccl() is False\n"
+        "print('clean', rc)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MH_RCCL_LIB="/nonexistent/librccl.so"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "clean" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])

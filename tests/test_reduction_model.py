@@ -31,8 +31,11 @@ def plan(c, first, stride, nj, num_simds):
     lgM = 0
     while (1 << lgM) < R:
         lgM += 1
-    target = 128 * num_simds
-    Lt = max(1, (2 * nj * nbown + target - 1) // target)
+    per_simd = 2 * nj * nbown
+    Lt = (per_simd + 128 * num_simds - 1) // (128 * num_simds)
+    if Lt < 16:
+        Lt = min(16, (per_simd + 64 * num_simds - 1) // (64 * num_simds))
+    Lt = max(1, Lt)
 
     def lanes(length):
         lg = 0
