@@ -371,6 +371,10 @@ def main():
     ap.add_argument("--simulate-rank", default=None, metavar="R/G",
                     help="MEASUREMENT AID, one GPU: run what rank R of G would run (its bucket range of every MSM + the replicated "
                          "AHP rounds) with the exchange replaced by a local copy; the proof is not valid and the JSON line says so")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="multi-GPU: accept that several ranks share a physical device (tests / tools/rehearse_ranks.sh on a one-GPU box); "
+                         "without it a line whose ranks_seen hold fewer distinct devices than ranks carries value = null -- N ranks on "
+                         "one GPU are not an N-GPU measurement")
     ap.add_argument("--pc", choices=["marlin", "sonic"], default="marlin",
                     help="polynomial commitment scheme (MarlinKZG10 = headline config; SonicKZG10 = configs[4]); "
                          "the curve is chosen with MARLIN_AMD_CURVE=bls12_381|bn254")
@@ -593,6 +597,22 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the same proof through the HOST-pointer entry point (mh_marlin_prove: instance + witness cross PCIe inside the call, 32 B per
+    # constraint) -- what a caller whose witness lives in a Vec<Fr> pays; reported beside the headline, never as `value`
+    # (benches/bench.rs:94-107 times prove with the circuit in host memory; its witness synthesis is outside BOTH numbers here)
+    host_inputs_ms = None
+    if workload == "marlin-prove" and world == 1 and not args.simulate_rank and not wl.host_inputs:
+        M.prof_enable(False)
+        hsteps = max(1, min(3, args.steps))
+        wl.host_inputs = True
+        wl.step(dist, torch)
+        barrier()
+        th0 = time.perf_counter()
+        for _ in range(hsteps):
+            wl.step(dist, torch)
+        barrier()
+        host_inputs_ms = (time.perf_counter() - th0) * 1e3 / hsteps
+        wl.host_inputs = False
 
     # which physical devices took part: every rank reports (rank, local device, PCI bus id / uuid), all-gathered -- lets a
     # scaling record prove that N distinct GPUs ran
@@ -663,7 +683,8 @@ def main():
     ntt_side_ms, _ = M.prof_get(6)      # the transforms that ran beside round 1's bucket reduction (their own family: concurrent with msm)
     msm_ms, _ = M.prof_get(1)
     glue_ms, _ = M.prof_get(3)
-    stages_ms, _ = M.prof_get(4)      # sort + bucket reduction by themselves; they run beside the other half's accumulation
+    stages_ms, _ = M.prof_get(4)      # sort + bucket reduction by themselves
+    reduce_ms, reduce_launches = M.prof_get(7)   # the bucket reduction by itself (rsum + plane kernels), part of family 4
     # pairs the timed launches really process: the prover folds each opening's shifted witness into the witness MSM
     from marlin_amd import workload as W
     msms_run = W.msm_executed(wl.N, pc=args.pc) if workload == "marlin-prove" else wl.msms
@@ -737,6 +758,25 @@ def main():
                             int(pair_bytes), sum(mix.values()), W_windows,
                             (ntt_bytes * breakdown_steps) / ((ntt_ms + ntt_side_ms) * 1e-3) / 1e9 if ntt_ms > 0 else 0.0, ntt_what)}
 
+    # ---- the bucket reduction (msm_fb.cuh: rsum_kernel + plane_kernel): general additions against the VALU-issue bound of their
+    # instruction mix.  Algorithmic work: 2 general additions per owned bucket (one into its row sum, one into its column sum);
+    # the butterflies, the bit planes and the host's ~40 operations per job come on top and are what `frac` loses.
+    roofline_reduce = None
+    red_mix = (mixes or {}).get("reduce")
+    if tab_w and reduce_ms > 0 and red_mix:
+        buckets_step = len(msms_run) * (1 << (tab_c - 1)) / world_eff
+        gadds_per_s = 2.0 * buckets_step * breakdown_steps / (reduce_ms * 1e-3)
+        red_bound = valu_bound_adds_per_s(red_mix)
+        roofline_reduce = {"bound": "valu-issue", "kernel": "msmfb::rsum_kernel + msmfb::plane_kernel", "achieved": round(gadds_per_s / 1e9, 3),
+                           "peak": round(red_bound / 1e9, 3), "unit": "G general additions/s (XYZZ += XYZZ)", "frac": round(gadds_per_s / red_bound, 4),
+                           "ms_per_step": round(reduce_ms / breakdown_steps, 3), "launch_pairs_per_step": reduce_launches / breakdown_steps,
+                           "buckets_per_step": buckets_step, "additions_per_bucket": 2,
+                           "waves_per_simd": "2 (214 registers; 1 where a lane would get fewer than 16 buckets)",
+                           "valu_instr_per_add": sum(red_mix.values()), "instr_mix_per_add": red_mix,
+                           "instr_mix_source": "profiles/accum_isa_mix.json [%s][reduce]" % _Lc.CURVE,
+                           "note": "round 4's segment reduction (running sums + a ~19-bit double-and-add per thread + tree) took 6.83 ms per proof "
+                                   "at 2^20 = 0.35 of this bound; row / column sums + bit planes need no device-side point multiplication"}
+
     # ---- every rank's own view (a SCALE record has to explain itself): its wall time per step, its kernel families, and what
     # the exchanges cost it -- events on the library's stream around each collective (family 5) and the host's wall clock inside them
     exch_ms, exch_n = M.prof_get(5)
@@ -795,6 +835,11 @@ def main():
                                                   % (breakdown_steps, breakdown_ms_per_step))},
         "roofline": roofline,
         "roofline_valu": valu,
+        "roofline_reduce": roofline_reduce,
+        "host_inputs_ms_per_step": round(host_inputs_ms, 3) if host_inputs_ms is not None else None,
+        "host_inputs_note": ("mh_marlin_prove with HOST pointers: the formatted input and the witness (32 B per constraint) cross PCIe inside the "
+                             "call; ms_per_step / value above are mh_marlin_prove_dev, inputs already in HBM (the contract's timed region)"
+                             if host_inputs_ms is not None else None),
         "accum_launches_per_step": acc_launches / max(1, args.steps),
         "proof": proof_info,
         "per_rank": per_rank if (world > 1 or args.simulate_rank) else None,
@@ -810,6 +855,12 @@ def main():
     if _L.CURVE != "bls12_381" or args.pc != "marlin":
         out["dtype"] = "u32-limb Montgomery integers (Fr 256-bit, Fq %d-bit)" % (64 * _L.FQ_LIMBS)
         args.no_cpu_baseline = True          # the C restatement covers the headline configuration only
+    if world > 1 and out["distinct_devices"] < world:
+        out["rehearsal"] = bool(args.rehearsal)
+        if not args.rehearsal:
+            out["value"] = None
+            out["note"] = ("%d ranks ran on %d distinct device(s): not an N-GPU measurement, so no scaling value is printed "
+                           "(--rehearsal accepts shared devices for tests)" % (world, out["distinct_devices"]))
     if args.simulate_rank:
         out["simulated_rank"] = args.simulate_rank
         out["simulated_sliced_rounds"] = not args.no_sliced

@@ -348,7 +348,8 @@ int mh_marlin_get_poly(uint64_t pk, const char* label, uint64_t* out, size_t cap
  * bucket-reduction stages by themselves, 5 = the exchanges of a sharded proof (events on the library's stream around each
  * collective; with a host-synchronising callback transport the host's wait is in mh_marlin_exchange_stats instead), 6 = work the
  * prover runs on a second stream BESIDE an MSM batch's bucket reduction (the challenge-independent transforms of round 2 during
- * round 1's commitment): concurrent with family 1, so families 0 + 1 + 3 + 5 still add up to the step.
+ * round 1's commitment): concurrent with family 1, so families 0 + 1 + 3 + 5 still add up to the step; 7 = the bucket reduction of the
+ * fixed-base MSMs by itself (row / column sums and bit planes: part of family 4).
  * mh_prof_enable(on): 0 = off, 1 = every family, any other value = a mask with bit (f + 1) set for each family f to record
  * (8 = the accumulate kernel only).  An event pair per scope is not free: ~90 scopes per proof cost ~1 ms of launch gaps, so a
  * timed run records the one family it needs (bench.py) and takes the full breakdown from untimed proofs.  */
@@ -359,6 +360,13 @@ int mh_prof_get(int family, double* total_ms_out, uint64_t* launches_out);
  * Montgomery arithmetic: n pseudo-random operand pairs (field operations, XYZZ doubling / addition incl. the equal-x
  * path); *mismatches_out = number of operand pairs with any disagreement (0 expected). */
 int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out);
+/* Test hook: the nth (>= 1) request for device scratch memory from now on fails with MH_ENOMEM, as if the device had run out of
+ * memory, whether or not that request would have had to allocate (0 disarms the hook); *calls_out (may be NULL) = the number of
+ * such requests made so far.  How the tests make ONE rank of a sharded proof fail mid-prove: a rank that fails locally keeps
+ * entering the collectives of the proof (with a meaningless payload) up to the next all-gather of partial points, whose error word
+ * makes EVERY rank return non-zero from the same commit round -- the job fails, nobody hangs, the next proof can run.  Replaces
+ * nothing in the reference (it has no FFI and no device memory). */
+int mh_debug_fail_scratch(int nth, uint64_t* calls_out);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,8 @@ using hostff::FQ_L; using hostff::FQ_B; using hostff::PT_B; using hostff::AFF_L;
 
 namespace mh {
 thread_local std::string g_err;
+int g_debug_fail_scratch = 0;
+uint64_t g_debug_scratch_calls = 0;
 Context& ctx() {
   static Context c;
   return c;
@@ -703,6 +705,7 @@ struct FbRun {
   int reduce(hipStream_t s) {
     namespace F = msmfb;
     ProfScope ps(c, PF_MSM_STAGES, s);
+    ProfScope pr(c, PF_MSM_REDUCE, s);
     F::G1Xyzz30* sums = (F::G1Xyzz30*)ws.seg.ptr;
     const u32* d_max = (const u32*)ws.sums.ptr;
     const u64 threads = (u64)nj * rs.NT;
@@ -1723,6 +1726,16 @@ int mh_prof_reset(void) {
   LOCKED_CTX();
   MH_TRY(prof_drain(c));
   for (int i = 0; i < PF_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; }
+  return MH_OK;
+}
+// Test hook: the nth (>= 1) request for device scratch from now on fails with MH_ENOMEM (0 disarms); calls_out (may be NULL)
+// receives the number of such requests the library has made so far.
+int mh_debug_fail_scratch(int nth, uint64_t* calls_out) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (nth < 0) return fail(MH_EINVAL, "mh_debug_fail_scratch: nth must be >= 0");
+  g_debug_fail_scratch = nth;
+  if (calls_out) *calls_out = g_debug_scratch_calls;
   return MH_OK;
 }
 int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out) {

@@ -37,10 +37,18 @@ inline int fail(int code, const std::string& msg) {
     if (_r != MH_OK) return _r; \
   } while (0)
 
+// Test hook (mh_debug_fail_scratch): the n-th Scratch::ensure call from now on fails as if the device were out of memory, whether
+// or not it would have had to allocate -- how tests/test_gpu_rccl_native.py makes ONE rank of a sharded proof fail mid-prove.
+extern int g_debug_fail_scratch;          // > 0: calls left until the forced failure
+extern uint64_t g_debug_scratch_calls;    // Scratch::ensure calls so far (the test measures a proof with it)
+
 struct Scratch {
   void* ptr = nullptr;
   size_t cap = 0;
+  bool hookable = true;                   // false: the staging buffers of the transport itself (a rank without them cannot enter a collective at all)
   int ensure(size_t bytes) {
+    if (hookable) g_debug_scratch_calls++;
+    if (hookable && g_debug_fail_scratch > 0 && --g_debug_fail_scratch == 0) return fail(MH_ENOMEM, "hipMalloc scratch failed (forced by mh_debug_fail_scratch)");
     if (bytes <= cap) return MH_OK;
     if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8;
@@ -88,7 +96,8 @@ struct G2Set { void* d_points = nullptr; size_t n = 0; };   // G2Affine[n] (x.c0
 // round polynomials), events on the library's stream around each
 // PF_SIDE: whatever a side job (Context::side_job) runs on the second stream beside an MSM batch's bucket reduction -- kept apart from
 // its own family so that the families of the main stream still add up to the step
-enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_MSM_STAGES = 4, PF_EXCHANGE = 5, PF_SIDE = 6, PF_COUNT = 7 };
+// PF_MSM_REDUCE: the bucket reduction by itself (rsum + plane kernels; inside PF_MSM_STAGES) -- bench.py's roofline_reduce
+enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_MSM_STAGES = 4, PF_EXCHANGE = 5, PF_SIDE = 6, PF_MSM_REDUCE = 7, PF_COUNT = 8 };
 
 struct ProfRec { int family; hipEvent_t a, b; };
 
@@ -147,8 +156,8 @@ struct Context {
   int prof_override = -1;              // >= 0: every scope opened meanwhile records under this family (side jobs: PF_SIDE)
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
-  double prof_ms[PF_COUNT] = {0, 0, 0, 0, 0, 0, 0};
-  uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+  double prof_ms[PF_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 Context& ctx();

@@ -314,6 +314,40 @@ struct ExchangeScope {
   ~ExchangeScope() { g_shard.host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g_shard.calls++; }
 };
 
+// ---- a rank that fails locally fails the JOB instead of hanging it ---------------------------------------
+// Inside a sharded mh_marlin_prove a rank that returned at its first local error would leave its peers blocked in the next
+// collective.  Instead it is POISONED: the remaining local steps of the proof are skipped (PTRY), every collective up to the next
+// all-gather of partial points is still entered with a payload of the right size (the buffers it would have used, or two of the
+// key's scratch vectors when those are what could not be allocated), and that all-gather carries an error word: every rank sees
+// it, marks the job failed and returns non-zero from the same commit round -- the transport stays in step and the next proof
+// can run.  One GPU (world = 1): nothing changes, the first error returns at once.
+struct JobStatus {
+  int poison = MH_OK; std::string msg;       // this rank's first local failure
+  bool failed = false;                       // some rank's error word came back from an all-gather: every rank is returning
+  void* buf[2] = {nullptr, nullptr}; size_t buf_bytes = 0;   // stand-in exchange buffers of a poisoned rank
+} g_job;
+inline void poison(int rc) { if (g_job.poison == MH_OK) { g_job.poison = rc; g_job.msg = g_err; } }
+inline int job_error() { return g_job.poison != MH_OK ? fail(g_job.poison, g_job.msg) : MH_EHIP; }
+// local step: skipped once poisoned; its failure poisons (sharded) or returns (one GPU)
+#define PTRY(expr)                                                            \
+  do {                                                                        \
+    if (g_job.poison == MH_OK) {                                              \
+      int _r = (expr);                                                        \
+      if (_r != MH_OK) { if (g_shard.world <= 1) return _r; poison(_r); }     \
+    }                                                                         \
+  } while (0)
+// step with a collective inside: always entered; returns when the job failed on every rank, poisons on a failure of this rank only
+#define CTRY(expr)                                                            \
+  do {                                                                        \
+    int _r = (expr);                                                          \
+    if (_r != MH_OK) {                                                        \
+      if (g_shard.world <= 1) return _r;                                      \
+      if (g_job.failed) return g_job.poison != MH_OK ? fail(g_job.poison, g_job.msg) : _r; \
+      poison(_r);                                                             \
+    }                                                                         \
+  } while (0)
+#define PHIP(call) PTRY([&]() -> int { MH_HIP(call); return MH_OK; }())
+
 HG1 jac_from(const uint64_t* xyz);
 int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, uint32_t log_n, int inverse);
 struct MsmJob { const char* bases; const Fr* scalars; uint64_t n; };
@@ -336,8 +370,11 @@ int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<H
   std::vector<uint8_t> partial(nj, 0);
   // already_shares: the jobs ARE this rank's part of the sums (blocks of the scalar vectors against the matching base
   // ranges: point sharding) -- computed in full here and flagged as shares for the combination below
-  int rc = msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), is_mont, part.data(), sharded && !already_shares ? sh : nullptr,
-                            sharded ? partial.data() : nullptr);
+  // a poisoned rank (see JobStatus) skips its launches and reports through the error word
+  int rc = sharded && g_job.poison != MH_OK ? g_job.poison
+                                            : msm_batch_device(c, nj, b.data(), sc.data(), ns.data(), is_mont, part.data(),
+                                                               sharded && !already_shares ? sh : nullptr, sharded ? partial.data() : nullptr);
+  if (sharded && rc != MH_OK) poison(rc);
   if (sharded && already_shares) std::fill(partial.begin(), partial.end(), (uint8_t)1);
   if (!sharded) { MH_TRY(rc); for (int j = 0; j < nj; j++) out[j] = jac_from(part.data() + XYZ_L * j); return MH_OK; }
   if (!g_shard.cb) return fail(MH_EINVAL, "sharded prove: no all_gather callback registered");
@@ -355,9 +392,9 @@ int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<H
     ExchangeScope xs(c);
     if (g_shard.cb(send.data(), send.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather failed: " + g_err);
   }
-  MH_TRY(rc);
-  for (int g = 0; g < g_shard.world; g++)
-    if (all[(size_t)g * stride + npts] != 0) return fail(MH_EHIP, "sharded prove: the MSM of another rank failed");
+  for (int g = 0; g < g_shard.world; g++) if (all[(size_t)g * stride + npts] != 0) g_job.failed = true;
+  if (rc != MH_OK) return fail(rc, g_job.msg);
+  if (g_job.failed) return fail(MH_EHIP, "sharded prove: another rank failed (its error word came with the partial points)");
   for (int j = 0; j < nj; j++) {
     int whole = -1;
     for (int g = 0; g < g_shard.world && whole < 0; g++) if (all[(size_t)g * stride + npts + 1 + j] == 0) whole = g;
@@ -737,8 +774,17 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
   if (log_n < 2 * lg) return fail(MH_EINVAL, "mh_ntt_dist_dev: the transform must have at least world^2 points");
   const uint32_t log_m = log_n - lg;
   const uint64_t m = 1ull << log_m, chunk = m >> lg;
-  MH_TRY(c.ntt_dist_buf[0].ensure(m * 32)); MH_TRY(c.ntt_dist_buf[1].ensure(m * 32));
+  // lrc: this rank's local status.  Once it is not MH_OK the local kernels are skipped but the exchange below is still entered
+  // (JobStatus): the peers are already on their way into it.
+  int lrc = g_job.poison;
+  auto L = [&](int r) { if (lrc == MH_OK && r != MH_OK) { lrc = r; poison(r); } };
+  L(c.ntt_dist_buf[0].ensure(m * 32));
+  if (lrc == MH_OK) L(c.ntt_dist_buf[1].ensure(m * 32));
   Fr* A = (Fr*)c.ntt_dist_buf[0].ptr; Fr* B = (Fr*)c.ntt_dist_buf[1].ptr;
+  if (c.ntt_dist_buf[0].cap < m * 32 || c.ntt_dist_buf[1].cap < m * 32) {       // what failed is these very buffers
+    if (g_job.buf_bytes < m * 32) return fail(MH_ENOMEM, "mh_ntt_dist_dev: no exchange buffer (this rank cannot enter the all-to-all)");
+    A = (Fr*)g_job.buf[0]; B = (Fr*)g_job.buf[1];
+  }
   // w_n, and the tables of (w_n^(+-rank))^k2 = hi[k2 >> 11] * lo[k2 & 2047], the inverse's lo carrying G^-1
   HFr wn = hostff::fr_two_adic_root();
   for (uint32_t i = log_n; i < hostff::FR_TWO_ADICITY_H; i++) wn = wn.sqr();
@@ -746,7 +792,7 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
   const uint64_t LO = 1ull << poly::COSET_LO_BITS, nhi = (m + LO - 1) / LO;
   const uint64_t tab_key = ((uint64_t)log_n << 16) | ((uint64_t)(inverse ? 1 : 0) << 15) | ((uint64_t)G << 8) | (uint64_t)rank;
   Scratch& tabs = c.ntt_dist_tabs[tab_key];
-  if (!tabs.ptr) {                                  // built once per (size, direction, geometry): ~2300 host multiplications
+  if (!tabs.ptr && lrc == MH_OK) {                  // built once per (size, direction, geometry): ~2300 host multiplications
     const HFr base = wn.pow_u64((uint64_t)rank);
     std::vector<uint64_t> tab(4 * (LO + nhi));
     HFr a = inverse ? HFr::from_u64((uint64_t)G).inv() : HFr::one();
@@ -754,9 +800,11 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
     const HFr bl = base.pow_u64(LO);
     a = HFr::one();
     for (uint64_t j = 0; j < nhi; j++) { memcpy(&tab[4 * (LO + j)], a.v, 32); a = a * bl; }
-    MH_TRY(tabs.ensure(tab.size() * 8));
-    MH_HIP(hipMemcpyAsync(tabs.ptr, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c.stream));
-    MH_HIP(hipStreamSynchronize(c.stream));          // `tab` is pageable and goes out of scope
+    L(tabs.ensure(tab.size() * 8));
+    if (lrc == MH_OK) {
+      MH_HIP(hipMemcpyAsync(tabs.ptr, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c.stream));
+      MH_HIP(hipStreamSynchronize(c.stream));        // `tab` is pageable and goes out of scope
+    } else tabs.release();
   }
   const Fr* t_lo = (const Fr*)tabs.ptr; const Fr* t_hi = t_lo + LO;
   nttdist::Roots roots;
@@ -789,17 +837,17 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
     return MH_OK;
   };
   if (!inverse) {
-    MH_TRY(ntt_device_len(c, d_in, in_len, A, log_m, 0));   // Y_rank = local transform of the cyclic slice (short input: zero-padded)
-    MH_TRY(twist(A));                                // * w_n^(rank k2)
-    MH_TRY(exchange(A, B));                          // chunk q = k2 in block q -> rank q
-    MH_TRY(gdft((Fr*)d_out, B));                     // X[k2 + m k1], k1-major
+    if (lrc == MH_OK) L(ntt_device_len(c, d_in, in_len, A, log_m, 0));   // Y_rank = local transform of the cyclic slice (short input: zero-padded)
+    if (lrc == MH_OK) L(twist(A));                   // * w_n^(rank k2)
+    MH_TRY(exchange(A, B));                          // chunk q = k2 in block q -> rank q (always entered)
+    if (lrc == MH_OK) L(gdft((Fr*)d_out, B));        // X[k2 + m k1], k1-major
   } else {
-    MH_TRY(gdft(A, (const Fr*)d_in));                // G Z_j1[k2] for k2 in this rank's block, j1-major
-    MH_TRY(exchange(A, B));                          // chunk j1 -> rank j1: B = G w^(j1 k2) Y_j1, k2 in order
-    MH_TRY(twist(B));                                // * w_n^(-rank k2) / G
-    MH_TRY(ntt_device(c, B, d_out, log_m, 1));       // local inverse (with m^-1)
+    if (lrc == MH_OK) L(gdft(A, (const Fr*)d_in));   // G Z_j1[k2] for k2 in this rank's block, j1-major
+    MH_TRY(exchange(A, B));                          // chunk j1 -> rank j1: B = G w^(j1 k2) Y_j1, k2 in order (always entered)
+    if (lrc == MH_OK) L(twist(B));                   // * w_n^(-rank k2) / G
+    if (lrc == MH_OK) L(ntt_device(c, B, d_out, log_m, 1));   // local inverse (with m^-1)
   }
-  return MH_OK;
+  return lrc == MH_OK ? MH_OK : fail(lrc, g_job.msg);
 }
 }  // namespace
 namespace {
@@ -821,20 +869,31 @@ uint64_t slice_c(Context& c, Fr* dst, const Fr* src, uint64_t len) {
 int allgather2(Context& c, const Fr* a, uint64_t na, const Fr* b, uint64_t nb, const Fr** recv_out) {
   const uint64_t G = (uint64_t)g_shard.world, ch = na + nb;
   const uint64_t copies = g_shard.ag_dev ? 1 : G;        // a real all-gather sends its chunk once
-  MH_TRY(c.sl_send.ensure(copies * ch * 32)); MH_TRY(c.sl_recv.ensure(G * ch * 32));
-  hipLaunchKernelGGL(nttdist::replicate_kernel, dim3(grid256(ch)), dim3(256), 0, c.stream, (Fr*)c.sl_send.ptr, a, (u64)na, b, (u64)nb, (u32)copies);
-  MH_HIP(hipGetLastError());
+  // a poisoned rank (JobStatus) still enters the collective, with whatever its buffers hold
+  int lrc = g_job.poison;
+  auto L = [&](int r) { if (lrc == MH_OK && r != MH_OK) { lrc = r; poison(r); } };
+  L(c.sl_send.ensure(copies * ch * 32));
+  if (lrc == MH_OK) L(c.sl_recv.ensure(G * ch * 32));
+  void* snd = c.sl_send.ptr; void* rcv = c.sl_recv.ptr;
+  if (c.sl_send.cap < copies * ch * 32 || c.sl_recv.cap < G * ch * 32) {
+    if (g_job.buf_bytes < G * ch * 32) return fail(MH_ENOMEM, "sliced prove: no exchange buffer (this rank cannot enter the all-gather)");
+    snd = g_job.buf[0]; rcv = g_job.buf[1];
+  }
+  if (lrc == MH_OK) {
+    hipLaunchKernelGGL(nttdist::replicate_kernel, dim3(grid256(ch)), dim3(256), 0, c.stream, (Fr*)snd, a, (u64)na, b, (u64)nb, (u32)copies);
+    MH_HIP(hipGetLastError());
+  }
   if (!g_shard.a2a_ordered) MH_HIP(hipStreamSynchronize(c.stream));
   {
     ExchangeScope xs(c);
     if (g_shard.ag_dev) {
-      if (g_shard.ag_dev(c.sl_send.ptr, (size_t)ch * 32, c.sl_recv.ptr, g_shard.ag_dev_user) != 0) return fail(MH_EHIP, "sliced prove: all_gather failed: " + g_err);
-    } else if (g_shard.a2a(c.sl_send.ptr, (size_t)ch * 32, c.sl_recv.ptr, g_shard.a2a_user) != 0) {
+      if (g_shard.ag_dev(snd, (size_t)ch * 32, rcv, g_shard.ag_dev_user) != 0) return fail(MH_EHIP, "sliced prove: all_gather failed: " + g_err);
+    } else if (g_shard.a2a(snd, (size_t)ch * 32, rcv, g_shard.a2a_user) != 0) {
       return fail(MH_EHIP, "sliced prove: all_to_all failed: " + g_err);
     }
   }
-  *recv_out = (const Fr*)c.sl_recv.ptr;
-  return MH_OK;
+  *recv_out = (const Fr*)rcv;
+  return lrc == MH_OK ? MH_OK : fail(lrc, g_job.msg);
 }
 void unslice_c(Context& c, Fr* full, const Fr* recv, uint64_t len, uint64_t stride, uint64_t off) {
   hipLaunchKernelGGL(nttdist::unslice_c_kernel, dim3(grid256(len)), dim3(256), 0, c.stream, full, recv, (u64)len, (u32)g_shard.world, (u64)stride, (u64)off);
@@ -1372,6 +1431,12 @@ int mh_marlin_prove_fs(uint64_t pk_handle, const uint64_t* instance, const uint6
   const fsh::ExternalFs ext{fs->user, fs->initialize, fs->absorb, fs->next_u64};
   return marlin_prove_impl(pk_handle, instance, witness, false, zk_seed, zk_rounds, nullptr, 0, proof_out, cap, len_out, &ext);
 }
+// inside the prover a poisoned rank (JobStatus) launches nothing more: its buffers may be the ones that could not be set up
+#undef KLAUNCH
+#define KLAUNCH(kern, n, ...)                                                                          \
+  do {                                                                                                 \
+    if (g_job.poison == MH_OK) hipLaunchKernelGGL(kern, dim3(poly::grid_for(n)), dim3(poly::TPB), 0, c.stream, __VA_ARGS__); \
+  } while (0)
 static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const uint64_t* witness, bool inputs_on_device,
                              const uint8_t* zk_seed, int zk_rounds, const uint64_t* zk_draws, size_t n_draws, uint8_t* proof_out, size_t cap,
                              size_t* len_out, const fsh::ExternalFs* ext_fs) {
@@ -1388,6 +1453,8 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   if (zk_draws) { zk.draws = zk_draws; zk.n = n_draws; } else zk.chacha = fsh::ChaChaRng(zk_seed, zk_rounds);
   Trace tr(c);
   Fr* S[8]; for (int i = 0; i < 8; i++) S[i] = pk.S[i].fr();
+  g_job = JobStatus();                          // see JobStatus: a rank that fails locally fails the job instead of hanging it
+  g_job.buf[0] = S[6]; g_job.buf[1] = S[7]; g_job.buf_bytes = std::min(pk.S[6].bytes, pk.S[7].bytes);
   const Fr* tw = (const Fr*)c.tw;
   // sliced sections (rounds 2 and 3 on 1 / G of every 4H- and K-sized vector): with an all-to-all registered and a
   // power-of-two number of ranks; MH_SLICED=0 keeps every rank on the replicated rounds
@@ -1397,11 +1464,11 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   // at 2^20 for 2.4 ms of saved kernels; MH_SLICED=2 forces it for tests)
   static const bool sliced_force = [] { const char* e = getenv("MH_SLICED"); return e && atoi(e) == 2; }();
   const bool sliced = sliced_env && (Gs >= 4 || (sliced_force && Gs > 1)) && g_shard.a2a && (Gs & (Gs - 1)) == 0 && Gs <= 8 && H >= Gs * Gs;
-  if (sliced) MH_TRY(prepare_sliced(c, pk));
+  if (sliced) PTRY(prepare_sliced(c, pk));
 
   // ---------------- prover_init (prover.rs:211-306): z = x || w, z_A = A z, z_B = B z --------------------
-  if (inputs_on_device) { MH_TRY(d2d(c, pk.z.fr(), (const Fr*)instance, X)); MH_TRY(d2d(c, pk.z.fr() + X, (const Fr*)witness, nw)); }
-  else { MH_TRY(h2d(c, pk.z.fr(), instance, X * 32)); MH_TRY(h2d(c, pk.z.fr() + X, witness, nw * 32)); }
+  if (inputs_on_device) { PTRY(d2d(c, pk.z.fr(), (const Fr*)instance, X)); PTRY(d2d(c, pk.z.fr() + X, (const Fr*)witness, nw)); }
+  else { PTRY(h2d(c, pk.z.fr(), instance, X * 32)); PTRY(h2d(c, pk.z.fr() + X, witness, nw * 32)); }
   {
     ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::spmv_kernel, nc, pk.za_ev.fr(), (const u64*)pk.A.row_ptr.p, (const u32*)pk.A.col.p,
@@ -1409,7 +1476,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     KLAUNCH(poly::spmv_kernel, nc, pk.zb_ev.fr(), (const u64*)pk.B.row_ptr.p, (const u32*)pk.B.col.p,
             pk.B.has_val ? (const Fr*)pk.B.val.p : (const Fr*)nullptr, (const Fr*)pk.z.fr(), (u64)nc);
   }
-  MH_TRY(zero_tail(c, pk.za_ev.fr(), nc, H)); MH_TRY(zero_tail(c, pk.zb_ev.fr(), nc, H));
+  PTRY(zero_tail(c, pk.za_ev.fr(), nc, H)); PTRY(zero_tail(c, pk.zb_ev.fr(), nc, H));
   std::vector<HFr> pub(X - 1);                      // public_input() = formatted input without the leading one
   for (uint64_t i = 1; i < X; i++) memcpy(pub[i - 1].v, instance + 4 * i, 32);
   fsh::FiatShamirRng fs;
@@ -1424,36 +1491,36 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
 
   tr.mark("AHP::Prover::Init (z_A, z_B)");
   // ---------------- first round (prover.rs:309-409) -----------------------------------------------------------
-  MH_TRY(ntt_device(c, pk.z.fr(), pk.xpoly.fr(), lgX, 1));              // x_poly = interpolate(formatted input)
+  PTRY(ntt_device(c, pk.z.fr(), pk.xpoly.fr(), lgX, 1));              // x_poly = interpolate(formatted input)
   if (X <= 16) {                                                        // x_evals = domain_h.fft(x_poly): Horner per point
     ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::eval_small_poly_kernel, H, S[1], (const Fr*)pk.xpoly.fr(), (u32)X, tw, lgH);
   } else {
-    MH_TRY(d2d(c, S[0], pk.xpoly.fr(), X)); MH_TRY(zero_tail(c, S[0], X, H));
-    MH_TRY(ntt_device(c, S[0], S[1], lgH, 0));
+    PTRY(d2d(c, S[0], pk.xpoly.fr(), X)); PTRY(zero_tail(c, S[0], X, H));
+    PTRY(ntt_device(c, S[0], S[1], lgH, 0));
   }
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::w_evals_kernel, H, S[2], (const Fr*)(pk.z.fr() + X), (u64)nw, (const Fr*)S[1], (u64)H, (u64)(H / X)); }
-  MH_TRY(ntt_device(c, S[2], S[3], lgH, 1));
+  PTRY(ntt_device(c, S[2], S[3], lgH, 1));
   // + r * v_H: the reference multiplies by FFT (prover.rs:352); the product is exactly [-r, 0.., 0, r]
   HFr r_w = zk.fr();
-  hipLaunchKernelGGL(poly::blind_vanishing_kernel, dim3(1), dim3(64), 0, c.stream, S[3], (u64)H, arg(r_w));
+  if (g_job.poison == MH_OK) hipLaunchKernelGGL(poly::blind_vanishing_kernel, dim3(1), dim3(64), 0, c.stream, S[3], (u64)H, arg(r_w));
   const uint64_t w_len = H + 1 - X;                                       // (w + r v_H) / v_X, remainder zero
-  MH_TRY(div_vanishing(c, pk.w.fr(), S[3], H + 1, X, S[4]));
+  PTRY(div_vanishing(c, pk.w.fr(), S[3], H + 1, X, S[4]));
   auto blind_h = [&](Fr* dst, const Fr* evals, HFr* r_out) -> int {
-    MH_TRY(ntt_device(c, evals, dst, lgH, 1));
+    PTRY(ntt_device(c, evals, dst, lgH, 1));
     HFr r = zk.fr(); *r_out = r;
-    hipLaunchKernelGGL(poly::blind_vanishing_kernel, dim3(1), dim3(64), 0, c.stream, dst, (u64)H, arg(r));
+    if (g_job.poison == MH_OK) hipLaunchKernelGGL(poly::blind_vanishing_kernel, dim3(1), dim3(64), 0, c.stream, dst, (u64)H, arg(r));
     return MH_OK;
   };
   HFr r_za, r_zb;
-  MH_TRY(blind_h(pk.za.fr(), pk.za_ev.fr(), &r_za));
-  MH_TRY(blind_h(pk.zb.fr(), pk.zb_ev.fr(), &r_zb));
+  PTRY(blind_h(pk.za.fr(), pk.za_ev.fr(), &r_za));
+  PTRY(blind_h(pk.zb.fr(), pk.zb_ev.fr(), &r_zb));
   const uint64_t za_len = H + 1;
   // mask polynomial (prover.rs:369-381): 3H sequential draws, then force sum over H to zero
   const uint64_t mask_len = 3 * H;          // degree 3H + 2*zk_bound - 3
-  MH_TRY(device_poly_rand(c, pk, zk, pk.mask.fr(), mask_len, S[0], (u32*)S[1]));
-  hipLaunchKernelGGL(rng::mask_fix_kernel, dim3(1), dim3(1), 0, c.stream, pk.mask.fr(), (u64)H, (u64)mask_len);
+  PTRY(device_poly_rand(c, pk, zk, pk.mask.fr(), mask_len, S[0], (u32*)S[1]));
+  if (g_job.poison == MH_OK) hipLaunchKernelGGL(rng::mask_fix_kernel, dim3(1), dim3(1), 0, c.stream, pk.mask.fr(), (u64)H, (u64)mask_len);
   tr.mark("AHP::Prover::FirstRound (w, z_A, z_B, mask polys)");
   // Three of round 2's five forward 4H transforms need no challenge: z_a and z_b (prover.rs:467) and z = w v_X + x
   // (prover.rs:503-516, 534).  They are handed to the commitment's MSM batch as its side job (Context::side_job): issued on the
@@ -1465,10 +1532,10 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   const uint64_t z_len = w_len + X;
   const bool side_ntt = !sliced;
   auto early_transforms = [&]() -> int {
-    MH_TRY(ntt_device_len(c, pk.za.fr(), za_len, S[0], lg4H, 0));
-    MH_TRY(ntt_device_len(c, pk.zb.fr(), za_len, S[1], lg4H, 0));
+    PTRY(ntt_device_len(c, pk.za.fr(), za_len, S[0], lg4H, 0));
+    PTRY(ntt_device_len(c, pk.zb.fr(), za_len, S[1], lg4H, 0));
     { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::z_poly_kernel, z_len, S[7], (const Fr*)pk.w.fr(), (u64)w_len, (u64)X, (const Fr*)pk.xpoly.fr(), (u64)X); }
-    MH_TRY(ntt_device_len(c, S[7], z_len, S[2], lg4H, 0));
+    PTRY(ntt_device_len(c, S[7], z_len, S[2], lg4H, 0));
     return MH_OK;
   };
   struct SideJobGuard { Context& c; ~SideJobGuard() { c.side_job = nullptr; } } side_guard{c};   // the job captures this frame
@@ -1476,11 +1543,11 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   if (side_ntt) c.side_job = early_transforms;
   // PC::commit first round (lib.rs:172): w, z_a, z_b hiding 1; mask none
   std::vector<fsh::Commitment> cm1; std::vector<PolyRand> rd1;
-  MH_TRY(marlin_commit(c, pk, {{pk.w.fr(), w_len, false, 0, true}, {pk.za.fr(), za_len, false, 0, true},
+  CTRY(marlin_commit(c, pk, {{pk.w.fr(), w_len, false, 0, true}, {pk.za.fr(), za_len, false, 0, true},
                                {pk.zb.fr(), za_len, false, 0, true}, {pk.mask.fr(), mask_len, false, 0, false}}, &zk, cm1, rd1));
   if (side_ntt) {
-    if (c.side_ran) { MH_HIP(hipStreamWaitEvent(c.stream, c.side_ev[1], 0)); c.side_ran = false; }   // round 2 starts behind the side stream
-    else { c.side_job = nullptr; MH_TRY(early_transforms()); }                                       // the batch never took it (variable-base path)
+    if (c.side_ran) { PHIP(hipStreamWaitEvent(c.stream, c.side_ev[1], 0)); c.side_ran = false; }   // round 2 starts behind the side stream
+    else { c.side_job = nullptr; PTRY(early_transforms()); }                                       // the batch never took it (variable-base path)
   }
   fsh::Commitment &c_w = cm1[0], &c_za = cm1[1], &c_zb = cm1[2], &c_mask = cm1[3];
   PolyRand &rd_w = rd1[0], &rd_za = rd1[1], &rd_zb = rd1[2];
@@ -1499,11 +1566,11 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   // ---------------- second round (prover.rs:443-570) ---------------------------------------------------------
   const uint64_t H4loc = sliced ? H4 / Gs : H4;          // elements of a 4H-vector this rank works on
   if (sliced) {
-    MH_TRY(ntt_dist_device(c, S[0], slice_c(c, S[0], pk.za.fr(), za_len), S[0], lg4H, 0));
-    MH_TRY(ntt_dist_device(c, S[1], slice_c(c, S[1], pk.zb.fr(), za_len), S[1], lg4H, 0));
+    CTRY(ntt_dist_device(c, S[0], slice_c(c, S[0], pk.za.fr(), za_len), S[0], lg4H, 0));
+    CTRY(ntt_dist_device(c, S[1], slice_c(c, S[1], pk.zb.fr(), za_len), S[1], lg4H, 0));
   } else if (!side_ntt) {
-  MH_TRY(ntt_device_len(c, pk.za.fr(), za_len, S[0], lg4H, 0));
-  MH_TRY(ntt_device_len(c, pk.zb.fr(), za_len, S[1], lg4H, 0));
+  PTRY(ntt_device_len(c, pk.za.fr(), za_len, S[0], lg4H, 0));
+  PTRY(ntt_device_len(c, pk.zb.fr(), za_len, S[1], lg4H, 0));
   }
   // The reference forms z_c = z_a * z_b (two forward transforms, a pointwise product, one inverse: prover.rs:467),
   // summed_z_m = eta_a z_a + eta_b z_b + eta_c z_c (468-471), and later evaluates summed_z_m on the same 4H domain
@@ -1515,8 +1582,8 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::x_minus_elements_kernel, H, S[4], tw, arg(alpha), lgH);
   }
-  MH_TRY(batch_inverse(c, S[4], S[5], H, vH_alpha, 1));
-  MH_TRY(ntt_device(c, S[4], S[5], lgH, 1));                                 // r_alpha_poly
+  PTRY(batch_inverse(c, S[4], S[5], H, vH_alpha, 1));
+  PTRY(ntt_device(c, S[4], S[5], lgH, 1));                                 // r_alpha_poly
   // t (prover.rs:411-428)
   { ProfScope ps(c, PF_GLUE);
     Fr* partial = pk.small.fr();
@@ -1525,7 +1592,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     Fr* partial2 = partial + pk.t_nitems;
     KLAUNCH(poly::t_sum_kernel, pk.t_ngroups, partial2, (const Fr*)partial, (const u64*)pk.t_group_ptr.p, (u64)pk.t_ngroups);
     KLAUNCH(poly::t_sum_kernel, H, S[6], (const Fr*)partial2, (const u64*)pk.t_item_ptr.p, (u64)H); }
-  MH_TRY(ntt_device(c, S[6], pk.t.fr(), lgH, 1));
+  PTRY(ntt_device(c, S[6], pk.t.fr(), lgH, 1));
   // z = w * v_X + x  (prover.rs:503-516)
   if (!side_ntt) { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::z_poly_kernel, z_len, S[7], (const Fr*)pk.w.fr(), (u64)w_len, (u64)X, (const Fr*)pk.xpoly.fr(), (u64)X); }
   // q_1 (prover.rs:520-547): forward transforms on the 4H domain (summed_z_m's is known, see above), pointwise, one inverse
@@ -1535,38 +1602,38 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     // M-layout block -> distributed inverse -> q_1, the division by v_H (stride H / G inside a slice) and the remainder, all
     // local; then ONE all-gather returns h_1 and x g_1 to every rank
     const uint64_t Hloc = H / Gs;
-    MH_TRY(ntt_dist_device(c, S[0], slice_c(c, S[0], S[5], H), S[0], lg4H, 0));                  // r_alpha
-    MH_TRY(ntt_dist_device(c, S[2], slice_c(c, S[2], S[7], z_len), S[2], lg4H, 0));              // z
-    MH_TRY(ntt_dist_device(c, S[4], slice_c(c, S[4], pk.t.fr(), H), S[4], lg4H, 0));             // t
+    CTRY(ntt_dist_device(c, S[0], slice_c(c, S[0], S[5], H), S[0], lg4H, 0));                  // r_alpha
+    CTRY(ntt_dist_device(c, S[2], slice_c(c, S[2], S[7], z_len), S[2], lg4H, 0));              // z
+    CTRY(ntt_dist_device(c, S[4], slice_c(c, S[4], pk.t.fr(), H), S[4], lg4H, 0));             // t
     { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_sub_mul_kernel, H4loc, S[0], (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2], (const Fr*)S[4], (u64)H4loc); }
-    MH_TRY(ntt_dist_device(c, S[0], H4loc, S[1], lg4H, 1));                                      // rhs, cyclic slice
+    CTRY(ntt_dist_device(c, S[0], H4loc, S[1], lg4H, 1));                                      // rhs, cyclic slice
     const uint64_t mask_loc = slice_c(c, S[2], pk.mask.fr(), mask_len);
-    MH_TRY(lincomb(c, S[2], H4loc, {{S[2], mask_loc, HFr::one()}, {S[1], H4loc, HFr::one()}}));  // q_1 slice
-    MH_TRY(div_vanishing(c, S[6], S[2], H4loc, Hloc, S[3]));                                     // h_1 slice (3H / G)
-    MH_TRY(lincomb(c, S[4], Hloc, {{S[2], Hloc, HFr::one()}, {S[6], Hloc, HFr::one()}}));        // slice of the remainder x g_1
+    PTRY(lincomb(c, S[2], H4loc, {{S[2], mask_loc, HFr::one()}, {S[1], H4loc, HFr::one()}}));  // q_1 slice
+    PTRY(div_vanishing(c, S[6], S[2], H4loc, Hloc, S[3]));                                     // h_1 slice (3H / G)
+    PTRY(lincomb(c, S[4], Hloc, {{S[2], Hloc, HFr::one()}, {S[6], Hloc, HFr::one()}}));        // slice of the remainder x g_1
     const Fr* rcv = nullptr;
-    MH_TRY(allgather2(c, S[6], 2 * Hloc, S[4], Hloc, &rcv));
+    CTRY(allgather2(c, S[6], 2 * Hloc, S[4], Hloc, &rcv));
     { ProfScope ps(c, PF_GLUE);
       unslice_c(c, pk.h1.fr(), rcv, h1_len, 3 * Hloc, 0);
       unslice_c(c, S[4], rcv, H, 3 * Hloc, 2 * Hloc); }
-    MH_HIP(hipGetLastError());
+    PHIP(hipGetLastError());
   } else {
-  MH_TRY(ntt_device_len(c, S[5], H, S[0], lg4H, 0));                                     // r_alpha
+  PTRY(ntt_device_len(c, S[5], H, S[0], lg4H, 0));                                     // r_alpha
   // summed_z_m: already in S[1]
-  if (!side_ntt) MH_TRY(ntt_device_len(c, S[7], z_len, S[2], lg4H, 0));                  // z (else: already there, beside round 1's commitment)
-  MH_TRY(ntt_device_len(c, pk.t.fr(), H, S[4], lg4H, 0));                                // t
+  if (!side_ntt) PTRY(ntt_device_len(c, S[7], z_len, S[2], lg4H, 0));                  // z (else: already there, beside round 1's commitment)
+  PTRY(ntt_device_len(c, pk.t.fr(), H, S[4], lg4H, 0));                                // t
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::mul_sub_mul_kernel, H4, S[0], (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2], (const Fr*)S[4], (u64)H4); }
-  MH_TRY(ntt_device(c, S[0], S[1], lg4H, 1));                                  // rhs
-  MH_TRY(lincomb(c, S[2], H4, {{pk.mask.fr(), mask_len, HFr::one()}, {S[1], H4, HFr::one()}}));      // q_1 = mask + rhs
+  PTRY(ntt_device(c, S[0], S[1], lg4H, 1));                                  // rhs
+  PTRY(lincomb(c, S[2], H4, {{pk.mask.fr(), mask_len, HFr::one()}, {S[1], H4, HFr::one()}}));      // q_1 = mask + rhs
   // (h_1, x g_1) = q_1 / v_H (prover.rs:550-551)
-  MH_TRY(div_vanishing(c, pk.h1.fr(), S[2], H4, H, S[3]));
-  MH_TRY(lincomb(c, S[4], H, {{S[2], H, HFr::one()}, {pk.h1.fr(), H, HFr::one()}}));   // remainder = x g_1
+  PTRY(div_vanishing(c, pk.h1.fr(), S[2], H4, H, S[3]));
+  PTRY(lincomb(c, S[4], H, {{S[2], H, HFr::one()}, {pk.h1.fr(), H, HFr::one()}}));   // remainder = x g_1
   }
-  MH_TRY(d2d(c, pk.g1.fr(), S[4] + 1, H - 1));
+  PTRY(d2d(c, pk.g1.fr(), S[4] + 1, H - 1));
   const uint64_t g1_len = H - 1;
   tr.mark("AHP::Prover::SecondRound");
   std::vector<fsh::Commitment> cm2; std::vector<PolyRand> rd2;
-  MH_TRY(marlin_commit(c, pk, {{pk.t.fr(), H, false, 0, false}, {pk.g1.fr(), g1_len, true, H - 2, true},
+  CTRY(marlin_commit(c, pk, {{pk.t.fr(), H, false, 0, false}, {pk.g1.fr(), g1_len, true, H - 2, true},
                                {pk.h1.fr(), h1_len, false, 0, false}}, &zk, cm2, rd2));
   fsh::Commitment &c_t = cm2[0], &c_g1 = cm2[1], &c_h1 = cm2[2];
   PolyRand& rd_g1 = rd2[1];
@@ -1600,12 +1667,12 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     const uint64_t Kloc = K / Gs;
     { ProfScope ps(c, PF_GLUE);
       KLAUNCH(poly::denom_kernel, Kloc, S[1], (const Fr*)pk.sl_ev[0].p, (const Fr*)pk.sl_ev[1].p, arg(alpha), arg(beta), (u64)Kloc); }
-    MH_TRY(batch_inverse(c, S[1], S[3], Kloc, HFr::one(), 0));
+    PTRY(batch_inverse(c, S[1], S[3], Kloc, HFr::one(), 0));
     { ProfScope ps(c, PF_GLUE);
       KLAUNCH(poly::f_evals_kernel, Kloc, S[3], (const Fr*)S[1], (const Fr*)pk.sl_ev[2].p, (const Fr*)pk.sl_ev[3].p, (const Fr*)pk.sl_ev[4].p, arg(ea), arg(eb), arg(ec), (u64)Kloc); }
-    MH_TRY(ntt_dist_device(c, S[3], Kloc, S[4], lgK, 1));                        // f, cyclic slice
+    CTRY(ntt_dist_device(c, S[3], Kloc, S[4], lgK, 1));                        // f, cyclic slice
     { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, Kloc, S[5], (const Fr*)S[4], (const Fr*)pk.sl_gpow_hi.p, (const Fr*)pk.sl_gpow_lo.p, (u64)Kloc); }
-    MH_TRY(ntt_dist_device(c, S[5], Kloc, S[6], lgK, 0));                        // f on g K, this rank's block
+    CTRY(ntt_dist_device(c, S[5], Kloc, S[6], lgK, 0));                        // f on g K, this rank's block
     {
       HFr vk_inv = (pk.coset_g.pow_u64(K) - HFr::one()).inv();
       ProfScope ps(c, PF_GLUE);
@@ -1613,26 +1680,26 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
               (const Fr*)pk.sl_cs[3].p, (const Fr*)pk.sl_cs[4].p, (const Fr*)pk.sl_cs[5].p, arg(ea), arg(eb), arg(ec), arg(alpha), arg(beta),
               arg(alpha_beta), arg(vk_inv), (u64)Kloc);
     }
-    MH_TRY(ntt_dist_device(c, S[5], Kloc, S[6], lgK, 1));
+    CTRY(ntt_dist_device(c, S[5], Kloc, S[6], lgK, 1));
     { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, Kloc, S[7], (const Fr*)S[6], (const Fr*)pk.sl_ginv_hi.p, (const Fr*)pk.sl_ginv_lo.p, (u64)Kloc); }
     const Fr* rcv = nullptr;
-    MH_TRY(allgather2(c, S[4], Kloc, S[7], Kloc, &rcv));
+    CTRY(allgather2(c, S[4], Kloc, S[7], Kloc, &rcv));
     { ProfScope ps(c, PF_GLUE);
       unslice_c(c, S[4], rcv, K, 2 * Kloc, 0);
       unslice_c(c, pk.h2.fr(), rcv, K, 2 * Kloc, Kloc); }
-    MH_HIP(hipGetLastError());
-    MH_TRY(d2d(c, pk.g2.fr(), S[4] + 1, K - 1));                                // g_2 = f / X
+    PHIP(hipGetLastError());
+    PTRY(d2d(c, pk.g2.fr(), S[4] + 1, K - 1));                                // g_2 = f / X
   } else {
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::denom_kernel, K, S[1], (const Fr*)pk.ev_row.p, (const Fr*)pk.ev_col.p, arg(alpha), arg(beta), (u64)K);
   }
-  MH_TRY(batch_inverse(c, S[1], S[3], K, HFr::one(), 0));
+  PTRY(batch_inverse(c, S[1], S[3], K, HFr::one(), 0));
   { ProfScope ps(c, PF_GLUE);
     KLAUNCH(poly::f_evals_kernel, K, S[3], (const Fr*)S[1], (const Fr*)pk.ev_val_a.p, (const Fr*)pk.ev_val_b.p, (const Fr*)pk.ev_val_c.p, arg(ea), arg(eb), arg(ec), (u64)K); }
-  MH_TRY(ntt_device(c, S[3], S[4], lgK, 1));                                    // f
-  MH_TRY(d2d(c, pk.g2.fr(), S[4] + 1, K - 1));                                  // g_2 = f / X
+  PTRY(ntt_device(c, S[3], S[4], lgK, 1));                                    // f
+  PTRY(d2d(c, pk.g2.fr(), S[4] + 1, K - 1));                                  // g_2 = f / X
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, K, S[5], (const Fr*)S[4], (const Fr*)pk.gpow_hi.p, (const Fr*)pk.gpow_lo.p, (u64)K); }
-  MH_TRY(ntt_device(c, S[5], S[6], lgK, 0));                                    // f on g K
+  PTRY(ntt_device(c, S[5], S[6], lgK, 0));                                    // f on g K
   {
     HFr vk_inv = (pk.coset_g.pow_u64(K) - HFr::one()).inv();
     ProfScope ps(c, PF_GLUE);
@@ -1640,14 +1707,14 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
             (const Fr*)pk.cs_row.p, (const Fr*)pk.cs_col.p, (const Fr*)pk.cs_row_col.p, arg(ea), arg(eb), arg(ec), arg(alpha), arg(beta),
             arg(alpha_beta), arg(vk_inv), (u64)K);
   }
-  MH_TRY(ntt_device(c, S[5], S[6], lgK, 1));
+  PTRY(ntt_device(c, S[5], S[6], lgK, 1));
   { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::twist_kernel, K, pk.h2.fr(), (const Fr*)S[6], (const Fr*)pk.ginv_hi.p, (const Fr*)pk.ginv_lo.p, (u64)K); }
   }
   const uint64_t g2_len = K - 1;
   const uint64_t h2_len = K - 1;
   tr.mark("AHP::Prover::ThirdRound");
   std::vector<fsh::Commitment> cm3; std::vector<PolyRand> rd3;
-  MH_TRY(marlin_commit(c, pk, {{pk.g2.fr(), g2_len, true, K - 2, false}, {pk.h2.fr(), h2_len, false, 0, false}}, &zk, cm3, rd3));
+  CTRY(marlin_commit(c, pk, {{pk.g2.fr(), g2_len, true, K - 2, false}, {pk.h2.fr(), h2_len, false, 0, false}}, &zk, cm3, rd3));
   fsh::Commitment &c_g2 = cm3[0], &c_h2 = cm3[1];
   {
     std::vector<uint8_t> b;
@@ -1662,13 +1729,13 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   {
     // four evaluations, ONE copy back
     Fr* slots = (Fr*)pk.scal.p;
-    MH_TRY(eval_poly(c, pk, pk.g1.fr(), g1_len, beta, nullptr, slots + 0));
-    MH_TRY(eval_poly(c, pk, pk.g2.fr(), g2_len, gamma, nullptr, slots + 1));
-    MH_TRY(eval_poly(c, pk, pk.t.fr(), H, beta, nullptr, slots + 2));
-    MH_TRY(eval_poly(c, pk, pk.zb.fr(), za_len, beta, nullptr, slots + 3));
+    PTRY(eval_poly(c, pk, pk.g1.fr(), g1_len, beta, nullptr, slots + 0));
+    PTRY(eval_poly(c, pk, pk.g2.fr(), g2_len, gamma, nullptr, slots + 1));
+    PTRY(eval_poly(c, pk, pk.t.fr(), H, beta, nullptr, slots + 2));
+    PTRY(eval_poly(c, pk, pk.zb.fr(), za_len, beta, nullptr, slots + 3));
     uint64_t hv[16];
-    MH_HIP(hipMemcpyAsync(hv, slots, 4 * 32, hipMemcpyDeviceToHost, c.stream));
-    MH_HIP(hipStreamSynchronize(c.stream));
+    PHIP(hipMemcpyAsync(hv, slots, 4 * 32, hipMemcpyDeviceToHost, c.stream));
+    PHIP(hipStreamSynchronize(c.stream));
     memcpy(g1_beta.v, hv, 32); memcpy(g2_gamma.v, hv + 4, 32); memcpy(t_beta.v, hv + 8, 32); memcpy(zb_beta.v, hv + 12, 32);
   }
   {
@@ -1693,9 +1760,9 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   const bool sliced_open = sliced && sliced_open_env && pk.pc == 0 && pk.srs_max_degree - (K - 2) == 1 &&
                            std::max(mask_len - 1, pk.srs_max_degree - (H - 2) + (H - 2)) <= pk.S[1].bytes / 32;
   if (!sliced_open) {
-  MH_TRY(lincomb(c, pk.outer.fr(), mask_len, {{pk.mask.fr(), mask_len, HFr::one()}, {pk.za.fr(), za_len, c_za_lc},
+  PTRY(lincomb(c, pk.outer.fr(), mask_len, {{pk.mask.fr(), mask_len, HFr::one()}, {pk.za.fr(), za_len, c_za_lc},
                                                {pk.w.fr(), w_len, c_w_lc}, {pk.h1.fr(), h1_len, c_h1_lc}}));
-  MH_TRY(lincomb(c, pk.inner.fr(), K, {{pk.p_a_val.fr(), K, ea}, {pk.p_b_val.fr(), K, eb}, {pk.p_c_val.fr(), K, ec},
+  PTRY(lincomb(c, pk.inner.fr(), K, {{pk.p_a_val.fr(), K, ea}, {pk.p_b_val.fr(), K, eb}, {pk.p_c_val.fr(), K, ec},
                                        {pk.p_row.fr(), K, alpha * mult}, {pk.p_col.fr(), K, beta * mult}, {pk.p_row_col.fr(), K, mult.neg()},
                                        {pk.h2.fr(), h2_len, vK_gamma.neg()}}));
   }
@@ -1710,13 +1777,13 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   if (pk.pc == 1) {
     // SonicKZG10::open [SURVEY B-5]: per point ONE combined polynomial sum_i xi^i p_i (labels in BTreeSet order) and one
     // KZG10::open on the unshifted powers.  beta: g_1, outer_sumcheck, t, z_b; gamma: g_2, inner_sumcheck.
-    MH_TRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(1)},
+    PTRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(1)},
                                        {pk.t.fr(), H, xi_pow(2)}, {pk.zb.fr(), za_len, xi_pow(3)}}));
-    MH_TRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));
-    MH_TRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(1)}}));
-    MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
+    PTRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));
+    PTRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(1)}}));
+    PTRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
     std::vector<HG1> om;
-    MH_TRY(sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts, S[5], K - 1}}, om));
+    CTRY(sharded_msm_batch(c, {{srs_pts, S[1], mask_len - 1}, {srs_pts, S[5], K - 1}}, om));
     HG1 wacc = om[0];
     std::vector<HFr> r;
     host_axpy(r, HFr::one(), rd_g1.rand.blind);
@@ -1752,12 +1819,12 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     const uint64_t ab = bounds(mb_len, wb_len, mask_len, r), eb_ = bounds(mb_len, wb_len, mask_len, r + 1);     // beta: block [ab, eb_)
     const uint64_t ag = bounds(mg_len, wg_len, K, r), eg = bounds(mg_len, wg_len, K, r + 1);                    // gamma
     // blocks of the combined polynomials: beta in S[0], gamma in S[3]
-    MH_TRY(lincomb(c, S[0], eb_ - ab, {clip(pk.g1.fr(), g1_len, ab, eb_, HFr::one()), clip(pk.mask.fr(), mask_len, ab, eb_, xi_pow(2)),
+    PTRY(lincomb(c, S[0], eb_ - ab, {clip(pk.g1.fr(), g1_len, ab, eb_, HFr::one()), clip(pk.mask.fr(), mask_len, ab, eb_, xi_pow(2)),
                                        clip(pk.za.fr(), za_len, ab, eb_, xi_pow(2) * c_za_lc), clip(pk.w.fr(), w_len, ab, eb_, xi_pow(2) * c_w_lc),
                                        clip(pk.h1.fr(), h1_len, ab, eb_, xi_pow(2) * c_h1_lc), clip(pk.t.fr(), H, ab, eb_, xi_pow(3)),
                                        clip(pk.zb.fr(), za_len, ab, eb_, xi_pow(4))}));
     const HFr x2 = xi_pow(2);
-    MH_TRY(lincomb(c, S[3], eg - ag, {clip(pk.g2.fr(), g2_len, ag, eg, HFr::one()), clip(pk.p_a_val.fr(), K, ag, eg, x2 * ea),
+    PTRY(lincomb(c, S[3], eg - ag, {clip(pk.g2.fr(), g2_len, ag, eg, HFr::one()), clip(pk.p_a_val.fr(), K, ag, eg, x2 * ea),
                                       clip(pk.p_b_val.fr(), K, ag, eg, x2 * eb), clip(pk.p_c_val.fr(), K, ag, eg, x2 * ec),
                                       clip(pk.p_row.fr(), K, ag, eg, x2 * alpha * mult), clip(pk.p_col.fr(), K, ag, eg, x2 * beta * mult),
                                       clip(pk.p_row_col.fr(), K, ag, eg, x2 * mult.neg()), clip(pk.h2.fr(), h2_len, ag, eg, x2 * vK_gamma.neg())}));
@@ -1768,8 +1835,8 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     }
     // block values at the points, exchanged
     HFr Eb = HFr::zero(), Eg = HFr::zero();
-    if (eb_ > ab) MH_TRY(eval_poly(c, pk, S[0], eb_ - ab, beta, &Eb));
-    if (eg > ag) MH_TRY(eval_poly(c, pk, S[3], eg - ag, gamma, &Eg));
+    if (eb_ > ab) PTRY(eval_poly(c, pk, S[0], eb_ - ab, beta, &Eb));
+    if (eg > ag) PTRY(eval_poly(c, pk, S[3], eg - ag, gamma, &Eg));
     std::vector<uint64_t> snd(8), all_e(8 * G);
     memcpy(&snd[0], Eb.v, 32); memcpy(&snd[4], Eg.v, 32);
     {
@@ -1790,58 +1857,58 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
       const uint64_t qb = std::min(e, qlen);                 // quotient indices [a, qb)
       if (qb <= a) return MH_OK;
       uint64_t n = e - a;
-      if (r + 1 < G) { MH_TRY(set_fr(c, blk + (qb - a), car)); n = qb - a + 1; }
+      if (r + 1 < G) { PTRY(set_fr(c, blk + (qb - a), car)); n = qb - a + 1; }
       return div_linear(c, q, blk, n, z, S[2]);
     };
     const uint64_t lo_b = mb_len * r / G, hi_b = mb_len * (r + 1) / G;     // this rank's block of the merged beta vector
-    MH_HIP(hipMemsetAsync(S[1], 0, (hi_b - lo_b + 1) * 32, c.stream));
-    if (ab >= lo_b) MH_TRY(divide_block(S[1] + (ab - lo_b), S[0], ab, eb_, wb_len, beta, carry(0, beta, mb_len, wb_len, mask_len)));   // else: no main-witness index in this block
+    PHIP(hipMemsetAsync(S[1], 0, (hi_b - lo_b + 1) * 32, c.stream));
+    if (ab >= lo_b) PTRY(divide_block(S[1] + (ab - lo_b), S[0], ab, eb_, wb_len, beta, carry(0, beta, mb_len, wb_len, mask_len)));   // else: no main-witness index in this block
     // shifted witness of g_1 on [lo_b, hi_b) n [off_b, off_b + swb_len): quotient indices [ka, kb) of g_1 / (X - beta)
     {
       const uint64_t ka = std::max(lo_b, off_b) - off_b, kb = std::min(std::max(hi_b, off_b), off_b + swb_len) - off_b;
       if (kb > ka) {
         HFr car = HFr::zero();
-        MH_TRY(eval_poly(c, pk, pk.g1.fr() + kb, g1_len - kb, beta, &car));                 // sum_{j >= kb} g_1[j] beta^(j - kb)
-        MH_TRY(d2d(c, S[4], pk.g1.fr() + ka, kb - ka));
-        MH_TRY(set_fr(c, S[4] + (kb - ka), car));
-        MH_TRY(div_linear(c, S[6], S[4], kb - ka + 1, beta, S[2]));
+        PTRY(eval_poly(c, pk, pk.g1.fr() + kb, g1_len - kb, beta, &car));                 // sum_{j >= kb} g_1[j] beta^(j - kb)
+        PTRY(d2d(c, S[4], pk.g1.fr() + ka, kb - ka));
+        PTRY(set_fr(c, S[4] + (kb - ka), car));
+        PTRY(div_linear(c, S[6], S[4], kb - ka + 1, beta, S[2]));
         ProfScope ps(c, PF_GLUE);
         KLAUNCH(poly::axpy_shifted_kernel, kb - ka, S[1], (const Fr*)S[6], arg(xi_pow(1)), (u64)(off_b + ka - lo_b), (u64)(kb - ka));
       }
     }
-    MH_TRY(divide_block(S[5], S[3], ag, eg, wg_len, gamma, carry(1, gamma, mg_len, wg_len, K)));
-    if (r == 0) hipLaunchKernelGGL(poly::add_const_kernel, dim3(1), dim3(64), 0, c.stream, S[5], arg((xi_pow(1) * g2_gamma).neg()));
-    MH_HIP(hipGetLastError());
+    PTRY(divide_block(S[5], S[3], ag, eg, wg_len, gamma, carry(1, gamma, mg_len, wg_len, K)));
+    if (r == 0 && g_job.poison == MH_OK) hipLaunchKernelGGL(poly::add_const_kernel, dim3(1), dim3(64), 0, c.stream, S[5], arg((xi_pow(1) * g2_gamma).neg()));
+    PHIP(hipGetLastError());
     const uint64_t qg_end = std::min(eg, wg_len);
     std::vector<MsmJob> jobs;
     jobs.push_back({srs_pts + lo_b * PT_B, S[1], hi_b - lo_b});
     jobs.push_back({srs_pts + ag * PT_B, S[5], qg_end > ag ? qg_end - ag : 0});
     std::vector<HG1> res;
-    MH_TRY(sharded_msm_batch(c, jobs, res, 1, true));
+    CTRY(sharded_msm_batch(c, jobs, res, 1, true));
     om = {res[0], res[1]};
   }
   // The MSMs of the two opening proofs (witness + shifted witness at beta and at gamma, merged below) run as one batch.
   // --- at beta: labels g_1, outer_sumcheck, t, z_b  -> challenges xi^0 (g_1), xi^1 (g_1 shifted), xi^2, xi^3, xi^4
   if (!sliced_open) {
-  MH_TRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(2)},
+  PTRY(lincomb(c, S[0], mask_len, {{pk.g1.fr(), g1_len, HFr::one()}, {pk.outer.fr(), mask_len, xi_pow(2)},
                                      {pk.t.fr(), H, xi_pow(3)}, {pk.zb.fr(), za_len, xi_pow(4)}}));
-  MH_TRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));                         // witness of the combined polynomial
-  MH_TRY(div_linear(c, S[3], pk.g1.fr(), g1_len, beta, S[2]));                     // degree-bounded g_1: shifted witness
-  MH_TRY(lincomb(c, S[4], g1_len - 1, {{S[3], g1_len - 1, xi_pow(1)}}));
+  PTRY(div_linear(c, S[1], S[0], mask_len, beta, S[2]));                         // witness of the combined polynomial
+  PTRY(div_linear(c, S[3], pk.g1.fr(), g1_len, beta, S[2]));                     // degree-bounded g_1: shifted witness
+  PTRY(lincomb(c, S[4], g1_len - 1, {{S[3], g1_len - 1, xi_pow(1)}}));
   // --- at gamma: labels g_2, inner_sumcheck -> challenges xi^0 (g_2), xi^1 (g_2 shifted), xi^2
   // When shifted_powers(K - 2) starts at SRS index 1 (max_degree = K - 1, the usual case) the witness plus the shifted
   // witness moved up by one coefficient is the quotient of ONE polynomial: with C = g_2 + xi^2 inner,
   //   (C - C(gamma)) / (X - gamma) + X xi (g_2 - g_2(gamma)) / (X - gamma) = quotient(C + xi X g_2) - xi g_2(gamma),
   // so a single division serves both (the general offset keeps two divisions and adds the vectors).
-  MH_TRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(2)}}));
+  PTRY(lincomb(c, S[0], K, {{pk.g2.fr(), g2_len, HFr::one()}, {pk.inner.fr(), K, xi_pow(2)}}));
   if (fuse_g) {
     { ProfScope ps(c, PF_GLUE); KLAUNCH(poly::axpy_shifted_kernel, g2_len, S[0], (const Fr*)pk.g2.fr(), arg(xi_pow(1)), (u64)1, (u64)g2_len); }
-    MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
-    hipLaunchKernelGGL(poly::add_const_kernel, dim3(1), dim3(64), 0, c.stream, S[5], arg((xi_pow(1) * g2_gamma).neg()));
+    PTRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
+    if (g_job.poison == MH_OK) hipLaunchKernelGGL(poly::add_const_kernel, dim3(1), dim3(64), 0, c.stream, S[5], arg((xi_pow(1) * g2_gamma).neg()));
   } else {
-    MH_TRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
-    MH_TRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
-    MH_TRY(lincomb(c, S[6], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
+    PTRY(div_linear(c, S[5], S[0], K, gamma, S[2]));
+    PTRY(div_linear(c, S[3], pk.g2.fr(), g2_len, gamma, S[2]));
+    PTRY(lincomb(c, S[6], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
   }
   }
   // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b); its witness and the shifted
@@ -1868,8 +1935,8 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   // (an SRS much larger than this index needs puts the shifted range beyond the scratch vectors: then the two stay apart)
   const bool merge_b = mb_len <= pk.S[1].bytes / 32, merge_g = fuse_g || mg_len <= pk.S[5].bytes / 32;
   if (!sliced_open) {
-  if (merge_b) MH_TRY(zero_tail(c, S[1], wb_len, mb_len));
-  if (merge_g && !fuse_g) MH_TRY(zero_tail(c, S[5], wg_len, mg_len));
+  if (merge_b) PTRY(zero_tail(c, S[1], wb_len, mb_len));
+  if (merge_g && !fuse_g) PTRY(zero_tail(c, S[5], wg_len, mg_len));
   { ProfScope ps(c, PF_GLUE);
     if (merge_b) KLAUNCH(poly::add_shifted_kernel, swb_len, S[1], (const Fr*)S[4], (u64)off_b, (u64)swb_len);
     if (merge_g && !fuse_g) KLAUNCH(poly::add_shifted_kernel, swg_len, S[5], (const Fr*)S[6], (u64)off_g, (u64)swg_len); }
@@ -1880,7 +1947,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     if (!merge_b) jobs.push_back({srs_pts + off_b * PT_B, S[4], swb_len});
     if (!merge_g) jobs.push_back({srs_pts + off_g * PT_B, S[6], swg_len});
     std::vector<HG1> res;
-    MH_TRY(sharded_msm_batch(c, jobs, res));
+    CTRY(sharded_msm_batch(c, jobs, res));
     om = {res[0], res[1]};
     size_t nx = 2;
     if (!merge_b) om[0] = om[0].add(res[nx++]);
@@ -1919,6 +1986,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
                    {"h_1", {pk.h1.fr(), h1_len}}, {"g_2", {pk.g2.fr(), g2_len}}, {"h_2", {pk.h2.fr(), h2_len}},
                    {"row", {pk.p_row.fr(), K}}, {"col", {pk.p_col.fr(), K}}, {"a_val", {pk.p_a_val.fr(), K}},
                    {"b_val", {pk.p_b_val.fr(), K}}, {"c_val", {pk.p_c_val.fr(), K}}, {"row_col", {pk.p_row_col.fr(), K}}};
+  if (g_job.poison != MH_OK) return job_error();   // (unreachable after a completed last all-gather; kept as the last line of defence)
   if (zk.bad) return fail(MH_EINVAL, "mh_marlin_prove_draws: too few zk draws, or a draw that is not a reduced field element");
   // ---------------- Proof (lib.rs:305-310), flat ToBytes layout ------------------------------------------------
   std::vector<uint8_t> out;
@@ -1934,5 +2002,10 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   memcpy(proof_out, out.data(), out.size());
   return MH_OK;
 }
+#undef KLAUNCH
+#define KLAUNCH(kern, n, ...)                                                                          \
+  do {                                                                                                 \
+    hipLaunchKernelGGL(kern, dim3(poly::grid_for(n)), dim3(poly::TPB), 0, c.stream, __VA_ARGS__);      \
+  } while (0)
 
 }  // extern "C"

@@ -132,6 +132,7 @@ inline int init(Context& c, int rank, int world, const uint8_t* id128) {
   MH_HIP(hipSetDevice(c.device));
   MH_RCCL(s.api.CommInitRank(&s.comm, world, id, rank));
   s.rank = rank; s.world = world;
+  s.d_send.hookable = s.d_recv.hookable = false;          // (mh_debug_fail_scratch never strikes the transport's own staging)
   s.n_allgather_host = s.n_alltoall = s.n_allgather_dev = s.bytes_moved = 0;
   return MH_OK;
 }

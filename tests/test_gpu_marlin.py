@@ -555,7 +555,7 @@ def test_bench_gpus_2_runs_two_sharded_ranks(gpu):
     env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal", "--steps", "1", "--warmup", "1",
                           "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -568,6 +568,13 @@ def test_bench_gpus_2_runs_two_sharded_ranks(gpu):
     assert one.returncode == 0, one.stderr[-3000:]
     rec1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert rec1["proof"]["verified"] is True and rec1["proof"]["sha256_32"] == rec["proof"]["sha256_32"]
+    assert rec["rehearsal"] is True and rec["distinct_devices"] == 1
+    # without --rehearsal two ranks on ONE device are refused a scaling value: the line still explains itself
+    bare = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log-constraints", "12",
+                           "--no-cpu-baseline", "--no-verify"], env=env, capture_output=True, text=True, timeout=600)
+    assert bare.returncode == 0, bare.stderr[-3000:]
+    recb = json.loads([l for l in bare.stdout.splitlines() if l.startswith("{")][-1])
+    assert recb["value"] is None and recb["rehearsal"] is False and "not an N-GPU measurement" in recb["note"]
 
 
 @pytest.mark.skipif(F.CURVE != "bls12_381", reason="the golden proofs are BLS12-381 + MarlinKZG10")
@@ -618,7 +625,7 @@ def test_bench_gpus_4_runs_the_sliced_rounds(gpu):
     env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearsal", "--steps", "1", "--warmup", "1",
                           "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

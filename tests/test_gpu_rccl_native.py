@@ -208,7 +208,7 @@ def test_bench_native_transport_with_n_ranks(gpu, world, log_n):
     env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1", MH_RCCL_LIB=MOCK)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--transport", "native",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rehearsal", "--steps", "2", "--warmup", "1", "--transport", "native",
                           "--log-constraints", str(log_n), "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -233,10 +233,98 @@ def test_bench_falls_back_to_the_callbacks_when_one_rank_fails_the_native_self_t
     env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1", MH_RCCL_LIB=MOCK, MH_MOCK_RCCL_CORRUPT_RANK="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--transport", "native",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearsal", "--steps", "1", "--warmup", "1", "--transport", "native",
                           "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "native RCCL transport unavailable" in out.stderr
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["transport"]["kind"] == "callback-torch.distributed-gloo" and rec["transport"]["native_rccl"] is None, rec["transport"]
     assert rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True and "slices" in rec["config"]["parallelism"]
+
+
+FAIL_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+import ctypes as C
+import torch.distributed as dist
+import marlin_amd as M
+from marlin_amd import marlin as GM, dist as MD, _lib
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+M.init(0)
+lib = _lib.load()
+n = 1 << %(log_n)d
+srs = GM.universal_setup(n, n, 3 * n, %(tau)d, %(gamma)d)
+nc, ni, mats, inst, wit = GM.dummy_circuit(%(a)d, %(b)d, 10, n)
+pk = GM.index(srs, nc, ni, mats)
+assert MD.enable_native_rccl(dist, sliced=bool(%(sliced)d))
+seed = bytes(range(32))
+first = GM.prove(pk, inst, wit, seed)                     # warm: every buffer has its size now
+c0, c1 = C.c_uint64(), C.c_uint64()
+_lib.check(lib.mh_debug_fail_scratch(0, C.byref(c0)), "hook")
+assert GM.prove(pk, inst, wit, seed) == first
+_lib.check(lib.mh_debug_fail_scratch(0, C.byref(c1)), "hook")
+per_proof = c1.value - c0.value                            # scratch requests of one proof on this rank
+assert per_proof > 20, per_proof
+log = []
+for frac in %(fracs)r:
+    dist.barrier()
+    if rank == %(victim)d:
+        _lib.check(lib.mh_debug_fail_scratch(int(per_proof * frac) + 1, None), "hook")
+    t0 = time.time()
+    try:
+        GM.prove(pk, inst, wit, seed)
+        outcome = "ok"
+    except _lib.MarlinHipError as e:
+        outcome = "failed: " + str(e)[:160].replace("\n", " ")
+    dt = time.time() - t0
+    _lib.check(lib.mh_debug_fail_scratch(0, None), "hook")
+    again = GM.prove(pk, inst, wit, seed) == first         # the transport is still in step: the next proof is the right proof
+    log.append("%%.2f %%.3f %%s %%s" %% (frac, dt, again, outcome))
+open(os.path.join(%(out)r, "fail%%d.txt" %% rank), "w").write("\n".join(log))
+open(os.path.join(%(out)r, "first%%d.bin" %% rank), "wb").write(first)
+dist.barrier(); MD.disable_sharded_prove(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,sliced,victim", [(4, 1, 2), (2, 0, 1)])
+def test_a_rank_that_fails_mid_prove_fails_the_job_on_every_rank(gpu, tmp_path, world, sliced, victim):
+    """VERDICT r04 item 4: a rank that fails locally inside a sharded proof must fail the JOB, not hang it.  One rank's request for
+    device scratch is forced to fail (mh_debug_fail_scratch) a quarter, half and most of the way through a proof -- inside the sliced
+    rounds with their all-to-alls and round gathers at 4 ranks, inside the replicated rounds at 2: the poisoned rank keeps entering
+    the collectives up to the next all-gather of partial points, whose error word makes EVERY rank return non-zero from the same
+    commit round, within seconds; and because all ranks left the proof at the same collective, the very next proof is again the
+    one-GPU proof on every rank."""
+    from marlin_amd import marlin as GM
+    import json
+    GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "marlin_proofs.json")))
+    TAU, GAMMA = int(GOLD["tau"], 16), int(GOLD["gamma"], 16)
+    assert os.path.exists(MOCK)
+    a, b, log_n = 0x1234567, 0x7654321, 12
+    n = 1 << log_n
+    srs = GM.universal_setup(n, n, 3 * n, TAU, GAMMA)
+    nc, ni, mats, inst, wit = GM.dummy_circuit(a, b, 10, n)
+    pk = GM.index(srs, nc, ni, mats)
+    want = GM.prove(pk, inst, wit, bytes(range(32)))
+    fracs = (0.22, 0.5, 0.8)
+    script = tmp_path / "fail_worker.py"
+    script.write_text(FAIL_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "sliced": sliced,
+                                     "victim": victim, "fracs": fracs})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29871 + world), WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK)
+    if sliced:
+        env["MH_SLICED"] = "2"
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-800:] + se[-2500:]
+    for r in range(world):
+        assert open(tmp_path / ("first%d.bin" % r), "rb").read() == want
+        lines = open(tmp_path / ("fail%d.txt" % r)).read().splitlines()
+        assert len(lines) == len(fracs)
+        for line in lines:
+            frac, dt, again, outcome = line.split(" ", 3)
+            assert outcome.startswith("failed"), (r, line)          # non-zero on EVERY rank, the victim included
+            assert float(dt) < 10.0, (r, line)
+            assert again == "True", (r, line)
+        if r == victim:
+            assert all("forced by mh_debug_fail_scratch" in l for l in lines), lines     # the victim reports its own cause

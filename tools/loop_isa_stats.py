@@ -24,7 +24,8 @@ with tempfile.TemporaryDirectory() as td:
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only"] + (["-DMH_CURVE_BN254"] if curve == "bn254" else []) + [src, "-o", out],
                    check=True, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-for kern in ("accum30_kernel", "accum_kernel"):
+# rsum_kernel: the bucket reduction's row / column sums (msm_fb.cuh); its loop body is one GENERAL addition (XYZZ += XYZZ)
+for kern in ("accum30_kernel", "accum_kernel", "rsum_kernel"):
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN\d+msm(fb)?\d+%s\w*:" % kern, l)]
     if len(starts) > 1:
         print("%s: %d instantiations, the first is shown" % (kern, len(starts)))
@@ -48,13 +49,13 @@ for kern in ("accum30_kernel", "accum_kernel"):
     ins = [x for _, i in hot for x in i]
     c = collections.Counter(ins)
     valu = sum(v for k, v in c.items() if k.startswith("v_"))
-    print("%s: basic blocks %s = loop body of one bucket addition" % (kern, " + ".join("%s (%d)" % (n, len(i)) for n, i in hot)))
+    print("%s: basic blocks %s = loop body of one %s addition" % (kern, " + ".join("%s (%d)" % (n, len(i)) for n, i in hot), "general (XYZZ += XYZZ)" if kern == "rsum_kernel" else "bucket"))
     print("  instructions %d, VALU %d, v_mad_u64_u32 %d" % (len(ins), valu, c["v_mad_u64_u32"]))
     for k, v in c.most_common(14):
         print("    %-22s %5d" % (k, v))
     half = sum(v for k, v in c.items() if k.startswith("v_") and k.split("_e")[0] in HALF)
     mad = c["v_mad_u64_u32"]
-    mixes["fixed-base" if kern == "accum30_kernel" else "variable-base"] = {"mad_u64": mad, "half_rate_other": half, "full_rate": valu - mad - half}
+    mixes[{"accum30_kernel": "fixed-base", "accum_kernel": "variable-base", "rsum_kernel": "reduce"}[kern]] = {"mad_u64": mad, "half_rate_other": half, "full_rate": valu - mad - half}
     print("  classes: v_mad_u64_u32 %d, other half-rate %d, full-rate %d" % (mad, half, valu - mad - half))
 if json_out:
     cur = json.load(open(json_out)) if os.path.exists(json_out) else {}
