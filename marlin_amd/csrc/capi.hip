@@ -441,7 +441,7 @@ struct FbRun {
   msmfb::RsPlan rs; std::vector<u64> coef;        // bucket reduction: matrix shape, chunking, planes; the host's coefficient of each plane
   std::vector<msmfb::FbWin> desc; std::vector<msmfb::FbBlk> blk; std::vector<u32> ptot;
   bool skewed = false;
-  u32 skew_limit = 0xffffffffu;
+  u32 skew_limit = 0xffffffffu, skew_floor = 4096;   // a batch is skewed when its largest bucket exceeds max(skew_floor, 32 x the average)
   FbRun(Context& c_, const BaseSet& bs_, Context::FbWs& ws_) : c(c_), bs(bs_), ws(ws_) {}
 
   int prepare(int is_mont_, const int* shard) {
@@ -643,7 +643,7 @@ struct FbRun {
     // The skew decision (largest bucket > max(4096, 32 x average)) is taken on the device by the accumulate kernel and read
     // by the host together with the results (finish): no host round trip between the sort and the accumulation.
     const u64 avg = ent / WB + 1;
-    skew_limit = (u32)std::min<u64>(std::max<u64>(4096, 32 * avg), 0xffffffffull);
+    skew_limit = (u32)std::min<u64>(std::max<u64>(skew_floor, 32 * avg), 0xffffffffull);
     // (a strided slice has no variable-base fallback -- its bases are not a contiguous range --: msm_batch_strided_device turns a
     // skewed batch into an error instead of letting one thread walk a list of millions)
     return MH_OK;
@@ -764,11 +764,13 @@ struct FbRun {
 // measured slower -- 80.8 vs 78.1 ms per proof, profiles/r03a_*: the accumulate kernel fills every SIMD's registers, so a
 // second stream only ever ran in its tail -- and is gone; `git show 3c10b42:marlin_amd/csrc/capi.hip` has it.)
 static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* offs, const void* const* d_scalars, const size_t* ns,
-                           int is_mont, HG1* out, bool& skewed, const int* shard, bool& partial, const size_t* strides = nullptr) {
+                           int is_mont, HG1* out, bool& skewed, const int* shard, bool& partial, const size_t* strides = nullptr,
+                           u32 skew_floor = 4096) {
   skewed = false;
   hipStream_t s0 = c.stream;
   ProfScope wall(c, PF_MSM, s0);
   FbRun A(c, bs, c.fbws);
+  A.skew_floor = skew_floor;
   for (int k = 0; k < nj; k++) {
     A.offs.push_back(offs[k]); A.sc.push_back(d_scalars[k]); A.ns.push_back(ns[k]); A.strides.push_back(strides ? strides[k] : 1);
   }
@@ -1028,8 +1030,13 @@ int msm_batch_strided_device(Context& c, const BaseSet& bs, int njobs, const siz
     std::vector<HG1> res(nj);
     bool skewed = false, part = false;
     MH_TRY(msm_fb_pipeline(c, bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, nullptr, part, st.data()));
+    // A strided slice has no variable-base fallback (its bases are not a contiguous range).  A skewed batch -- heavily repeated
+    // digits, e.g. a round polynomial with one dominant coefficient value -- is run again as it is with the limit at 2^22 entries
+    // per bucket: one thread then walks a long list (seconds for millions of entries), but a valid sliced proof completes on
+    // every rank, as the replicated and the one-GPU prover do on the same instance.  Beyond that it is refused.
+    if (skewed) MH_TRY(msm_fb_pipeline(c, bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, nullptr, part, st.data(), 1u << 22));
     if (skewed)
-      return fail(MH_EINVAL, "strided MSM: one bucket holds more than max(4096, 32 x the average) entries (heavily repeated digits); gather the "
+      return fail(MH_EINVAL, "strided MSM: one bucket holds more than 2^22 entries (almost all digits equal); gather the "
                              "slice into a contiguous vector and use mh_msm_batch_dev, whose variable-base path handles skewed inputs");
     c.n_fb_groups++;
     for (int k = 0; k < nj; k++) {

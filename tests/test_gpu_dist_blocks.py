@@ -98,11 +98,12 @@ def test_distributed_ntt_and_sliced_msm(gpu, tmp_path, world, logs):
         assert p.returncode == 0 and "rank %d ok" % r in so, "rank %d:\n%s\n%s" % (r, so[-1500:], se[-3000:])
 
 
-def test_sliced_msm_refuses_skewed_digits(gpu):
-    """a strided selection has no variable-base fallback (its bases are not a contiguous range).  A slice whose
-    digits repeat so heavily that one bucket holds most of the entries is refused with MH_EINVAL -- the accumulate kernel
-    returns at once on the device flag -- instead of one thread walking a list of tens of thousands of entries; the same
-    vector through mh_msm_batch_dev takes the variable-base path and gives the result."""
+def test_sliced_msm_completes_on_skewed_digits(gpu):
+    """a strided selection has no variable-base fallback (its bases are not a contiguous range).  Round 4 refused a
+    slice whose digits repeat so heavily that one bucket holds most of the entries -- which made a valid sliced multi-GPU proof
+    abort where the replicated prover succeeds.  Now the batch is run again as it is with the limit at 2^22 entries per bucket
+    (one thread walks the long list: ~0.5 s for the 65536 entries here) and gives the result of the same MSM over the gathered
+    bases, which takes the variable-base path."""
     import numpy as np
     import marlin_amd as M
     from marlin_amd import dist as MD, _lib
@@ -113,13 +114,15 @@ def test_sliced_msm_refuses_skewed_digits(gpu):
     hot = np.zeros((n, 4), dtype=np.uint64)
     hot[:] = np.array([0x1234, 0, 0, 0], dtype=np.uint64)           # Montgomery words with ONE non-zero digit: one bucket gets everything
     d = M.DeviceBuffer.from_numpy(hot)
-    with pytest.raises(_lib.MarlinHipError, match="strided MSM: one bucket"):
-        MD.msm_batch_sliced_dev(B, [(0, d, n)], 2, combine=False)
+    got = MD.msm_batch_sliced_dev(B, [(0, d, n)], 2, combine=False)
+    B2 = M.Bases(np.ascontiguousarray(B.download()[0:2 * n:2]))     # the slice's bases as a contiguous set, no table
+    ref = M.msm_batch_dev([(B2, 0, d, n)])
+    assert tuple(M.g1_to_affine(got[0])[0]) == tuple(M.g1_to_affine(ref[0])[0])
     fb0, vb0 = M.msm_path_counts()
     M.msm_batch_dev([(B, 0, d, n)])
     fb1, vb1 = M.msm_path_counts()
     assert vb1 == vb0 + 1                                             # the contiguous call left the fixed-base path and finished
-    # a well-spread slice still works after the refusal
+    # a well-spread slice still works afterwards
     rng = np.random.default_rng(3)
     ok = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
     d2 = M.DeviceBuffer.from_numpy(ok)

@@ -310,3 +310,35 @@ def test_fq30_device_selftest(gpu):
         assert bad.value == 0
 
 
+
+
+def test_fixed_base_msm_at_2p22_matches_the_c_restatement(gpu):
+    """the fixed-base MSM kernels at the size of the largest commitment of a 2^20-constraint proof -- 2^22
+    pseudo-random points ([tau^i]G, generated on the device and downloaded), window table at c = 20, one bucket set of 2^19, the
+    row / column + bit-plane reduction at full size -- against the C restatement's Pippenger (oracle/c/ref_hotpath.c: unsigned
+    windows, one bucket set per window: another algorithm, the same group element) on the same points and scalars, and against the
+    closed form [p(tau)]G.  `VariableBaseMSM::multi_scalar_mul` as reached from /root/reference src/lib.rs:172,193,213,292."""
+    import os
+    from oracle import cref, poly as OP, curve as EC
+    n = 1 << 22
+    tau = 0x1f3a9c5d7e2b4a6f8091a2b3c4d5e6f7
+    B = gpu.Bases.srs_powers(fr_to_np([tau])[0], n)
+    B.precompute()
+    c, W, _ = B.table_info()
+    assert (c, W) == (20, 13)
+    rng = np.random.default_rng(22)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)        # Montgomery words of pseudo-random field elements
+    sc[:, 3] &= np.uint64((1 << 61) - 1)
+    sc[:5] = 0                                                          # a few zeros and a repeated scalar among them
+    sc[5:9] = sc[9]
+    fb0, _ = gpu.msm_path_counts()
+    got = jac_np_to_affine(gpu.msm(B, sc))
+    assert gpu.msm_path_counts()[0] > fb0                               # the fixed-base path answered
+    try:
+        th = max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        th = 4
+    assert got == jac_np_to_affine(cref.msm(B.download(), sc, threads=th))
+    # and the closed form: sum_i s_i tau^i by Horner over the canonical scalars (numpy object arithmetic would take minutes:
+    # the C restatement's poly_eval on the same Montgomery words)
+    assert got == EC.scalar_mul(EC.G1_GEN, cref.poly_eval(sc, tau))

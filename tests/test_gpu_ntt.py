@@ -138,3 +138,40 @@ def test_ntt_len_equals_the_padded_transform(gpu, log_n, in_len):
         _lib.check(lib.mh_ntt_len(_lib.CURVE_ID, buf.ctypes.data, in_len, log_n, inverse), "mh_ntt_len")
         assert np.array_equal(buf, want)
     assert lib.mh_ntt_len(_lib.CURVE_ID, x.ctypes.data, n + 1, log_n, 0) != 0          # in_len beyond the domain is refused
+
+
+def _host_threads():
+    import os
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+@pytest.mark.parametrize("log_n", [20, 23])
+def test_ntt_large_matches_the_c_restatement(gpu, log_n):
+    """the transform kernels themselves, at the sizes of a 2^20-constraint proof -- 2^20 (|H|: one-stage rounds,
+    Shoup twiddle products) and 2^23 (2|K|: two-stage rounds, Montgomery products) -- forward and inverse, element for element
+    against the C restatement of the radix-2 transform (oracle/c/ref_hotpath.c, itself pinned to the Python oracle and the naive DFT
+    by tests/test_oracle_c.py).  What `GeneralEvaluationDomain::{fft, ifft}` return at /root/reference src/ahp/prover.rs:532-535,685.
+    Until round 5 these sizes were pinned only through whole proofs (a mismatch said "proof differs", not "this kernel differs")."""
+    from oracle import cref
+    n = 1 << log_n
+    rng = np.random.default_rng(1000 + log_n)
+    x = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    x[:, 3] &= np.uint64((1 << 61) - 1)
+    th = _host_threads()
+    assert np.array_equal(gpu.ntt(x), cref.ntt(x, threads=th))
+    assert np.array_equal(gpu.intt(x), cref.ntt(x, inverse=True, threads=th))
+
+
+@pytest.mark.skipif(__import__("os").environ.get("MH_NTT") is not None, reason="already inside the re-run")
+def test_ntt_large_parity_also_holds_for_the_32_bit_limb_kernel():
+    """The same direct comparison at 2^20 with MH_NTT=32, the 32-bit-limb cross-check kernel (the switch is read once per process,
+    hence the subprocess)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "tests/test_gpu_ntt.py",
+                        "-k", "large_matches_the_c_restatement and 20"], cwd=root, env=dict(os.environ, MH_NTT="32"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
