@@ -75,7 +75,19 @@ fb0, vb0 = M.msm_path_counts()
 got = MD.msm_batch_sliced_dev(B, [(rank, e1, len(l1)), (37 + rank, e2, len(l2)), (rank, e2, len(l2))], world)
 fb1, vb1 = M.msm_path_counts()
 aff = lambda a: [tuple(M.g1_to_affine(r)[0]) for r in a]
-assert aff(got) == aff(whole), "rank %%d: sliced MSM differs" %% rank
+if aff(got) != aff(whole):
+    # say WHAT differs before failing: which jobs, whether this rank's own partial points are right (against the variable-base path
+    # on the gathered bases of its slice) and whether the unsliced result reproduces
+    allb = B.download()
+    mine = MD.msm_batch_sliced_dev(B, [(rank, e1, len(l1)), (37 + rank, e2, len(l2)), (rank, e2, len(l2))], world, combine=False)
+    refs = []
+    for first, l in ((rank, l1), (37 + rank, l2), (rank, l2)):
+        Bg = M.Bases(np.ascontiguousarray(allb[first:first + world * len(l):world][:len(l)]))
+        refs.append(M.msm(Bg, l))
+    again = M.msm_batch_dev([(B, 0, d1, n), (B, 37, d2, n - 5), (B, 0, d2, n - 5)])
+    raise AssertionError("rank %%d: sliced MSM differs in jobs %%s; own partials (recomputed) right: %%s; unsliced result reproduces: %%s; combined result reproduces: %%s"
+                         %% (rank, [j for j in range(3) if aff(got)[j] != aff(whole)[j]], aff(mine) == aff(refs), aff(again) == aff(whole),
+                            aff(MD.msm_batch_sliced_dev(B, [(rank, e1, len(l1)), (37 + rank, e2, len(l2)), (rank, e2, len(l2))], world)) == aff(got)))
 assert vb1 == vb0 and fb1 > fb0
 part = MD.msm_batch_sliced_dev(B, [(rank, e1, len(l1))], world, combine=False)
 parts = [None] * world

@@ -9,7 +9,7 @@ import threading
 import numpy as np
 import pytest
 
-from tests.util import fr_to_np, jac_np_to_affine
+from tests.util import fr_to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -61,14 +61,20 @@ def test_four_threads_on_one_context_get_the_serial_results(gpu):
                  lambda s1=s1, t=t: msm(s1, 100 * t),
                  lambda s2=s2, s3=s3, t=t: msm_batch([s2, s3, s2], [t, n, 7 + t])]
         jobs.append(calls)
-    want = [[np.array(f()) for f in calls] for calls in jobs]          # serial reference
+    # MSM results are compared as affine points: the Jacobian coordinates of one and the same sum depend on the order in which the
+    # sort's LDS atomics happened to rank the entries of a bucket
+    def canon(k, r):
+        if k == 0:
+            return np.array(r)
+        return np.stack([gpu.g1_to_affine(row)[0] for row in np.atleast_2d(r)])
+    want = [[canon(k, f()) for k, f in enumerate(calls)] for calls in jobs]          # serial reference
     errors = []
 
     def worker(t):
         try:
             for rnd in range(6):
                 for k, f in enumerate(jobs[t]):
-                    got = np.array(f())
+                    got = canon(k, f())
                     if not np.array_equal(got, want[t][k]):
                         errors.append((t, rnd, k))
         except Exception as e:                                            # noqa: BLE001
@@ -103,7 +109,7 @@ def test_msm_and_ntt_from_other_threads_while_a_proof_is_being_made(gpu):
     B.precompute()
     sc = _rand_fr_np(rng, 1 << 13)
     x = _rand_fr_np(rng, 1 << 16)
-    want_msm, want_ntt = gpu.msm(B, sc), gpu.ntt(x)
+    want_msm, want_ntt = gpu.g1_to_affine(gpu.msm(B, sc))[0], gpu.ntt(x)
     errors, stop = [], threading.Event()
 
     def prover():
@@ -122,7 +128,7 @@ def test_msm_and_ntt_from_other_threads_while_a_proof_is_being_made(gpu):
             count = 0
             while not stop.is_set() or count < 3:
                 if which == 0:
-                    ok = np.array_equal(gpu.msm(B, sc), want_msm)
+                    ok = np.array_equal(gpu.g1_to_affine(gpu.msm(B, sc))[0], want_msm)
                 else:
                     ok = np.array_equal(gpu.ntt(x), want_ntt)
                 count += 1
@@ -139,4 +145,3 @@ def test_msm_and_ntt_from_other_threads_while_a_proof_is_being_made(gpu):
         th.join(timeout=180)
     assert not any(th.is_alive() for th in threads), "a thread is stuck inside the library"
     assert errors == []
-    assert jac_np_to_affine(want_msm) is not None
