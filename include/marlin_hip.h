@@ -367,6 +367,10 @@ int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out);
  * makes EVERY rank return non-zero from the same commit round -- the job fails, nobody hangs, the next proof can run.  Replaces
  * nothing in the reference (it has no FFI and no device memory). */
 int mh_debug_fail_scratch(int nth, uint64_t* calls_out);
+/* Test hook: on != 0 fills every device allocation the library makes from now on (scratch buffers, prover-key buffers) with 0xA5
+ * bytes, so that a kernel reading memory nothing has written yet gets garbage for sure instead of whatever the heap held (usually
+ * zeros -- the identity, the zero polynomial -- on a fresh process): tests/test_gpu_poisoned_allocations.py. */
+int mh_debug_poison_scratch(int on);
 
 #ifdef __cplusplus
 }

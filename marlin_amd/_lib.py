@@ -46,6 +46,7 @@ SYMBOLS = {
     "mh_msm_path_counts": (C.c_int, [_u64p, _u64p]),
     "mh_selftest_fq30": (C.c_int, [C.c_uint64, C.c_uint64, _u64p]),
     "mh_debug_fail_scratch": (C.c_int, [C.c_int, _u64p]),
+    "mh_debug_poison_scratch": (C.c_int, [C.c_int]),
     "mh_bases_table_info": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _u64p]),
     "mh_msm": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "mh_msm_dev": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),

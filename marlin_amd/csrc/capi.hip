@@ -24,6 +24,7 @@ using hostff::FQ_L; using hostff::FQ_B; using hostff::PT_B; using hostff::AFF_L;
 namespace mh {
 thread_local std::string g_err;
 int g_debug_fail_scratch = 0;
+int g_debug_poison_scratch = 0;
 uint64_t g_debug_scratch_calls = 0;
 Context& ctx() {
   static Context c;
@@ -819,6 +820,7 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   void* tmp = nullptr;                                    // two ping-pong levels in standard form + the un-normalised points of one level
   e = hipMalloc(&tmp, 2 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd));
   if (e != hipSuccess) { (void)hipFree(tab); return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the doubling scratch failed"); }
+  if (g_debug_poison_scratch) { (void)hipMemset(tab, 0xA5, (size_t)W * bs.n * pt30); (void)hipMemset(tmp, 0xA5, 2 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd)); }
   msmfb::G1XyzzStd* xyzz_scratch = (msmfb::G1XyzzStd*)((char*)tmp + 2 * bs.n * PT_B);
   hipStream_t s = c.stream;
   const unsigned grid = (unsigned)(((bs.n + msmfb::TAB_BATCH - 1) / msmfb::TAB_BATCH + 127) / 128);
@@ -1299,6 +1301,7 @@ int mh_alloc(size_t bytes, void** dptr_out) {
   *dptr_out = nullptr;
   if (bytes == 0) return MH_OK;
   MH_HIP(hipMalloc(dptr_out, bytes));
+  if (g_debug_poison_scratch) MH_HIP(hipMemset(*dptr_out, 0xA5, bytes));
   return MH_OK;
 }
 int mh_free(void* dptr) {
@@ -1743,6 +1746,13 @@ int mh_debug_fail_scratch(int nth, uint64_t* calls_out) {
   if (nth < 0) return fail(MH_EINVAL, "mh_debug_fail_scratch: nth must be >= 0");
   g_debug_fail_scratch = nth;
   if (calls_out) *calls_out = g_debug_scratch_calls;
+  return MH_OK;
+}
+// Test hook: on != 0 fills every device allocation made from now on (scratch buffers, prover-key buffers) with 0xA5 bytes
+int mh_debug_poison_scratch(int on) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  g_debug_poison_scratch = on;
   return MH_OK;
 }
 int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out) {

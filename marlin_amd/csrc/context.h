@@ -39,6 +39,8 @@ inline int fail(int code, const std::string& msg) {
 
 // Test hook (mh_debug_fail_scratch): the n-th Scratch::ensure call from now on fails as if the device were out of memory, whether
 // or not it would have had to allocate -- how tests/test_gpu_rccl_native.py makes ONE rank of a sharded proof fail mid-prove.
+extern int g_debug_poison_scratch;        // != 0: every fresh device allocation is filled with 0xA5 bytes (mh_debug_poison_scratch): a read of
+                                          // memory nothing has written yet then returns garbage for sure instead of whatever the heap held
 extern int g_debug_fail_scratch;          // > 0: calls left until the forced failure
 extern uint64_t g_debug_scratch_calls;    // Scratch::ensure calls so far (the test measures a proof with it)
 
@@ -59,6 +61,7 @@ struct Scratch {
       if (e != hipSuccess) { ptr = nullptr; return fail(MH_ENOMEM, "hipMalloc scratch failed"); }
     }
     cap = want;
+    if (g_debug_poison_scratch) (void)hipMemset(ptr, 0xA5, want);
     return MH_OK;
   }
   void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }

@@ -166,6 +166,7 @@ extern "C" {
     pub fn mh_prof_get(family: c_int, total_ms_out: *mut f64, launches_out: *mut u64) -> c_int;
     pub fn mh_selftest_fq30(n: u64, seed: u64, mismatches_out: *mut u64) -> c_int;
     pub fn mh_debug_fail_scratch(nth: c_int, calls_out: *mut u64) -> c_int;
+    pub fn mh_debug_poison_scratch(on: c_int) -> c_int;
 }
 
 /// The library's thread-local message for the last failure on this thread.

@@ -18,7 +18,7 @@ fn every_header_symbol_links() {
         mh_ntt_dist_dev as usize, mh_msm_batch_sliced_dev as usize,
         mh_marlin_get_poly as usize, mh_prof_enable as usize, mh_prof_reset as usize, mh_prof_get as usize,
         mh_selftest_fq30 as usize, mh_g2_bases_upload as usize, mh_g2_srs_powers as usize, mh_g2_bases_download as usize,
-        mh_g2_bases_free as usize, mh_g2_msm as usize, mh_debug_fail_scratch as usize,
+        mh_g2_bases_free as usize, mh_g2_msm as usize, mh_debug_fail_scratch as usize, mh_debug_poison_scratch as usize,
     ];
     assert!(addrs.iter().all(|a| *a != 0));
 }

@@ -17,4 +17,7 @@ def gpu():
     when the HIP library or the GPU is missing."""
     import marlin_amd
     marlin_amd.init(0)
+    if os.environ.get("MARLIN_TEST_POISON"):          # tests/test_gpu_poisoned_allocations.py: every allocation starts as 0xA5 garbage
+        from marlin_amd import _lib
+        _lib.check(_lib.load().mh_debug_poison_scratch(1), "mh_debug_poison_scratch")
     yield marlin_amd

@@ -25,6 +25,9 @@ from marlin_amd import dist as MD
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 M.init(0)                                            # every rank shares the box's one GPU
+if os.environ.get("MARLIN_TEST_POISON"):             # tests/test_gpu_poisoned_allocations.py
+    from marlin_amd import _lib as _L
+    _L.check(_L.load().mh_debug_poison_scratch(1), "mh_debug_poison_scratch")
 MD.enable_sharded_prove(dist)
 MD.enable_alltoall(dist)
 rng = np.random.default_rng(11)                      # the same global vectors on every rank
