@@ -820,7 +820,7 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   void* tmp = nullptr;                                    // two ping-pong levels in standard form + the un-normalised points of one level
   e = hipMalloc(&tmp, 2 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd));
   if (e != hipSuccess) { (void)hipFree(tab); return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the doubling scratch failed"); }
-  if (g_debug_poison_scratch) { (void)hipMemset(tab, 0xA5, (size_t)W * bs.n * pt30); (void)hipMemset(tmp, 0xA5, 2 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd)); }
+  if (g_debug_poison_scratch) { debug_poison(tab, (size_t)W * bs.n * pt30); debug_poison(tmp, 2 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd)); }
   msmfb::G1XyzzStd* xyzz_scratch = (msmfb::G1XyzzStd*)((char*)tmp + 2 * bs.n * PT_B);
   hipStream_t s = c.stream;
   const unsigned grid = (unsigned)(((bs.n + msmfb::TAB_BATCH - 1) / msmfb::TAB_BATCH + 127) / 128);
@@ -1301,7 +1301,7 @@ int mh_alloc(size_t bytes, void** dptr_out) {
   *dptr_out = nullptr;
   if (bytes == 0) return MH_OK;
   MH_HIP(hipMalloc(dptr_out, bytes));
-  if (g_debug_poison_scratch) MH_HIP(hipMemset(*dptr_out, 0xA5, bytes));
+  if (g_debug_poison_scratch) debug_poison(*dptr_out, bytes);
   return MH_OK;
 }
 int mh_free(void* dptr) {

@@ -44,6 +44,10 @@ extern int g_debug_poison_scratch;        // != 0: every fresh device allocation
 extern int g_debug_fail_scratch;          // > 0: calls left until the forced failure
 extern uint64_t g_debug_scratch_calls;    // Scratch::ensure calls so far (the test measures a proof with it)
 
+// (the fill runs on the null stream, which the library's non-blocking streams do not wait for: drain the device on both sides, or
+// the poison could land on top of what a kernel has already written there)
+inline void debug_poison(void* p, size_t bytes) { (void)hipDeviceSynchronize(); (void)hipMemset(p, 0xA5, bytes); (void)hipDeviceSynchronize(); }
+
 struct Scratch {
   void* ptr = nullptr;
   size_t cap = 0;
@@ -61,7 +65,7 @@ struct Scratch {
       if (e != hipSuccess) { ptr = nullptr; return fail(MH_ENOMEM, "hipMalloc scratch failed"); }
     }
     cap = want;
-    if (g_debug_poison_scratch) (void)hipMemset(ptr, 0xA5, want);
+    if (g_debug_poison_scratch) debug_poison(ptr, want);
     return MH_OK;
   }
   void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }

@@ -61,7 +61,7 @@ struct DBuf {
     if (b == 0) b = 32;
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) { p = nullptr; return fail(MH_ENOMEM, "hipMalloc failed in prover key allocation"); }
-    if (g_debug_poison_scratch) (void)hipMemset(p, 0xA5, b);
+    if (g_debug_poison_scratch) debug_poison(p, b);
     bytes = b;
     return MH_OK;
   }

@@ -6,6 +6,11 @@
 // side of the call at N = 2 / 4 / 8 -- buffer sizes, counts, staging, chunk order, the device all-gather of round polynomials,
 // bench.py's transport set-up and self-tests -- not RCCL (AMD's code; executed for real at world 1 by
 // tests/test_gpu_rccl_native.py).
+// MH_MOCK_RCCL_ASYNC=1 (round 5): the collectives are ENQUEUED like RCCL's -- asynchronous copies through the (then
+// page-locked) segment and the barriers as host functions in stream order; the call returns at once -- so that the library's
+// stream-ordered use of its exchange buffers (sl_send / sl_recv / ntt_dist_buf reused while a collective is in flight) is
+// exercised at N > 1.  -DMOCK_NO_ALLTOALL builds the variant WITHOUT ncclAllToAll (libmock_rccl_noa2a.so): rccl_native.h then
+// takes its grouped ncclSend / ncclRecv path.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
@@ -22,13 +27,28 @@ typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2,
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
 struct Header { std::atomic<uint32_t> arrived; std::atomic<uint32_t> generation; std::atomic<uint32_t> attached; uint32_t nranks; };
-struct ncclComm { int rank, nranks; size_t slot; char name[64]; Header* hdr; char* slots; size_t map_bytes; bool solo; void* filled[16]; size_t filled_bytes[16]; };
+struct ncclComm { int rank, nranks; size_t slot; char name[64]; Header* hdr; char* slots; size_t map_bytes; bool solo; void* filled[16]; size_t filled_bytes[16];
+                  bool async; };
 typedef ncclComm* ncclComm_t;
 
 // per rank; the tests move a few MB, a 2^20 rehearsal 34 MB, a 2^22 one with 4 ranks 134 MB: MH_MOCK_RCCL_SLOT_MB (the same on
 // every rank) raises it (the segment is sparse: only what is written is ever backed by memory)
 static size_t slot_bytes() { const char* e = getenv("MH_MOCK_RCCL_SLOT_MB"); const long mb = e ? atol(e) : 96; return (size_t)(mb > 0 ? mb : 96) << 20; }
 
+static bool async_mode() { const char* e = getenv("MH_MOCK_RCCL_ASYNC"); return e && atoi(e) == 1; }
+static void barrier(ncclComm* c);
+static void barrier_hostfn(void* p) { barrier((ncclComm*)p); }
+// one collective in stream order: own chunk(s) into the own slot, barrier, the peers' chunks out of their slots, barrier
+static ncclResult_t enqueue_exchange(ncclComm* c, hipStream_t s, const void* send, size_t send_bytes, void* recv, size_t count, bool alltoall) {
+  if (hipMemcpyAsync(c->slots + (size_t)c->rank * c->slot, send, send_bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ncclUnhandledCudaError;
+  if (hipLaunchHostFunc(s, barrier_hostfn, c) != hipSuccess) return ncclUnhandledCudaError;
+  for (int p = 0; p < c->nranks; p++) {
+    const char* src = c->slots + (size_t)p * c->slot + (alltoall ? (size_t)c->rank * count : 0);
+    if (hipMemcpyAsync((char*)recv + (size_t)p * count, src, count, hipMemcpyHostToDevice, s) != hipSuccess) return ncclUnhandledCudaError;
+  }
+  if (hipLaunchHostFunc(s, barrier_hostfn, c) != hipSuccess) return ncclUnhandledCudaError;
+  return ncclSuccess;
+}
 static void barrier(ncclComm* c) {
   Header* h = c->hdr;
   const uint32_t gen = h->generation.load(std::memory_order_acquire);
@@ -81,6 +101,8 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
   close(fd);
   if (p == MAP_FAILED) { delete c; return ncclSystemError; }
   c->hdr = (Header*)p; c->slots = (char*)p + 4096;
+  c->async = async_mode();
+  if (c->async && hipHostRegister(c->slots, (size_t)nranks * c->slot, hipHostRegisterDefault) != hipSuccess) { munmap(p, c->map_bytes); delete c; return ncclSystemError; }
   // a fresh segment is zero-filled: the counters start at 0 without an initialisation race
   c->hdr->attached.fetch_add(1, std::memory_order_acq_rel);
   while (c->hdr->attached.load(std::memory_order_acquire) < (uint32_t)nranks) usleep(100);     // ncclCommInitRank is collective
@@ -90,6 +112,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
   if (!c) return ncclSuccess;
   if (c->solo) { delete c; return ncclSuccess; }
+  if (c->async) { (void)hipDeviceSynchronize(); (void)hipHostUnregister(c->slots); }
   munmap((void*)c->hdr, c->map_bytes);
   if (c->rank == 0) shm_unlink(c->name);
   delete c;
@@ -110,6 +133,7 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     return hipMemcpyAsync((char*)recv + (size_t)c->rank * count, send, count, hipMemcpyDeviceToDevice, s) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
   }
   if (count > c->slot) return ncclInvalidArgument;
+  if (c->async && !getenv("MH_MOCK_RCCL_CORRUPT_RANK")) return enqueue_exchange(c, s, send, count, recv, count, false);
   if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slots + (size_t)c->rank * c->slot, send, count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
   barrier(c);
@@ -122,6 +146,7 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     if (atoi(e) == c->rank && hipMemset(recv, 0xA5, 1) != hipSuccess) return ncclUnhandledCudaError;
   return ncclSuccess;
 }
+#ifndef MOCK_NO_ALLTOALL
 ncclResult_t ncclAllToAll(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t c, hipStream_t s) {
   if (c->solo) {
     if (solo_fill(c, recv, count * c->nranks) != ncclSuccess) return ncclUnhandledCudaError;
@@ -129,6 +154,7 @@ ncclResult_t ncclAllToAll(const void* send, void* recv, size_t count, ncclDataTy
     return hipMemcpyAsync((char*)recv + off, (const char*)send + off, count, hipMemcpyDeviceToDevice, s) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
   }
   if (count * (size_t)c->nranks > c->slot) return ncclInvalidArgument;
+  if (c->async) return enqueue_exchange(c, s, send, count * c->nranks, recv, count, true);
   if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slots + (size_t)c->rank * c->slot, send, count * c->nranks, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
   barrier(c);
@@ -138,9 +164,50 @@ ncclResult_t ncclAllToAll(const void* send, void* recv, size_t count, ncclDataTy
   barrier(c);
   return ncclSuccess;
 }
-// resolved by rccl_native.h but never reached while ncclAllToAll exists
-ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclInternalError; }
-ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclInternalError; }
-ncclResult_t ncclGroupStart(void) { return ncclSuccess; }
-ncclResult_t ncclGroupEnd(void) { return ncclSuccess; }
+#endif
+// grouped point-to-point (what rccl_native.h issues when the library has no ncclAllToAll): the operations between ncclGroupStart
+// and ncclGroupEnd are collected and carried out together -- every send staged into the own slot at the peer's chunk position,
+// barrier, every receive taken from the peer's slot at the own chunk position, barrier (stream-ordered when MH_MOCK_RCCL_ASYNC=1)
+struct P2P { const void* send; void* recv; size_t count; int peer; ncclComm* c; hipStream_t s; };
+static thread_local P2P g_ops[64]; static thread_local int g_nops = 0; static thread_local bool g_in_group = false;
+static ncclResult_t run_group() {
+  if (g_nops == 0) return ncclSuccess;
+  ncclComm* c = g_ops[0].c; hipStream_t s = g_ops[0].s;
+  if (c->solo) {
+    for (int i = 0; i < g_nops; i++)
+      if (g_ops[i].recv && g_ops[i].peer == c->rank)
+        for (int j = 0; j < g_nops; j++)
+          if (g_ops[j].send && g_ops[j].peer == c->rank && hipMemcpyAsync(g_ops[i].recv, g_ops[j].send, g_ops[i].count, hipMemcpyDeviceToDevice, s) != hipSuccess) return ncclUnhandledCudaError;
+    return ncclSuccess;
+  }
+  if (!c->async && hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
+  for (int i = 0; i < g_nops; i++)
+    if (g_ops[i].send) {
+      char* dst = c->slots + (size_t)c->rank * c->slot + (size_t)g_ops[i].peer * g_ops[i].count;
+      if ((size_t)(g_ops[i].peer + 1) * g_ops[i].count > c->slot) return ncclInvalidArgument;
+      const hipError_t e = c->async ? hipMemcpyAsync(dst, g_ops[i].send, g_ops[i].count, hipMemcpyDeviceToHost, s) : hipMemcpy(dst, g_ops[i].send, g_ops[i].count, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return ncclUnhandledCudaError;
+    }
+  if (c->async) { if (hipLaunchHostFunc(s, barrier_hostfn, c) != hipSuccess) return ncclUnhandledCudaError; } else barrier(c);
+  for (int i = 0; i < g_nops; i++)
+    if (g_ops[i].recv) {
+      const char* src = c->slots + (size_t)g_ops[i].peer * c->slot + (size_t)c->rank * g_ops[i].count;
+      const hipError_t e = c->async ? hipMemcpyAsync(g_ops[i].recv, src, g_ops[i].count, hipMemcpyHostToDevice, s) : hipMemcpy(g_ops[i].recv, src, g_ops[i].count, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return ncclUnhandledCudaError;
+    }
+  if (c->async) { if (hipLaunchHostFunc(s, barrier_hostfn, c) != hipSuccess) return ncclUnhandledCudaError; } else barrier(c);
+  return ncclSuccess;
+}
+ncclResult_t ncclSend(const void* send, size_t count, ncclDataType_t, int peer, ncclComm_t c, hipStream_t s) {
+  if (!g_in_group || g_nops >= 64) return ncclInvalidArgument;          // this stand-in only knows grouped, symmetric exchanges
+  g_ops[g_nops++] = P2P{send, nullptr, count, peer, c, s};
+  return ncclSuccess;
+}
+ncclResult_t ncclRecv(void* recv, size_t count, ncclDataType_t, int peer, ncclComm_t c, hipStream_t s) {
+  if (!g_in_group || g_nops >= 64) return ncclInvalidArgument;
+  g_ops[g_nops++] = P2P{nullptr, recv, count, peer, c, s};
+  return ncclSuccess;
+}
+ncclResult_t ncclGroupStart(void) { g_in_group = true; g_nops = 0; return ncclSuccess; }
+ncclResult_t ncclGroupEnd(void) { g_in_group = false; const ncclResult_t r = run_group(); g_nops = 0; return r; }
 }

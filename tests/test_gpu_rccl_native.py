@@ -127,6 +127,7 @@ def test_bench_world_1_under_torchrun_uses_no_transport(gpu):
 
 # ---- N > 1 through the native transport, on ONE GPU: the shared-memory stand-in for librccl (tests/mock_rccl/) ----------------
 MOCK = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+MOCK_NOA2A = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl_noa2a.so")      # the same without ncclAllToAll: grouped ncclSend / ncclRecv
 
 MOCK_WORKER = r'''
 import os, sys
@@ -157,14 +158,21 @@ dist.barrier(); MD.disable_sharded_prove(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,log_n,pc,sliced", [(2, 12, "marlin", 0), (4, 16, "marlin", 0), (2, 12, "marlin", 1), (4, 12, "sonic", 1),
-                                                   (4, 16, "marlin", 1), (8, 16, "marlin", 1), (8, 16, "sonic", 1), (3, 12, "marlin", 1)])
-def test_native_transport_at_n_ranks_gives_the_single_gpu_proof(gpu, tmp_path, world, log_n, pc, sliced):
+@pytest.mark.parametrize("world,log_n,pc,sliced,variant", [(2, 12, "marlin", 0, "sync"), (4, 16, "marlin", 0, "sync"), (2, 12, "marlin", 1, "sync"),
+                                                           (4, 12, "sonic", 1, "sync"), (4, 16, "marlin", 1, "sync"), (8, 16, "marlin", 1, "sync"),
+                                                           (8, 16, "sonic", 1, "sync"), (3, 12, "marlin", 1, "sync"),
+                                                           (4, 14, "marlin", 1, "async"), (8, 16, "marlin", 1, "async"), (4, 12, "sonic", 1, "async-noa2a"),
+                                                           (2, 12, "marlin", 0, "async")])
+def test_native_transport_at_n_ranks_gives_the_single_gpu_proof(gpu, tmp_path, world, log_n, pc, sliced, variant):
     """mh_marlin_set_rccl with N = 2 / 3 / 4 / 8 ranks -- the C++ all-gather of partial points, the all-to-all of the distributed
     transforms and the device all-gather of round polynomials (rccl_native.h), entered from mh_marlin_prove exactly as on a
     multi-GPU node -- with the collectives carried by the shared-memory stand-in for librccl (RCCL refuses two ranks on the one
     device of this box): every rank's two proofs are the unsharded prover's bytes, and the counters show which collectives ran
-    (sliced = 1 and a power-of-two world: distributed transforms and two device all-gathers per proof)."""
+    (sliced = 1 and a power-of-two world: distributed transforms and two device all-gathers per proof).
+    variant "async" (ADVICE r04): the stand-in ENQUEUES its collectives -- asynchronous copies and the barriers as host functions in
+    stream order, the call returns at once, like RCCL's -- so the library's reuse of sl_send / sl_recv / ntt_dist_buf and the host
+    all-gather's staging are exercised the way a real communicator exercises them; "noa2a": the stand-in has no ncclAllToAll and
+    the transport takes its grouped ncclSend / ncclRecv path."""
     from marlin_amd import marlin as GM
     import json
     GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "marlin_proofs.json")))
@@ -178,8 +186,10 @@ def test_native_transport_at_n_ranks_gives_the_single_gpu_proof(gpu, tmp_path, w
     want = GM.prove(pk, inst, wit, bytes(range(32))) + GM.prove(pk, inst, wit, bytes(range(1, 33)))
     script = tmp_path / "mock_worker.py"
     script.write_text(MOCK_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "pc": pc, "sliced": sliced})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29913 + world + log_n + 40 * sliced + (7 if pc == "sonic" else 0)), WORLD_SIZE=str(world),
-               MH_RCCL_LIB=MOCK)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29913 + world + log_n + 40 * sliced + (7 if pc == "sonic" else 0) + 100 * len(variant)),
+               WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK_NOA2A if "noa2a" in variant else MOCK)
+    if "async" in variant:
+        env["MH_MOCK_RCCL_ASYNC"] = "1"
     if sliced:
         env["MH_SLICED"] = "2"               # also with 2 ranks, where the library would keep the rounds replicated
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
@@ -287,8 +297,8 @@ dist.barrier(); MD.disable_sharded_prove(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,sliced,victim", [(4, 1, 2), (2, 0, 1)])
-def test_a_rank_that_fails_mid_prove_fails_the_job_on_every_rank(gpu, tmp_path, world, sliced, victim):
+@pytest.mark.parametrize("world,sliced,victim,enqueued", [(4, 1, 2, False), (2, 0, 1, False), (4, 1, 0, True)])
+def test_a_rank_that_fails_mid_prove_fails_the_job_on_every_rank(gpu, tmp_path, world, sliced, victim, enqueued):
     """a rank that fails locally inside a sharded proof must fail the JOB, not hang it.  One rank's request for
     device scratch is forced to fail (mh_debug_fail_scratch) a quarter, half and most of the way through a proof -- inside the sliced
     rounds with their all-to-alls and round gathers at 4 ranks, inside the replicated rounds at 2: the poisoned rank keeps entering
@@ -310,9 +320,11 @@ def test_a_rank_that_fails_mid_prove_fails_the_job_on_every_rank(gpu, tmp_path, 
     script = tmp_path / "fail_worker.py"
     script.write_text(FAIL_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "sliced": sliced,
                                      "victim": victim, "fracs": fracs})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29871 + world), WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29871 + world + 10 * enqueued), WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK)
     if sliced:
         env["MH_SLICED"] = "2"
+    if enqueued:
+        env["MH_MOCK_RCCL_ASYNC"] = "1"          # collectives enqueued in stream order, as RCCL's are
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):
