@@ -713,9 +713,20 @@ def main():
                 traffic = per_pair * msm_pairs_rank * args.steps / max(1, acc_launches)
             else:
                 traffic = pj.get("msm_accum_bytes_per_launch")
+            import hashlib
+            from marlin_amd import _lib as _Lh
+            try:
+                loaded = hashlib.sha256(open(_Lh.LIB_PATH, "rb").read()).hexdigest()[:16]
+            except Exception:
+                loaded = None
+            cap_build = (pj.get("build") or {}).get("libmarlin_hip.so_sha256_16")
             traffic_source = {"file": "profiles/pmc_traffic.json", "capture": pj.get("source"), "box": pj.get("box"),
                               "build": pj.get("build"), "fetch_size_factor": pj.get("fetch_size_factor"),
-                              "same_run_as_timing": False}
+                              "loaded_library_sha256_16": loaded,
+                              "capture_is_of_the_loaded_build": bool(loaded and cap_build and loaded == cap_build),
+                              "same_run_as_timing": False,
+                              "note": "counters need their own rocprofv3 --pmc passes (a separate run of this very bench command, tools/profile.sh); "
+                                      "capture_is_of_the_loaded_build says whether that run used the library that is loaded now"}
         except Exception:
             traffic, traffic_source = None, None
     # NTT bytes: the transforms this workload executes (the prover runs 16 of the reference's 30, see workload.ntt_executed)
