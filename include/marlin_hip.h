@@ -319,8 +319,12 @@ int mh_marlin_test_exchange_dev(int which, const void* d_send, size_t bytes, voi
  *                by bucket range and runs rounds 2, 3 and the openings on slices when world is 4 or 8
  * mh_marlin_rccl_sliced(0) keeps the AHP rounds replicated (MSM sharding only); mh_marlin_set_shard / _set_alltoall with a
  * callback replace the native transport again; mh_marlin_rccl_destroy (also run by mh_shutdown) frees the communicator.
- * A failure on one rank inside a sharded mh_marlin_prove leaves the peers waiting in the next collective: the caller must
- * tear the job down (torch.distributed.run does when a rank exits non-zero). */
+ * A rank that fails LOCALLY inside a sharded mh_marlin_prove (an allocation, a launch) fails the job on every rank: it keeps
+ * entering the proof's collectives with a meaningless payload up to the next all-gather of partial points, whose error word makes
+ * every rank return non-zero from the same commit round (the failing rank with its own message); the transport stays in step
+ * and the next proof can run.  A rank that cannot enter a collective at all (a dead process, a sticky HIP error, the transport's
+ * own staging buffers) still leaves its peers waiting: the caller must tear such a job down (torch.distributed.run does when a
+ * rank exits non-zero). */
 int mh_rccl_unique_id(uint8_t* id128_out);
 int mh_marlin_set_rccl(int rank, int world, const uint8_t* id128);
 int mh_marlin_rccl_sliced(int sliced);

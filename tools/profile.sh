@@ -24,7 +24,7 @@ for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
 rows.sort()
 d = [x[1] / 1e6 for x in rows]
 steps = 2
-per_prove = 4            # the 4 MSM groups of a prove (rounds 1-3, openings); 8 with MH_FB_SPLIT=1
+per_prove = 4            # the 4 MSM groups of a prove (rounds 1-3, openings)
 timed = d[-per_prove * steps:]
 json.dump({"kernel": "bucket accumulation (msmfb::accum30_kernel)", "dispatch_ms_in_launch_order": [round(x, 3) for x in d],
            "avg_ms_all_dispatches": round(sum(d) / max(1, len(d)), 3),
