@@ -775,7 +775,7 @@ def main():
     roofline_reduce = None
     red_mix = (mixes or {}).get("reduce")
     if tab_w and reduce_ms > 0 and red_mix:
-        buckets_step = len(msms_run) * (3 << (tab_c - 3)) / world_eff          # 3 * 2^(c-3) buckets per MSM (msm_fb.cuh: digit_pos)
+        buckets_step = len(msms_run) * (1 << (tab_c - 1)) / world_eff
         gadds_per_s = 2.0 * buckets_step * breakdown_steps / (reduce_ms * 1e-3)
         red_bound = valu_bound_adds_per_s(red_mix)
         roofline_reduce = {"bound": "valu-issue", "kernel": "msmfb::rsum_kernel + msmfb::plane_kernel", "achieved": round(gadds_per_s / 1e9, 3),

@@ -117,9 +117,8 @@ int mh_bases_download(uint64_t handle, size_t offset, size_t n, uint64_t* xy_mon
 int mh_bases_free(uint64_t handle);
 int mh_bases_len(uint64_t handle, size_t* n_out);
 /* Fixed-base acceleration for a base set that is multiplied again and again (the SRS): precomputes the shifts
- * 2^{start_j} * P of all window positions AND their doubles (2 x W x n affine points of 128 B in device memory -- 96 B for BN254 --;
- * W = 13 at window_bits = 20: 26 x n x 128 B), after which every MSM against this handle with enough scalars runs Pippenger over ONE
- * shared set of 3 * 2^(window_bits - 3) buckets (a digit = 2 mod 4 goes, halved, against the doubled point: no such bucket exists).  window_bits
+ * 2^{start_j} * P of all window positions (W x n affine points of 128 B in device memory -- 96 B for BN254 --; W = 13 at window_bits = 20), after
+ * which every MSM against this handle with enough scalars runs Pippenger over ONE shared bucket set.  window_bits
  * in [4, 20], 0 = choose from n.  Results are unchanged (an MSM has one answer).  mh_marlin_index calls this for
  * powers_of_g.  No counterpart in the reference (arkworks recomputes nothing across calls). */
 int mh_bases_precompute(uint64_t handle, uint32_t window_bits);

@@ -449,7 +449,7 @@ struct FbRun {
     namespace F = msmfb;
     nj = (int)ns.size(); is_mont = is_mont_;
     W = msm::make_windows(bs.tab_c, win);
-    nbt = F::bucket_positions(bs.tab_c);                                 // buckets per job: 3 * 2^(c-3) (msm_fb.cuh: digit_pos)
+    nbt = 1u << (bs.tab_c - 1);                                          // buckets per job
     pshift = F::part_bits(bs.tab_c);
     nb = 1u << pshift;                                                   // per virtual window
     nparts = nbt / nb;
@@ -504,6 +504,9 @@ struct FbRun {
       if (rs.lgC < 1) rs.lgC = 1;
       rs.C = 1u << rs.lgC;
       rs.lgrpp = pshift - rs.lgC;
+      rs.R_own = nbown >> rs.lgC;
+      rs.lgM = 0;
+      while ((1u << rs.lgM) < rs.R_own) rs.lgM++;
       // Buckets per lane: two waves per SIMD on the full launches of a 2^20 proof (sort + reduce 9.34 vs 9.64 ms per proof at one
       // wave), one wave where two would leave a lane fewer than 16 buckets (2^16 + SonicKZG10: 2.63 vs 2.88 ms) -- either way the
       // kernel is bound by VALU issue: one wave with its three interleaved multiplication chains already fills the SIMD
@@ -515,42 +518,15 @@ struct FbRun {
       if (Lt < 1) Lt = 1;
       auto lanes = [&](u64 len) { u32 lg = 0; while (lg < 6 && (2ull << lg) * Lt <= len) lg++; return lg; };
       rs.lgJ = lanes(rs.C); rs.J = 1u << rs.lgJ; rs.Lr = rs.C >> rs.lgJ;
-      // the two levels of the bucket set (msm_fb.cuh: digit_pos): level A = the first 2 / 3 of the partitions, level B the rest; a
-      // rank owns the partitions v = first (mod stride) of each
-      const u32 npA = (1u << (bs.tab_c - 2)) >> pshift;
-      const u32 p0[2] = {0, npA}, npl[2] = {npA, nparts - npA};
-      u32 toff = 0, soff = 0;
-      for (int lvl = 0; lvl < 2; lvl++) {
-        F::RsLevel& l = rs.lv[lvl];
-        l.fv = p0[lvl] + (own.first + own.stride - p0[lvl] % own.stride) % own.stride;          // first v >= p0 with v = first (mod stride)
-        const u32 owned = l.fv < p0[lvl] + npl[lvl] ? (p0[lvl] + npl[lvl] - l.fv + own.stride - 1) / own.stride : 0;
-        l.R_own = owned << rs.lgrpp;
-        l.lgM = 0;
-        while ((1u << l.lgM) < l.R_own) l.lgM++;
-        l.toff = toff; l.soff = soff;
-        if (l.R_own) {
-          l.lgI = lanes(1ull << l.lgM); l.I = 1u << l.lgI; l.Lc = (l.R_own + l.I - 1) / l.I;
-          l.NTr = (u32)(((u64)l.R_own * rs.J + 63) & ~63ull);
-          l.NT = l.NTr + (u32)(((u64)rs.C * l.I + 63) & ~63ull);
-          soff += l.R_own + rs.C;
-        } else { l.lgI = 0; l.I = 1; l.Lc = 0; l.NTr = 0; l.NT = 0; }
-        toff += l.NT;
-      }
-      rs.NT = toff; rs.NS = soff;
-      // planes and the host's coefficient of each (msm_fb.cuh: plane_kernel).  Level A weighs position k = r' C + c with 2 k + 1, level
-      // B with 4 k + 4; r' = a + stride rpp (m / rpp) + m % rpp is the level-local row of owned row m, a = (fv - first partition of
-      // the level) rpp.
-      rs.nplanes = rs.lgC + 1 + rs.lv[0].lgM + rs.lv[1].lgM + 2;
+      rs.lgI = lanes(1ull << rs.lgM); rs.I = 1u << rs.lgI; rs.Lc = (rs.R_own + rs.I - 1) / rs.I;
+      rs.NTr = (u32)(((u64)rs.R_own * rs.J + 63) & ~63ull);
+      rs.NT = rs.NTr + (u32)(((u64)rs.C * rs.I + 63) & ~63ull);
+      rs.NS = rs.R_own + rs.C;
+      rs.nplanes = rs.lgC + rs.lgM + 1;
       coef.assign(rs.nplanes, 0);
-      u32 pi = 0;
-      for (u32 g = 1; g <= rs.lgC + 1; g++) coef[pi++] = 1ull << g;
-      for (int lvl = 0; lvl < 2; lvl++)
-        for (u32 p = 0; p < rs.lv[lvl].lgM; p++)
-          coef[pi++] = (2ull << lvl) * ((u64)rs.C << p) * (p < rs.lgrpp ? 1ull : (u64)own.stride);
-      for (int lvl = 0; lvl < 2; lvl++) {
-        const u64 a = (u64)(rs.lv[lvl].fv - p0[lvl]) << rs.lgrpp;
-        coef[pi++] = (1ull << (2 * lvl)) + (2ull << lvl) * rs.C * a;
-      }
+      for (u32 p = 0; p < rs.lgC; p++) coef[p] = 1ull << p;
+      for (u32 p = 0; p < rs.lgM; p++) coef[rs.lgC + p] = ((u64)rs.C << p) * (p < rs.lgrpp ? 1ull : (u64)own.stride);
+      coef[rs.nplanes - 1] = (((u64)rs.C * own.first) << rs.lgrpp) + 1;
     }
     MH_TRY(ws.seg.ensure((size_t)nj * rs.NS * sizeof(F::G1Xyzz30)));
     MH_TRY(ws.win.ensure((size_t)nj * rs.nplanes * sizeof(G1Xyzz)));
@@ -569,8 +545,7 @@ struct FbRun {
     ProfScope ps(c, PF_MSM_STAGES, s);
     unsigned short* key = (unsigned short*)ws.dig.ptr; u32* val = (u32*)ws.val.ptr;
     u32* d_ptot = (u32*)ws.ptot.ptr; u32* d_pstart = d_ptot + WT;
-    const u32 lgA = bs.tab_c - 2;                     // level A of the bucket set: 2^(c-2) positions (msm_fb.cuh: digit_pos)
-    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)ws.pc.ptr, W, win, is_mont, nparts, pshift, S, own, lgA);
+    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)ws.pc.ptr, W, win, is_mont, nparts, pshift, S, own);
     hipLaunchKernelGGL(F::pscan_kernel, dim3(nparts, nj), dim3(1024), 0, s, jobs, (u32*)ws.pc.ptr, d_ptot, nparts);
     hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
     // The partition totals are final once pscan has run, BEFORE the split kernel: they go to the host on the copy stream while
@@ -584,7 +559,7 @@ struct FbRun {
       MH_HIP(hipMemcpyAsync(ws.h_ptot.ptr, ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, c.copy_stream));
     }
     hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)ws.pc.ptr,
-                       (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S, own, lgA);
+                       (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S, own);
     if (side_copy) {
       MH_HIP(hipStreamSynchronize(c.copy_stream));
     } else {
@@ -836,19 +811,17 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
   if (cbits < 4 || cbits > (uint32_t)msmfb::MAX_C) return fail(MH_EINVAL, "mh_bases_precompute: window width must be in [4, 20]");
   msm::Windows win;
   const u32 W = msm::make_windows(cbits, win);
-  // levels [0, W): the window shifts; [W, 2 W): the same points doubled (msm_fb.cuh: digit_pos -- a digit = 2 (mod 4) is entered as
-  // half of itself against the doubled point)
-  if ((u64)2 * W * bs.n >= (1ull << 31)) return fail(MH_EINVAL, "mh_bases_precompute: table too large for 31-bit entry indices");
+  if ((u64)W * bs.n >= (1ull << 31)) return fail(MH_EINVAL, "mh_bases_precompute: table too large for 31-bit entry indices");
   void* tab = nullptr;
   const size_t pt30 = sizeof(msmfb::G1Aff30);
-  hipError_t e = hipMalloc(&tab, (size_t)2 * W * bs.n * pt30);
+  hipError_t e = hipMalloc(&tab, (size_t)W * bs.n * pt30);
   if (e != hipSuccess) return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the window table failed");
-  // two standard-form levels ping-pong through scratch while the chain of doublings runs; a third takes the doubled level
-  void* tmp = nullptr;                                    // three levels in standard form + the un-normalised points of one level
-  e = hipMalloc(&tmp, 3 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd));
+  // two standard-form levels ping-pong through scratch while the chain of doublings runs
+  void* tmp = nullptr;                                    // two ping-pong levels in standard form + the un-normalised points of one level
+  e = hipMalloc(&tmp, 2 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd));
   if (e != hipSuccess) { (void)hipFree(tab); return fail(MH_ENOMEM, "mh_bases_precompute: hipMalloc of the doubling scratch failed"); }
-  if (g_debug_poison_scratch) { debug_poison(tab, (size_t)2 * W * bs.n * pt30); debug_poison(tmp, 3 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd)); }
-  msmfb::G1XyzzStd* xyzz_scratch = (msmfb::G1XyzzStd*)((char*)tmp + 3 * bs.n * PT_B);
+  if (g_debug_poison_scratch) { debug_poison(tab, (size_t)W * bs.n * pt30); debug_poison(tmp, 2 * bs.n * PT_B + bs.n * sizeof(msmfb::G1XyzzStd)); }
+  msmfb::G1XyzzStd* xyzz_scratch = (msmfb::G1XyzzStd*)((char*)tmp + 2 * bs.n * PT_B);
   hipStream_t s = c.stream;
   const unsigned grid = (unsigned)(((bs.n + msmfb::TAB_BATCH - 1) / msmfb::TAB_BATCH + 127) / 128);
   const G1Affine* prev = (const G1Affine*)bs.d_points;
@@ -865,9 +838,6 @@ int bases_precompute(Context& c, BaseSet& bs, uint32_t cbits) {
     hipLaunchKernelGGL(msmfb::table_level_kernel, dim3(grid), dim3(128), 0, s, prev, next_std,
                        (msmfb::G1Aff30*)((char*)tab + (size_t)j * bs.n * pt30), xyzz_scratch, (u64)bs.n, j ? (u32)win.bits[j - 1] : 0u, kinv);
     prev = next_std;
-    // the doubled copy of this level: one doubling of the level just made (its standard form goes to the third scratch level)
-    hipLaunchKernelGGL(msmfb::table_level_kernel, dim3(grid), dim3(128), 0, s, prev, (G1Affine*)((char*)tmp + (size_t)2 * bs.n * PT_B),
-                       (msmfb::G1Aff30*)((char*)tab + (size_t)(W + j) * bs.n * pt30), xyzz_scratch, (u64)bs.n, 1u, kinv);
   }
   hipError_t le = hipGetLastError();
   hipError_t se = hipStreamSynchronize(s);
@@ -926,7 +896,7 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
         ok = find_table(c, d_bases[live[g0 + k]], ns[live[g0 + k]], o) == bs;
         offs[k] = o; sc[k] = d_scalars[live[g0 + k]]; nn[k] = ns[live[g0 + k]];
       }
-      if (ok && (u64)bs->tab_W * nsum >= 8ull * nj * (1ull << (bs->tab_c - 1))) {      // (the load rule of rounds 1-4, in units of 2^(c-1) buckets)
+      if (ok && (u64)bs->tab_W * nsum >= 8ull * nj * (1ull << (bs->tab_c - 1))) {
         std::vector<HG1> res(nj);
         bool skewed = false, part = false;
         MH_TRY(msm_fb_pipeline(c, *bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, shard, part));
@@ -1543,7 +1513,7 @@ int mh_bases_table_info(uint64_t handle, uint32_t* window_bits, uint32_t* window
   const BaseSet& bs = it->second;
   if (window_bits) *window_bits = bs.d_table ? bs.tab_c : 0;
   if (windows) *windows = bs.d_table ? bs.tab_W : 0;
-  if (table_bytes) *table_bytes = bs.d_table ? (uint64_t)2 * bs.tab_W * bs.n * sizeof(msmfb::G1Aff30) : 0;
+  if (table_bytes) *table_bytes = bs.d_table ? (uint64_t)bs.tab_W * bs.n * sizeof(msmfb::G1Aff30) : 0;
   return MH_OK;
 }
 

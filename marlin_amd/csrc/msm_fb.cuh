@@ -4,11 +4,7 @@
 // `powers_of_g[offset..]`; reference call sites /root/reference src/lib.rs:125,172,193,213,292), so the shifts
 // 2^{start_j} * P_i of all W window positions are computed once per base set (`mh_bases_precompute`, 13 x 128 B per
 // point at c = 20 -- HBM capacity is what MI355X has plenty of) and every (scalar, window) digit becomes an entry
-// "add table point T[j][i] to bucket |digit|".  Round 5 stores a SECOND copy of every level, doubled (2 T[j][i]): a digit
-// d = 2 (mod 4) is entered as d / 2 against the doubled point, so no bucket with an index = 2 (mod 4) exists and the set shrinks
-// from 2^(c-1) to 3 * 2^(c-3) buckets (digit_pos below) -- a quarter fewer buckets for the bucket reduction, whose cost is
-// per bucket, at the price of HBM capacity only (the accumulation still does one addition per digit).
-// All windows then share ONE set of 3 * 2^(c-3) buckets, the bucket
+// "add table point T[j][i] to bucket |digit|".  All windows then share ONE set of 2^(c-1) buckets, the bucket
 // reduction no longer scales with the number of windows, and c can grow past the 16 bits an LDS histogram holds:
 // c = 20 needs 13 bucket additions per scalar instead of 16.  Table points, bucket accumulators and the bucket
 // reduction use the 30-bit-limb field arithmetic of fq30.cuh.
@@ -69,23 +65,10 @@ __device__ __forceinline__ void store30(u32* p, const Fq30& a) {
   }
 }
 
-constexpr int MAX_C = 20;          // 3 * 2^17 buckets = 192 partitions x 2^11
+constexpr int MAX_C = 20;          // 2^19 buckets = 256 partitions x 2^11
 constexpr int PART_BITS = 11;      // buckets per virtual window = 2^11
 constexpr int MAX_PARTS = 256;
-// Bucket positions of a job (c = window width, digits |d| in [1, 2^(c-1)]), in two LEVELS:
-//   level A, positions [0, 2^(c-2)):            position k holds the digits d = 2k + 1 (odd) and d = 2 (2k + 1) (the latter against
-//                                                the DOUBLED table point): weight 2k + 1
-//   level B, positions 2^(c-2) + [0, 2^(c-3)):  position k holds the digits d = 4 (k + 1): weight 4 (k + 1)
-// Every digit value is one (position, multiplier) pair and weight x multiplier = d (tests/test_reduction_model.py).  Both levels are
-// whole partitions (a partition is 2^min(c-3, 11) positions), so bucket-range sharding and the row / column reduction see whole rows.
-inline u32 part_bits(u32 c) { return c - 3 < PART_BITS ? c - 3 : PART_BITS; }
-inline u32 bucket_positions(u32 c) { return 3u << (c - 3); }
-__host__ __device__ __forceinline__ u32 digit_pos(u32 d, u32 lgA, u32& doubled) {
-  if (d & 1u) { doubled = 0; return d >> 1; }
-  if (d & 2u) { doubled = 1; return d >> 2; }
-  doubled = 0;
-  return (1u << lgA) + (d >> 2) - 1;
-}
+inline u32 part_bits(u32 c) { return c - 1 < PART_BITS ? c - 1 : PART_BITS; }
 constexpr int TPB = 1024;          // count kernel: one scalar per thread
 constexpr int SORT_THREADS = 1024; // split / hist / scatter
 constexpr int SPLIT_ENTRIES = 13312;   // entries one split block stages in LDS (13 windows x 1024 scalars)
@@ -198,7 +181,7 @@ __device__ __forceinline__ bool owns(const Own& o, u32 v) {
   return (o.stride & (o.stride - 1)) == 0 ? (v & (o.stride - 1)) == o.first : v % o.stride == o.first;
 }
 __global__ __launch_bounds__(TPB) void count_kernel(FbJobs jobs, u32* __restrict__ pc, u32 W, Windows win, int is_mont, u32 nparts,
-                                                    u32 pshift, u32 S, Own own, u32 lgA) {
+                                                    u32 pshift, u32 S, Own own) {
   __shared__ u32 cnt[MAX_PARTS];
   const u32 job = blockIdx.y, blk = blockIdx.x;
   if (blk >= jobs.nblk[job]) return;
@@ -214,8 +197,7 @@ __global__ __launch_bounds__(TPB) void count_kernel(FbJobs jobs, u32* __restrict
       msm::for_each_digit(s, W, win, [&](u32, u32 e) {
         u32 b = e & 0x7fffffffu;
         if (b) {
-          u32 dbl;
-          const u32 v = digit_pos(b, lgA, dbl) >> pshift;
+          const u32 v = (b - 1) >> pshift;
           if (owns(own, v)) atomicAdd(&cnt[v], 1u);
         }
       });
@@ -270,7 +252,7 @@ __global__ __launch_bounds__(MAX_PARTS) void pstart_kernel(const u32* __restrict
 __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const u32* __restrict__ pc, const u32* __restrict__ ptot,
                                                              const u32* __restrict__ pstart, unsigned short* __restrict__ key,
                                                              u32* __restrict__ val, u32 W, Windows win, int is_mont, u32 nparts,
-                                                             u32 pshift, u32 tab_n, u32 S, Own own, u32 lgA) {
+                                                             u32 pshift, u32 tab_n, u32 S, Own own) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* cur = lds;                                  // [MAX_PARTS] counts -> local starts -> cursors
   u32* gdst = lds + MAX_PARTS;                     // [MAX_PARTS] global position of local entry 0 of each partition
@@ -306,14 +288,12 @@ __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const 
     msm::for_each_digit(s, W, win, [&](u32 w, u32 e) {
       u32 b = e & 0x7fffffffu;
       if (b) {
-        u32 dbl;
-        b = digit_pos(b, lgA, dbl);
+        b -= 1;
         const u32 v = b >> pshift;
         if (!owns(own, v)) return;                  // another rank's partition
         const u32 p = atomicAdd(&cur[v], 1u);
         skey[p] = (unsigned short)(b & ((1u << pshift) - 1));
-        // table levels [0, W): the shifts of the points; [W, 2 W): the same, doubled.  Indices stay below 2^31 (mh_bases_precompute checks)
-        sval[p] = ((dbl * W + w) * tab_n + t0) | (e & 0x80000000u);
+        sval[p] = (w * tab_n + t0) | (e & 0x80000000u);          // table indices stay below 2^31 (mh_bases_precompute checks)
         spart[p] = (unsigned char)v;
       }
     });
@@ -694,9 +674,8 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
 // by a ~19-bit double-and-add, then a tree over the segment results -- a chain of 2 seg + ~25 + ~14 dependent group
 // operations of ~15 us each at one wave per SIMD (profiles/r04o_last_prove_kernels_2p20.txt: 6.83 ms per proof at 2^20), a
 // third of it the offset multiplication that every thread repeats.  Here no point is ever multiplied on the device:
-//   * the owned buckets of each LEVEL of a job (digit_pos: weights 2k + 1 and 4 (k + 1)) are a matrix S[m][c] (m < R_own rows of
-//     C = 2^lgC buckets; a partition is rpp whole rows, so a rank's rows are its partitions' rows), position r(m) C + c with
-//     r(m) = (fv + (m / rpp) stride) rpp + m % rpp, k = position - first position of the level;
+//   * the owned buckets of a job are a matrix S[m][c] (m < R_own rows of C = 2^lgC buckets; a partition is rpp whole rows, so
+//     a rank's rows are its partitions' rows), bucket index b = r(m) C + c with r(m) = (first + (m / rpp) stride) rpp + m % rpp;
 //   * rsum_kernel: Row_m = sum_c S[m][c] and Col_c = sum_m S[m][c].  A group of J (rows) or I (columns) adjacent lanes shares
 //     one sum: every lane adds its strided share of <= Lr or Lc buckets, then the group's lanes are summed by an xor butterfly
 //     of lg J (lg I) shuffled additions -- 2 additions per bucket in all, a chain of L + lg G per thread, any number of
@@ -710,22 +689,16 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
 // Depth per batch: L + lg G + 2 + 8 additions instead of 2 seg + 25 + 14, and 2 additions per bucket instead of ~2.9.
 // (First form of round 5, profiles/r05a_*: plane sums over the per-thread partials instead of over whole rows and columns --
 // 16 x 20 x 4 blocks of LDS trees per batch, 1.0 ms per launch: slower than what it replaced.)
-// one LEVEL of the bucket set (digit_pos: level A = odd weights 2k + 1, level B = weights 4 (k + 1)) as this rank sees it
-struct RsLevel {
-  u32 fv;            // first owned partition of the level (global partition index; the others follow at own.stride)
-  u32 R_own;         // owned rows (0: this rank owns nothing of the level)
-  u32 lgI, I, Lc;    // lanes per column sum, rows per lane (I Lc >= R_own)
-  u32 NTr, NT;       // threads of the row sums (R_own J rounded up to whole waves), all threads of the level (+ C I, likewise)
-  u32 toff, soff;    // first thread / first sum of the level inside a job (sums: R_own rows, then C columns)
-  u32 lgM;           // bits of a row index m < R_own
-};
 struct RsPlan {
   u32 lgC, C;        // columns per row (C divides the partition size)
   u32 lgrpp;         // lg(rows per partition)
+  u32 R_own;         // owned rows
   u32 lgJ, J, Lr;    // lanes per row sum, buckets per lane (J Lr = C)
-  RsLevel lv[2];
-  u32 NT, NS;        // threads / sums per job (both levels)
-  u32 nplanes;       // lgC + 1 column planes (both levels merged: equal coefficients), lgM row planes per level, the two totals
+  u32 lgI, I, Lc;    // lanes per column sum, buckets per lane (I Lc >= R_own)
+  u32 NTr, NT;       // threads of the row sums (R_own J rounded up to whole waves), all threads per job (+ C I, likewise)
+  u32 NS;            // sums per job: R_own rows, then C columns
+  u32 lgM;           // bits of a row index m < R_own
+  u32 nplanes;       // lgC column planes, lgM row planes, the total
 };
 constexpr int PLANE_THREADS = 256;
 __device__ __forceinline__ u32 insert_one(u32 x, u32 p) { return ((x >> p) << (p + 1)) | (1u << p) | (x & ((1u << p) - 1)); }
@@ -736,32 +709,28 @@ __device__ __forceinline__ Fq30 f30_shfl_xor(const Fq30& a, u32 mask) {
   return r;
 }
 
-// thread q of job w, inside its level (q - toff): below NTr: lane g = q % J of row m = q / J adds columns g, g + J, ...; else lane
-// g = (q - NTr) % I of column c = (q - NTr) / I adds rows g, g + I, ...  NTr and NT are whole waves, so a wave is all rows or all
-// columns of ONE level: its trip count and its shuffles are uniform (threads past the last row / column carry the identity
-// through them).
+// thread q of job w: q < NTr: lane g = q % J of row m = q / J adds columns g, g + J, ...; else lane g = (q - NTr) % I of column
+// c = (q - NTr) / I adds rows g, g + I, ...  NTr and NT are whole waves, so a wave is all rows or all columns: its trip count
+// and its shuffles are uniform (threads past the last row / column carry the identity through them).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rsum_kernel(
     const G1Xyzz30* __restrict__ buckets, G1Xyzz30* __restrict__ sums, u32 nbt, u32 njobs, RsPlan p, Own own,
     const u32* __restrict__ largest, u32 skew_limit) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= njobs * p.NT) return;            // whole waves only (NT is a multiple of 64)
   if (*largest > skew_limit) return;        // a skewed batch left this path in the accumulate kernel: the buckets hold nothing
-  const u32 w = t / p.NT;
-  u32 q = t % p.NT;
-  const RsLevel& l = p.lv[q < p.lv[1].toff || p.lv[1].NT == 0 ? 0 : 1];
-  q -= l.toff;
+  const u32 w = t / p.NT, q = t % p.NT;
   const G1Xyzz30* B = buckets + (u64)w * nbt;
-  const bool row = q < l.NTr;
+  const bool row = q < p.NTr;
   u32 grp, g, lgG, L, m, c, dm, dc;
   bool valid;
-  if (row) { grp = q >> p.lgJ; g = q & (p.J - 1); lgG = p.lgJ; L = p.Lr; m = grp; c = g; dm = 0; dc = p.J; valid = grp < l.R_own; }
-  else { const u32 q2 = q - l.NTr; grp = q2 >> l.lgI; g = q2 & (l.I - 1); lgG = l.lgI; L = l.Lc; m = g; c = grp; dm = l.I; dc = 0; valid = grp < p.C; }
+  if (row) { grp = q >> p.lgJ; g = q & (p.J - 1); lgG = p.lgJ; L = p.Lr; m = grp; c = g; dm = 0; dc = p.J; valid = grp < p.R_own; }
+  else { const u32 q2 = q - p.NTr; grp = q2 >> p.lgI; g = q2 & (p.I - 1); lgG = p.lgI; L = p.Lc; m = g; c = grp; dm = p.I; dc = 0; valid = grp < p.C; }
   X30 acc = x30_identity();
   for (u32 step = 0; step < L + lgG; step++) {
     X30 b;
     if (step < L) {
-      if (valid && m < l.R_own && c < p.C) {
-        const u32 v = l.fv + (m >> p.lgrpp) * own.stride;
+      if (valid && m < p.R_own && c < p.C) {
+        const u32 v = own.first + (m >> p.lgrpp) * own.stride;
         const u32 r = (v << p.lgrpp) | (m & ((1u << p.lgrpp) - 1));
         b = x30_load(B + (((u64)r << p.lgC) | c));
       } else b = x30_identity();
@@ -772,7 +741,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     x30_add_ilp_inl(acc, b);
   }
-  if (valid && g == 0) x30_store(sums + (u64)w * p.NS + l.soff + (row ? grp : l.R_own + grp), acc);
+  if (valid && g == 0) x30_store(sums + (u64)w * p.NS + (row ? grp : p.R_own + grp), acc);
 }
 
 // tree sum of the block's first `nthreads` accumulators (a power of two) through LDS; the result is thread 0's `acc`
@@ -790,10 +759,7 @@ __device__ __forceinline__ void block_tree_sum(X30& acc, G1Xyzz30* sh, u32 nthre
   }
 }
 
-// grid (nplanes, njobs): block (plane, w) sums the members of one plane of job w -> out_std[w nplanes + plane], standard representation.
-// Planes: [0, lgC]: column plane g = plane + 1 (coefficient 2^g): the columns c of level A with bit g - 1 and those of level B with
-// bit g - 2 (A weighs a column 2 c, B 4 c); then lgM row planes of level A, lgM of level B (the rows m with the bit); then the
-// two level totals (every row of the level: the rows cover each bucket once).
+// grid (nplanes, njobs): block (plane, w) sums the members of one plane of job w -> out_std[w nplanes + plane], standard representation
 __global__ __launch_bounds__(PLANE_THREADS) void plane_kernel(const G1Xyzz30* __restrict__ sums, G1Xyzz* __restrict__ out_std, RsPlan p,
                                                               const u32* __restrict__ largest, u32 skew_limit) {
   extern __shared__ __attribute__((aligned(16))) u32 lds_plane[];
@@ -801,30 +767,17 @@ __global__ __launch_bounds__(PLANE_THREADS) void plane_kernel(const G1Xyzz30* __
   if (*largest > skew_limit) return;
   const u32 plane = blockIdx.x, w = blockIdx.y;
   const G1Xyzz30* S = sums + (u64)w * p.NS;
-  const u32 ncol = p.lgC + 1, nrowA = p.lv[0].lgM, nrowB = p.lv[1].lgM;
-  // members: k in [0, cntA) from level A, [cntA, cntA + cntB) from level B
-  u32 cntA = 0, cntB = 0, bitA = 0, bitB = 0;
-  int kind;                                               // 0 columns, 1 rows with a bit, 2 every row
-  if (plane < ncol) {
-    kind = 0;
-    const u32 g = plane + 1;
-    if (g <= p.lgC && p.lv[0].R_own) { cntA = p.C >> 1; bitA = g - 1; }
-    if (g >= 2 && p.lv[1].R_own) { cntB = p.C >> 1; bitB = g - 2; }
-  } else if (plane < ncol + nrowA) { kind = 1; bitA = plane - ncol; cntA = 1u << (nrowA - 1); }
-  else if (plane < ncol + nrowA + nrowB) { kind = 1; bitB = plane - ncol - nrowA; cntB = 1u << (nrowB - 1); }
-  else if (plane == ncol + nrowA + nrowB) { kind = 2; cntA = p.lv[0].R_own; }
-  else { kind = 2; cntB = p.lv[1].R_own; }
-  const u32 count = cntA + cntB;
+  u32 count;                                               // members enumerated below (some row indices fall past R_own)
+  if (plane < p.lgC) count = p.C >> 1;
+  else if (plane < p.lgC + p.lgM) count = 1u << (p.lgM - 1);
+  else count = p.R_own;
   X30 acc = x30_identity();
   for (u32 k = threadIdx.x; k < count; k += PLANE_THREADS) {
-    const bool inA = k < cntA;
-    const RsLevel& l = p.lv[inA ? 0 : 1];
-    const u32 kk = inA ? k : k - cntA, bit = inA ? bitA : bitB;
     u32 q;
-    if (kind == 0) q = l.R_own + insert_one(kk, bit);
-    else if (kind == 1) { q = insert_one(kk, bit); if (q >= l.R_own) continue; }
-    else q = kk;
-    const X30 t = x30_load(S + l.soff + q);
+    if (plane < p.lgC) q = p.R_own + insert_one(k, plane);                 // columns c with bit `plane`
+    else if (plane < p.lgC + p.lgM) { q = insert_one(k, plane - p.lgC); if (q >= p.R_own) continue; }   // rows m with bit (plane - lgC)
+    else q = k;                                                            // every row: the rows cover every bucket once
+    const X30 t = x30_load(S + q);
     x30_add_ilp(acc, t);
   }
   u32 width = 1;

@@ -249,8 +249,7 @@ def test_fixed_base_table_info_and_shard_resize(gpu, bases4k):
     pt = 128 if F.FQ_LIMBS64 == 6 else 96
     from tests.util import auto_window_bits
     c0 = auto_window_bits(n)
-    # two copies of every level: the window shifts and the same points doubled (a digit = 2 mod 4 is entered as half of itself)
-    assert c0 == 15 and (c, w, nbytes) == (c0, (256 + c0 - 1) // c0, 2 * ((256 + c0 - 1) // c0) * n * pt)
+    assert c0 == 15 and (c, w, nbytes) == (c0, (256 + c0 - 1) // c0, ((256 + c0 - 1) // c0) * n * pt)
     Bx = gpu.Bases(big).precompute(9)
     sc = rand_fr(n, 4242)
     want = EC.scalar_mul(EC.G1_GEN, sum(s * a for s, a in zip(sc, dlb)) % F.R_MOD)
