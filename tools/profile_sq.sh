@@ -1,6 +1,7 @@
 #!/bin/bash
 # Usage (on the GPU box, from the repo root): tools/profile_sq.sh <tag> [bench args...]
-# SQ / GRBM counters of the accumulate kernel over ONE prove: rocprofv3 --pmc in its own run (with
+# SQ / GRBM counters of one kernel over ONE prove (default: the accumulate kernel; SQ_KERNEL=rsum_kernel: the
+# row / column sums of the bucket reduction): rocprofv3 --pmc in its own run (with
 # --kernel-trace only), per dispatch; the summary keeps the prove's own dispatches (the last 4 launches of
 # msmfb::accum30_kernel: commit rounds 1-3 and the openings) apart from Marlin::index's.
 #   gpurun_out/prof_<tag>/sq_counters.json
@@ -19,9 +20,9 @@ timeout 900 rocprofv3 --pmc $SQ_COUNTERS GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD1 > $OUT/pmc_sq.log 2>&1
 find $OUT/pmc_sq -name "*counter_collection.csv" -exec cp {} $OUT/pmc_sq.csv \;
 cd $REPO
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "${SQ_KERNEL:-accum30_kernel}" <<'PY'
 import csv, json, sys, collections
-out = sys.argv[1]
+out, kname = sys.argv[1], sys.argv[2]
 rows = collections.defaultdict(dict)          # dispatch id -> counters
 names = {}
 dur = {}
@@ -30,7 +31,7 @@ for r in csv.DictReader(open(out + "/pmc_sq.csv")):
     rows[d][r["Counter_Name"]] = rows[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     names[d] = r["Kernel_Name"]
     dur[d] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-acc = [d for d in sorted(rows) if "accum30_kernel" in names[d]]
+acc = [d for d in sorted(rows) if kname in names[d]]
 def summarise(ds):
     tot = collections.Counter()
     for d in ds:
@@ -58,11 +59,11 @@ def summarise(ds):
     if tot.get("SQ_WAVE_CYCLES") and tot.get("SQ_BUSY_CYCLES"):
         s["resident_waves_per_busy_simd_cycle"] = round(tot["SQ_WAVE_CYCLES"] / tot["SQ_BUSY_CYCLES"], 3)
     return s
-res = {"kernel": "msmfb::accum30_kernel", "all_dispatches": summarise(acc), "prove_only_last4": summarise(acc[-4:]),
+res = {"kernel": "msmfb::" + kname, "all_dispatches": summarise(acc), "prove_only_last4": summarise(acc[-4:]),
        "per_dispatch": [dict(rows[d], dispatch=d, ms=dur.get(d)) for d in acc],
        "note": "counters summed over SEs/XCDs as rocprofv3 reports them; prove_only = the last 4 dispatches of the run "
                "(bench.py --steps 1 --warmup 0: index first, then one prove)"}
-json.dump(res, open(out + "/sq_counters.json", "w"), indent=1)
+json.dump(res, open(out + ("/sq_counters.json" if kname == "accum30_kernel" else "/sq_counters_%s.json" % kname), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("all_dispatches", "prove_only_last4")}, indent=1))
 PY
 rm -rf $OUT/pmc_sq
