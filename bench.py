@@ -782,7 +782,7 @@ def main():
                            "peak": round(red_bound / 1e9, 3), "unit": "G general additions/s (XYZZ += XYZZ)", "frac": round(gadds_per_s / red_bound, 4),
                            "ms_per_step": round(reduce_ms / breakdown_steps, 3), "launch_pairs_per_step": reduce_launches / breakdown_steps,
                            "buckets_per_step": buckets_step, "additions_per_bucket": 2,
-                           "waves_per_simd": "2 (214 registers; 1 where a lane would get fewer than 16 buckets)",
+                           "waves_per_simd": "2 (220 registers; 1 where a lane would get fewer than 16 buckets)",
                            "valu_instr_per_add": sum(red_mix.values()), "instr_mix_per_add": red_mix,
                            "instr_mix_source": "profiles/accum_isa_mix.json [%s][reduce]" % _Lc.CURVE,
                            "note": "round 4's segment reduction (running sums + a ~19-bit double-and-add per thread + tree) took 6.83 ms per proof "

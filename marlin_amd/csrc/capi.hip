@@ -492,7 +492,7 @@ struct FbRun {
     MH_TRY(ws.tot.ensure(WB * 4)); MH_TRY(ws.base.ensure(WB * 4)); MH_TRY(ws.pend.ensure(WB * 4));
     MH_TRY(ws.buckets.ensure(WB * sizeof(F::G1Xyzz30)));
     // Bucket reduction (msm_fb.cuh: rsum / plane kernels): the owned buckets as R_own rows of C, every row and every column summed
-    // by a group of lanes -- as many lanes that the launch has about two waves per SIMD (the kernel holds 214 registers), at
+    // by a group of lanes -- as many lanes that the launch has about two waves per SIMD (the kernel holds 220 registers), at
     // most a wave's 64 --, then the bit planes of the row and column indices.  With a rank's partitions interleaved (v = first, first + stride, ...) the
     // global row of local row m is r(m) = first rpp + stride rpp (m / rpp) + m % rpp: the planes run over the bits of m and
     // the constants go into the host's coefficients.

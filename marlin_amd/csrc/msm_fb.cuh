@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
 //   * rsum_kernel: Row_m = sum_c S[m][c] and Col_c = sum_m S[m][c].  A group of J (rows) or I (columns) adjacent lanes shares
 //     one sum: every lane adds its strided share of <= Lr or Lc buckets, then the group's lanes are summed by an xor butterfly
 //     of lg J (lg I) shuffled additions -- 2 additions per bucket in all, a chain of L + lg G per thread, any number of
-//     threads (two waves per SIMD: the loop has ONE inlined copy of the group law, 214 registers);
+//     threads (two waves per SIMD: the loop has ONE inlined copy of the group law, 220 registers);
 //   * plane_kernel: sum_m m Row_m and sum_c c Col_c as BIT PLANES -- Y_p = sum of the Col_c whose c has bit p, M_p likewise
 //     over the bits of m, T = sum of all rows: one block per (job, plane), members enumerated directly from the bit layout, a
 //     tree through LDS -- lg(owned buckets) + 1 points per job go to the host;
