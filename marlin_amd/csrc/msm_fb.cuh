@@ -21,7 +21,7 @@
 // (profiles/pmc_traffic.json; measured the same way for this path before the LDS staging: 2.6 GB written per launch
 // for 0.33 GB of entries).
 // followed by the ordering of all buckets by size, the accumulate kernel (entries index the table), the fix-up of deferred
-// collisions, and the segment reduction over the single bucket set of each MSM.
+// collisions, and the reduction of the single bucket set of each MSM (row / column sums, bit planes).
 #pragma once
 #include "msm.cuh"
 #include "fq30.cuh"
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __re
   for (u32 idx = t; idx < cnt; idx += SORT_THREADS) out[gdst[sbkt[idx]] + idx] = stage[idx];
 }
 
-// ---- XYZZ points on 30-bit limbs (buckets between accumulate and the segment reduction) -------------------------
+// ---- XYZZ points on 30-bit limbs (buckets between accumulate and the bucket reduction) -------------------------
 // Bounds kept by every operation below (units of p): X <= 6.2, Y <= 3.2, ZZ, ZZZ <= 1.1; the identity is ZZ = 0
 // exactly (a ZZ computed by the formulas is a product of non-zero residues).
 struct X30 { Fq30 x, y, zz, zzz; };
@@ -479,16 +479,16 @@ __device__ __noinline__ void x30_dbl(X30& a) {
 }
 
 // ---- the same group law with its independent multiplications side by side (fq30.cuh f30_mul_x3 ...) -------------------
-// The bucket reduction runs ONE wave per SIMD through a chain of ~90 dependent group operations per thread: a latency chain, and
-// inside it every field multiplication is itself one chain of ~400 dependent instructions.  The addition's 14 multiplications
-// are not all dependent on each other: {U1, S1, ZZ1 ZZ2}, {U2, S2, ZZZ1 ZZZ2}, {P^2, R^2}, {Q, PPP, ZZ3}, {Y3, ZZZ3} -- five
-// steps of 2-3 interleaved chains instead of 14 single ones; the doubling's 10 become 4 steps.  Measured (profiles/r04e_*, r04f_*):
-// sort + reduce stages 11.85 -> 11.57 ms per proof at 2^20, nothing at 2^16 -- far less than the 1.4 x a latency-bound chain would
-// gain, so a lone wave is NOT waiting for its own v_mad_u64_u32 results: it issues an instruction every ~6 cycles whatever their
-// dependencies.  (CALLING the multi-chain operations instead of inlining them -- 50 KB of code instead of 100 KB, in case the
-// 64-KB instruction cache were the limit -- costs 3.3 ms per proof: the operands travel through scratch.)  Same values mod p (Y3 is taken
-// as ONE reduction of R (Q - X3) + (2p - S1) PPP, so its lazy representative differs from x30_add's: compared through the
-// canonical form by mh_selftest_fq30; bounds: X <= 6.2, Y <= 1.2, ZZ, ZZZ <= 1.1).
+// Inside a general addition every field multiplication is one chain of ~400 dependent instructions, but the addition's 14
+// multiplications are not all dependent on each other: {U1, S1, ZZ1 ZZ2}, {U2, S2, ZZZ1 ZZZ2}, {P^2, R^2}, {Q, PPP, ZZ3}, {Y3, ZZZ3}
+// -- five steps of 2-3 interleaved chains instead of 14 single ones; the doubling's 10 become 4 steps.  Built in round 4 for the
+// segment reduction, which ran one wave per SIMD (sort + reduce stages 11.85 -> 11.57 ms per proof at 2^20,
+// profiles/r04ef_ab_reduce_ilp_and_called_field_ops.txt); round 5's row / column sums use the same law, and the sweep of their
+// launch shape shows what the interleaving buys: ONE such wave already saturates its SIMD's VALU (one and two resident waves run
+// at the same rate, profiles/r05c_sweep_rsum_threads.txt, r05w_sq_counters_rsum_kernel_wave_cycle_breakdown.json).  (CALLING the
+// multi-chain operations instead of inlining them costs 3.3 ms per proof: the operands travel through scratch.)  Same values mod p
+// (Y3 is taken as ONE reduction of R (Q - X3) + (2p - S1) PPP, so its lazy representative differs from x30_add's: compared through
+// the canonical form by mh_selftest_fq30; bounds: X <= 6.2, Y <= 1.2, ZZ, ZZZ <= 1.1).
 __device__ __noinline__ void x30_dbl_ilp(X30& a);
 __device__ __forceinline__ void x30_add_ilp_inl(X30& acc, const X30& b) {
   if (x30_is_identity(b)) return;
