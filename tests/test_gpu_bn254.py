@@ -27,7 +27,11 @@ def test_bn254_ntt_msm_srs_parity():
 def test_bn254_marlin_and_sonic_provers():
     """The whole prover on BN254 with both PC schemes: byte-identical proofs vs the oracle (fresh runs), polynomial
     parity, general R1CS, 2^20-constraint proofs verified by the oracle (BASELINE.json configs[4])."""
-    out = _run(["tests/test_gpu_marlin.py"], extra=["-k", "not golden and not two_ranks"])
+    # (the multi-rank cases are transport and sharding logic, which is curve-independent and runs in full on BLS12-381: three of
+    #  them -- replicated, sliced at 4 and at 8 ranks, both schemes -- are kept here; the bench.py launches are not repeated)
+    out = _run(["tests/test_gpu_marlin.py"],
+               extra=["-k", "not golden and not two_ranks and not bench_gpus and not (sharded_prove_ranks and not "
+                            "(2-12-marlin-0 or 8-16-sonic-1 or 4-16-marlin-1))"])
     assert " passed" in out
 
 
