@@ -556,7 +556,7 @@ def test_bench_gpus_2_runs_two_sharded_ranks(gpu):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal", "--steps", "1", "--warmup", "1",
-                          "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                          "--log-constraints", "14", "--no-cpu-baseline", "--no-throughput"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["constraints"] == 1 << 14
@@ -564,14 +564,14 @@ def test_bench_gpus_2_runs_two_sharded_ranks(gpu):
     # proof one GPU makes from the same inputs and seed
     assert rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True, rec["proof"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--log-constraints", "14",
-                          "--no-cpu-baseline", "--no-seam-route"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--no-throughput", "--no-seam-route"], env=env, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
     rec1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert rec1["proof"]["verified"] is True and rec1["proof"]["sha256_32"] == rec["proof"]["sha256_32"]
     assert rec["rehearsal"] is True and rec["distinct_devices"] == 1
     # without --rehearsal two ranks on ONE device are refused a scaling value: the line still explains itself
     bare = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log-constraints", "12",
-                           "--no-cpu-baseline", "--no-verify"], env=env, capture_output=True, text=True, timeout=600)
+                           "--no-cpu-baseline", "--no-throughput", "--no-verify"], env=env, capture_output=True, text=True, timeout=600)
     assert bare.returncode == 0, bare.stderr[-3000:]
     recb = json.loads([l for l in bare.stdout.splitlines() if l.startswith("{")][-1])
     assert recb["value"] is None and recb["rehearsal"] is False and "not an N-GPU measurement" in recb["note"]
@@ -586,7 +586,7 @@ def test_bench_line_says_its_proof_is_the_oracles_golden_proof(gpu):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--log-constraints", "16",
-                          "--no-cpu-baseline", "--no-seam-route"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--no-throughput", "--no-seam-route"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["proof"]["verified"] is True and rec["proof"]["oracle_golden"]["byte_identical"] is True, rec["proof"]
@@ -626,7 +626,7 @@ def test_bench_gpus_4_runs_the_sliced_rounds(gpu):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearsal", "--steps", "1", "--warmup", "1",
-                          "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--log-constraints", "14", "--no-cpu-baseline", "--no-throughput"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 4 and rec["value"] > 0 and "slices" in rec["config"]["parallelism"], rec["config"]
@@ -702,3 +702,23 @@ def test_exchange_callback_over_rccl_world_1(gpu, tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29791", WORLD_SIZE="1", RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl world=1 ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_bench_line_carries_the_fine_print(gpu):
+    """the default line itself says what the host-pointer entry point costs (`host_inputs_ms_per_step`), how
+    the bucket reduction stands against its issue bound (`roofline_reduce`), whether the PMC capture is of the loaded build, and -- apart
+    from the headline -- what two independent provers sharing the GPU deliver (`throughput_pipelined`)."""
+    import json, subprocess, sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log-constraints", "14",
+                          "--no-cpu-baseline", "--no-seam-route"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["value"] > 0 and rec["host_inputs_ms_per_step"] > 0 and "HOST pointers" in rec["host_inputs_note"]
+    rr = rec["roofline_reduce"]
+    assert rr["bound"] == "valu-issue" and 0 < rr["frac"] < 1 and rr["additions_per_bucket"] == 2 and "rsum_kernel" in rr["kernel"]
+    assert "capture_is_of_the_loaded_build" in rec["roofline"]["traffic_source"]
+    tp = rec["throughput_pipelined"]
+    assert tp["processes"] == 2 and tp["proofs_per_s"] > 0 and len(tp["proofs_per_process"]) == 2 and "not the headline" in tp["what"]

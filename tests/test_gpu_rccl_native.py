@@ -119,7 +119,7 @@ def test_bench_world_1_under_torchrun_uses_no_transport(gpu):
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", "29831", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                          "--log-constraints", "14", "--no-cpu-baseline", "--no-seam-route"], env=env, capture_output=True, text=True, timeout=900)
+                          "--log-constraints", "14", "--no-cpu-baseline", "--no-throughput", "--no-seam-route"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["transport"] is None and rec["proof"]["verified"] is True
@@ -219,7 +219,7 @@ def test_bench_native_transport_with_n_ranks(gpu, world, log_n):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rehearsal", "--steps", "2", "--warmup", "1", "--transport", "native",
-                          "--log-constraints", str(log_n), "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--log-constraints", str(log_n), "--no-cpu-baseline", "--no-throughput"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == world and rec["value"] > 0 and len(rec["per_rank"]) == world
@@ -244,7 +244,7 @@ def test_bench_falls_back_to_the_callbacks_when_one_rank_fails_the_native_self_t
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearsal", "--steps", "1", "--warmup", "1", "--transport", "native",
-                          "--log-constraints", "14", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--log-constraints", "14", "--no-cpu-baseline", "--no-throughput"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "native RCCL transport unavailable" in out.stderr
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

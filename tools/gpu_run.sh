@@ -20,7 +20,7 @@ TAG=${1:?tag}; shift
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=$(pwd)/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
-B="timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-seam-route"
+B="timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-throughput --no-seam-route"
 line() { python - "$@" <<'PY'
 import json, sys
 for f in sys.argv[1:]:
@@ -65,7 +65,7 @@ for R in "$@"; do
     small)
       $B --log-constraints 16 --pc sonic --steps 20 > $O/bench_2p16_sonic.json 2>/dev/null; line $O/bench_2p16_sonic.json
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace_2p16 -o t -- python $OLDPWD/bench.py --steps 3 --warmup 1 \
-          --no-cpu-baseline --no-seam-route --no-verify --log-constraints 16 --pc sonic > $O/trace_2p16.log 2>&1 )
+          --no-cpu-baseline --no-throughput --no-seam-route --no-verify --log-constraints 16 --pc sonic > $O/trace_2p16.log 2>&1 )
       T=$(find $O/trace_2p16 -name "*kernel_trace.csv" | head -1)
       [ -n "$T" ] && python tools/gap_analysis.py $T 4 > $O/gaps_2p16_sonic.txt 2>&1 && python tools/prove_kernels.py $T > $O/last_prove_kernels_2p16_sonic.txt 2>&1
       rm -rf $O/trace_2p16; tail -30 $O/gaps_2p16_sonic.txt ;;

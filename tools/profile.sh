@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-seam-route --full-prof $*"
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput --no-seam-route --full-prof $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # per-dispatch durations of the accumulate kernel: kernel_stats averages over index + warm-up + timed launches, the
@@ -35,7 +35,7 @@ json.dump({"kernel": "bucket accumulation (msmfb::accum30_kernel)", "dispatch_ms
 PY
 grep '^{' $OUT/trace.log | tail -1 > $OUT/bench_line_under_rocprof.json
 if [ "${PROFILE_STATS_ONLY:-0}" = 1 ]; then rm -rf $OUT/trace; ls -la $OUT; exit 0; fi
-CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam-route --full-prof $*"
+CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-throughput --no-seam-route --full-prof $*"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD1 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $CMD1 > $OUT/pmc_write.log 2>&1
 find $OUT/pmc_fetch -name "*counter_collection.csv" -exec cp {} $OUT/pmc_fetch.csv \;

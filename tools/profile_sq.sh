@@ -12,7 +12,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"
+CMD1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-throughput $*"
 # SQ_COUNTERS overrides the 8 SQ slots; the default set is the wave-cycle breakdown of MI355X_MICROARCH.md (rocprofv3 PMC slots):
 # WAIT_ANY (wave parked: s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES, all in quad-cycles
 SQ_COUNTERS=${SQ_COUNTERS:-"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES"}

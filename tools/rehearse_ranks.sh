@@ -13,7 +13,7 @@ for T in ${REHEARSE_TRANSPORTS:-native callback}; do
   for N in $WORLDS; do
     F=$O/bench_${N}_ranks_on_one_gpu_2p${LOGN}_${T}.json
     BENCH_BACKEND=gloo BENCH_SINGLE_DEVICE=1 MH_MOCK_RCCL_SLOT_MB=${MH_MOCK_RCCL_SLOT_MB:-1024} MH_RCCL_LIB=$PWD/tests/mock_rccl/libmock_rccl.so timeout 380 python bench.py --gpus $N --rehearsal --steps 3 --warmup 1 \
-      --transport $T --log-constraints $LOGN --no-cpu-baseline ${REHEARSE_ARGS:-} > $F 2> $O/err_${N}_${T}.txt
+      --transport $T --log-constraints $LOGN --no-cpu-baseline --no-throughput ${REHEARSE_ARGS:-} > $F 2> $O/err_${N}_${T}.txt
     python - $F $N $T <<'PY'
 import json, sys
 try:

@@ -8,7 +8,7 @@ VALS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do VALS+=("$1"); shift; done; [
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/$TAG; mkdir -p $O
 for V in "${VALS[@]}"; do
-  env $VAR=$V timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-seam-route --no-verify "$@" 2>/dev/null | python -c "
+  env $VAR=$V timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-throughput --no-seam-route --no-verify "$@" 2>/dev/null | python -c "
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); b = d['breakdown_ms_per_step']
 print('$VAR=$V', d['ms_per_step'], 'ms; accumulate', b['msm_accum'], 'sort+reduce', b['msm_sort_and_reduce_stages'], 'ntt', b['ntt'], '+', b.get('ntt_beside_msm_reduction'), 'beside the reduction',
