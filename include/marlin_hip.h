@@ -21,8 +21,10 @@
  *     arkworks' in-memory order and (unless stated) Montgomery form: Fr = 4 limbs,
  *     Fq = 6 limbs.  A G1 affine point is x||y (12 limbs, no infinity flag); a G1
  *     Jacobian point is X||Y||Z (18 limbs), Z = 0 meaning the identity.
- *   - one process drives one GPU (mh_init(device)); calls are serialised on one HIP
- *     stream per process (mh_set_stream lets the caller supply it).
+ *   - a CONTEXT drives one GPU.  mh_init(device) initialises the process's default context; mh_ctx_create
+ *     makes more (same or other GPUs) and mh_ctx_set_current binds the calling thread to one.  Calls into one
+ *     context are serialised (its lock, its HIP stream: mh_set_stream lets the caller supply it); calls into
+ *     different contexts run side by side.  Handles and device pointers belong to the context that made them.
  *   - "_dev" variants take device pointers (hipMalloc / mh_alloc / torch data_ptr).
  */
 #ifndef MARLIN_HIP_H
@@ -33,6 +35,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly what is declared in here is exported */
+#pragma GCC visibility push(default)
 
 #define MH_OK 0
 #define MH_EINVAL (-1)   /* bad argument */
@@ -40,6 +44,7 @@ extern "C" {
 #define MH_EHIP (-3)     /* HIP runtime error (see mh_last_error) */
 #define MH_ENOINIT (-4)  /* mh_init not called */
 #define MH_ENODEV (-5)   /* no usable gfx950 device */
+#define MH_ECHECK (-6)   /* an invariant of the MSM pipeline does not hold (MH_CHECK / mh_check_level): the result is not trusted */
 
 #define MH_FIELD_BLS12_381_FR 0
 #define MH_CURVE_BLS12_381_G1 0
@@ -55,13 +60,25 @@ int mh_curve_info(int* curve_id, int* fr_limbs64, int* fq_limbs64, int* fr_two_a
  * mh_init takes a single device id.  SURVEY.md 8b's sketch `mh_init(const int* device_ids, int n_devices)` is kept as
  * mh_init_devices for binding compatibility: it accepts exactly one id (n_devices == 1) and fails with MH_EINVAL
  * otherwise -- a deliberate deviation, documented in INTEGRATION.md section 2. */
-int mh_init(int device_id);               /* idempotent for the same device */
+int mh_init(int device_id);               /* the calling thread's current context (the default one unless mh_ctx_set_current chose another); idempotent for the same device */
 int mh_init_devices(const int* device_ids, int n_devices);
 int mh_shutdown(void);
 const char* mh_last_error(void);
 int mh_set_stream(void* hip_stream);      /* NULL -> library-owned stream */
 int mh_synchronize(void);
 int mh_device_info(char* name_out, size_t name_cap, int* cu_count, size_t* hbm_bytes);
+/* Contexts.  The reference proves inside ONE process on rayon threads (/root/reference src/ahp/mod.rs:9-10, benches/bench.rs:1-3,
+ * src/lib.rs:151-155 has one caller).  A context is one GPU's worth of library state -- streams, twiddles, workspaces, uploaded base
+ * sets, prover keys, shard configuration -- so one host process can keep two proofs in flight on one GPU (two contexts, two threads)
+ * or drive several GPUs (one context and one thread per GPU; mh_marlin_set_local_group joins them into one sharded prover without
+ * RCCL).  mh_ctx_create initialises the new context on `device_id` (no mh_init needed); mh_ctx_set_current(ctx) binds the CALLING
+ * THREAD to it (NULL: back to the default context) and every other entry point then works on it; mh_ctx_destroy releases everything
+ * the context owns (no thread may be inside it). */
+typedef struct mh_context* mh_ctx_t;
+int mh_ctx_create(int device_id, mh_ctx_t* ctx_out);
+int mh_ctx_set_current(mh_ctx_t ctx);
+mh_ctx_t mh_ctx_get_current(void);
+int mh_ctx_destroy(mh_ctx_t ctx);
 
 /* ---- device memory (plain hipMalloc/hipFree/hipMemcpy on the library stream) ---- */
 int mh_alloc(size_t bytes, void** dptr_out);
@@ -275,7 +292,26 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
  * multi-GPU host. */
 int mh_msm_batch_sharded_dev(size_t njobs, const uint64_t* bases_handles, const size_t* base_offsets, const void* const* d_scalars,
                              const size_t* ns, int scalars_are_montgomery, uint64_t* out_xyz_mont);
-int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv);   /* runs the callback once (host only) */
+int mh_marlin_probe_allgather(const void* send, size_t bytes, void* recv);  /* one all-gather through the registered transport (a caller's self-test of it) */
+
+/* ---- one process, several GPUs ------------------------------------------------------------------------------------------------
+ * The reference has ONE caller of Marlin::prove (/root/reference src/lib.rs:151-155) and parallelises inside the process (rayon,
+ * src/ahp/mod.rs:9-10).  A group is `world` contexts of THIS process -- one per listed device (a device may repeat: several ranks
+ * on one GPU, which is how the tests run it) -- joined by an in-process transport: host payloads meet in shared memory between
+ * rendezvous of the rank threads, device buffers are pulled peer-to-peer (hipMemcpyPeerAsync over xGMI, stream-ordered behind
+ * events).  No RCCL, no launcher, no second process.  mh_group_create makes and initialises the contexts and registers the
+ * transport on each (as mh_marlin_set_shard / _set_alltoall / _set_allgather_dev would); mh_group_run calls fn(rank, user) on `world`
+ * threads, thread r bound to context r (mh_ctx_set_current), and returns the first non-zero result: inside fn a rank uploads
+ * its SRS, indexes and proves with the ordinary entry points, and every rank's proof is the one-GPU proof.  mh_group_ctx gives
+ * a rank's context to a caller that runs its own threads.  A rank that does not reach a collective within MH_GROUP_TIMEOUT_S
+ * (default 300) fails it on the ranks that wait. */
+typedef struct mh_group* mh_group_t;
+typedef int (*mh_group_fn)(int rank, void* user);
+int mh_group_create(const int* device_ids, int world, mh_group_t* group_out);
+int mh_group_size(mh_group_t group);
+mh_ctx_t mh_group_ctx(mh_group_t group, int rank);
+int mh_group_run(mh_group_t group, mh_group_fn fn, void* user);
+int mh_group_destroy(mh_group_t group);
 
 /* ---- building blocks of the slice-sharded multi-GPU pipeline (src/ahp/prover.rs:351-366,532-535,655-688 are
  * the transforms it distributes) ----
@@ -305,7 +341,7 @@ typedef int (*mh_allgather_dev_fn)(const void* d_send, size_t bytes, void* d_rec
 int mh_marlin_set_allgather_dev(mh_allgather_dev_fn allgather_dev, void* user);
 /* Runs a registered device exchange once on the caller's device buffers and waits for it: which = 0 the all-to-all (bytes per
  * peer), 1 the device all-gather.  For a transport's self-test before the first proof. */
-int mh_marlin_test_exchange_dev(int which, const void* d_send, size_t bytes, void* d_recv);
+int mh_marlin_probe_exchange_dev(int which, const void* d_send, size_t bytes, void* d_recv);
 
 /* ---- native transport: RCCL called by the library itself (marlin_amd/csrc/rccl_native.h) --------------------------------
  * The three collectives of a sharded proof -- all-gather of partial points (src/lib.rs:172,193,213: one per PC::commit),
@@ -360,22 +396,20 @@ int mh_marlin_get_poly(uint64_t pk, const char* label, uint64_t* out, size_t cap
 int mh_prof_enable(int on);
 int mh_prof_reset(void);
 int mh_prof_get(int family, double* total_ms_out, uint64_t* launches_out);
-/* Device self-test of the 30-bit-limb base-field arithmetic used by the fixed-base MSM path against the 32-bit
- * Montgomery arithmetic: n pseudo-random operand pairs (field operations, XYZZ doubling / addition incl. the equal-x
- * path); *mismatches_out = number of operand pairs with any disagreement (0 expected). */
-int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out);
-/* Test hook: the nth (>= 1) request for device scratch memory from now on fails with MH_ENOMEM, as if the device had run out of
- * memory, whether or not that request would have had to allocate (0 disarms the hook); *calls_out (may be NULL) = the number of
- * such requests made so far.  How the tests make ONE rank of a sharded proof fail mid-prove: a rank that fails locally keeps
- * entering the collectives of the proof (with a meaningless payload) up to the next all-gather of partial points, whose error word
- * makes EVERY rank return non-zero from the same commit round -- the job fails, nobody hangs, the next proof can run.  Replaces
- * nothing in the reference (it has no FFI and no device memory). */
-int mh_debug_fail_scratch(int nth, uint64_t* calls_out);
-/* Test hook: on != 0 fills every device allocation the library makes from now on (scratch buffers, prover-key buffers) with 0xA5
- * bytes, so that a kernel reading memory nothing has written yet gets garbage for sure instead of whatever the heap held (usually
- * zeros -- the identity, the zero polynomial -- on a fresh process): tests/test_gpu_poisoned_allocations.py. */
-int mh_debug_poison_scratch(int on);
 
+/* ---- invariants of the MSM pipeline (diagnostics; off by default) -----------------------------------------------------------
+ * VariableBaseMSM::multi_scalar_mul (/root/reference src/lib.rs:172,193,213,292 via PC::commit / open_combinations) has exactly one
+ * right answer.  With level >= 1 (or the environment variable MH_CHECK at mh_init) every fixed-base MSM batch checks each stage's
+ * output against its input -- entries the scalars give = entries the split wrote = entries of the sorted lists, per partition;
+ * bucket sizes and starts consistent; every bucket, row / column sum and plane on the curve (buffers pre-filled with garbage);
+ * sum of rows = sum of columns = T plane; results on the curve -- and level 2 recomputes every list membership, every bucket (32-bit
+ * complete law) and, for bucket sets up to 2^17, the whole reduction on the host.  A violation makes the MSM call (and a proof
+ * that contains it) fail with MH_ECHECK naming the stage; mh_check_report returns the stage-by-stage text of the last checked
+ * batch and, in counts2, the number of batches checked and of violations since mh_init. */
+int mh_check_level(int level);
+int mh_check_report(char* out, size_t cap, uint64_t* counts2);
+
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,15 @@ SYMBOLS = {
     "mh_set_stream": (C.c_int, [C.c_void_p]),
     "mh_synchronize": (C.c_int, []),
     "mh_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "mh_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mh_ctx_set_current": (C.c_int, [C.c_void_p]),
+    "mh_ctx_get_current": (C.c_void_p, []),
+    "mh_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "mh_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "mh_group_size": (C.c_int, [C.c_void_p]),
+    "mh_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "mh_group_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mh_group_destroy": (C.c_int, [C.c_void_p]),
     "mh_curve_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "mh_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "mh_free": (C.c_int, [C.c_void_p]),
@@ -44,9 +53,6 @@ SYMBOLS = {
     "mh_bases_len": (C.c_int, [C.c_uint64, C.POINTER(C.c_size_t)]),
     "mh_bases_precompute": (C.c_int, [C.c_uint64, C.c_uint32]),
     "mh_msm_path_counts": (C.c_int, [_u64p, _u64p]),
-    "mh_selftest_fq30": (C.c_int, [C.c_uint64, C.c_uint64, _u64p]),
-    "mh_debug_fail_scratch": (C.c_int, [C.c_int, _u64p]),
-    "mh_debug_poison_scratch": (C.c_int, [C.c_int]),
     "mh_bases_table_info": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _u64p]),
     "mh_msm": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "mh_msm_dev": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
@@ -79,7 +85,7 @@ SYMBOLS = {
     "mh_marlin_set_alltoall": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mh_marlin_set_alltoall_mode": (C.c_int, [C.c_int]),
     "mh_marlin_set_allgather_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "mh_marlin_test_exchange_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mh_marlin_probe_exchange_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mh_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "mh_marlin_set_rccl": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "mh_marlin_rccl_sliced": (C.c_int, [C.c_int]),
@@ -88,7 +94,7 @@ SYMBOLS = {
     "mh_marlin_exchange_stats": (C.c_int, [_u64p, C.POINTER(C.c_double), C.c_int]),
     "mh_ntt_dist_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "mh_msm_batch_sliced_dev": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "mh_marlin_test_allgather": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mh_marlin_probe_allgather": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mh_marlin_get_poly": (C.c_int, [C.c_uint64, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mh_g2_bases_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, _u64p]),
     "mh_g2_srs_powers": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, _u64p]),
@@ -98,7 +104,18 @@ SYMBOLS = {
     "mh_prof_enable": (C.c_int, [C.c_int]),
     "mh_prof_reset": (C.c_int, []),
     "mh_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), _u64p]),
+    "mh_check_level": (C.c_int, [C.c_int]),
+    "mh_check_report": (C.c_int, [C.c_char_p, C.c_size_t, _u64p]),
 }
+# include/marlin_hip_testhooks.h: exported by libmarlin_hip[_bn254]_testhooks.so only (fault injection, device self-test); bound
+# when the loaded library has them -- a test that needs a hook runs with MARLIN_AMD_LIB pointing at the hooks library
+HOOK_SYMBOLS = {
+    "mh_selftest_fq30": (C.c_int, [C.c_uint64, C.c_uint64, _u64p]),
+    "mh_debug_fail_scratch": (C.c_int, [C.c_int, _u64p]),
+    "mh_debug_poison_scratch": (C.c_int, [C.c_int]),
+    "mh_debug_corrupt": (C.c_int, [C.c_int]),
+}
+HOOKS_LIB_PATH = os.path.join(_HERE, {"bls12_381": "libmarlin_hip_testhooks.so", "bn254": "libmarlin_hip_bn254_testhooks.so"}[CURVE])
 
 
 class MarlinHipError(RuntimeError):
@@ -122,6 +139,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in HOOK_SYMBOLS.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     cid, frl, fql, adic = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     lib.mh_curve_info(C.byref(cid), C.byref(frl), C.byref(fql), C.byref(adic))

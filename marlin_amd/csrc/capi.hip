@@ -6,7 +6,10 @@
 #include "msm.cuh"
 #include "msm_tree.cuh"
 #include "msm_fb.cuh"
+#include "msm_check.cuh"
 #include "msm_g2.cuh"
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include "ntt.cuh"
 #include "ntt30.cuh"
@@ -25,11 +28,16 @@ namespace mh {
 thread_local std::string g_err;
 int g_debug_fail_scratch = 0;
 int g_debug_poison_scratch = 0;
+int g_debug_corrupt = 0;
 uint64_t g_debug_scratch_calls = 0;
-Context& ctx() {
-  static Context c;
-  return c;
-}
+bool g_multi_ctx = false;
+// handles (base sets, prover keys) are unique across the process, not per context: one that reaches the wrong context (a binding's
+// finaliser running on another thread) is unknown there instead of naming somebody else's object
+std::atomic<uint64_t> g_next_handle{1};
+static thread_local Context* t_ctx = nullptr;
+// never destroyed: at process exit the HIP runtime may be gone before this library's statics
+Context& default_ctx() { static Context* c = new Context(); return *c; }
+Context& ctx() { return t_ctx ? *t_ctx : default_ctx(); }
 
 static Fr to_dev_fr(const HFr& h) {
   Fr r;
@@ -117,9 +125,8 @@ static int launch_pass(Context& c, const Fr* x, Fr* y, uint32_t log_n, uint32_t 
   return MH_OK;
 }
 
-static bool g_ntt_attr_done = false;
-static int ntt_set_attrs() {
-  if (g_ntt_attr_done) return MH_OK;
+static int ntt_set_attrs(Context& c) {
+  if (c.ntt_attr_done) return MH_OK;
   int lds = (int)ntt::pass_lds_bytes(ntt::MAX_B, ntt::MAX_LOGC);
   MH_HIP(hipFuncSetAttribute((const void*)ntt::pass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)ntt::pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -134,7 +141,7 @@ static int ntt_set_attrs() {
   MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<0, 1, 256, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30));
   MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<1, 1, 256, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30));
   MH_HIP(hipFuncSetAttribute((const void*)ntt30::pass30_kernel<2, 1, 256, 4, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds30));
-  g_ntt_attr_done = true;
+  c.ntt_attr_done = true;
   return MH_OK;
 }
 
@@ -153,7 +160,7 @@ int ntt_device_len(Context& c, const void* d_in, uint64_t in_len, void* d_out, u
     return MH_OK;
   }
   MH_TRY(ensure_twiddles(c, log_n));
-  MH_TRY(ntt_set_attrs());
+  MH_TRY(ntt_set_attrs(c));
   uint32_t bits[8];
   int np;
   plan_passes(log_n, bits, &np);
@@ -221,6 +228,13 @@ __global__ __launch_bounds__(256) void bases_check_kernel(const G1Affine* __rest
   bool same = true;
   for (int k = 0; k < Fq::N; k++) same = same && lhs.v[k] == rhs.v[k];
   if (!same) atomicAdd(bad, 1u);
+}
+// dst[i] = src[first + i * stride]: the bases of a strided slice as a contiguous vector (the skew fallback of msm_batch_strided_device)
+__global__ __launch_bounds__(256) void gather_strided_kernel(G1Affine* __restrict__ dst, const G1Affine* __restrict__ src, u64 first, u64 stride, u64 n) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const G1Affine p = g1_load_affine(src + first + i * stride);
+  ff_store(&dst[i].x, p.x); ff_store(&dst[i].y, p.y);
 }
 static int bases_validate(Context& c, const void* d_points, size_t n) {
   if (n == 0) return MH_OK;
@@ -318,9 +332,8 @@ __global__ __launch_bounds__(128) void g1_deserialize_kernel(const uint8_t* __re
 // --------------------------------------------------------------------------------
 // MSM driver
 // --------------------------------------------------------------------------------
-static bool g_msm_attr_done = false;
-static int msm_set_attrs() {
-  if (g_msm_attr_done) return MH_OK;
+static int msm_set_attrs(Context& c) {
+  if (c.msm_attr_done) return MH_OK;
   int lds = 32768 * 4;
   MH_HIP(hipFuncSetAttribute((const void*)msm::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -328,7 +341,7 @@ static int msm_set_attrs() {
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(msmfb::PLANE_THREADS * sizeof(msmfb::G1Xyzz30))));
-  g_msm_attr_done = true;
+  c.msm_attr_done = true;
   return MH_OK;
 }
 
@@ -502,6 +515,7 @@ struct FbRun {
       while ((1ull << lgown) < nbown) lgown++;
       rs.lgC = std::min<u32>(pshift, (lgown + 1) / 2);
       if (rs.lgC < 1) rs.lgC = 1;
+      if (rs.lgC > pshift) return fail(MH_EINVAL, "fixed-base MSM: partition narrower than a row of the bucket matrix");   // (window widths >= 4 never get here)
       rs.C = 1u << rs.lgC;
       rs.lgrpp = pshift - rs.lgC;
       rs.R_own = nbown >> rs.lgC;
@@ -552,10 +566,10 @@ struct FbRun {
     // the split runs on `s`, so the host's round trip (descriptors, block list) hides behind a kernel instead of idling the GPU
     // (one of the two host synchronisations per MSM batch; the other one carries the results).
     MH_TRY(ws.h_ptot.ensure((size_t)WT * 4));
-    const bool side_copy = c.copy_stream && c.copy_ev;
+    const bool side_copy = c.copy_stream && c.copy_ev[0] && c.copy_ev[1] && !(c.diag & 1u);
     if (side_copy) {
-      MH_HIP(hipEventRecord(c.copy_ev, s));
-      MH_HIP(hipStreamWaitEvent(c.copy_stream, c.copy_ev, 0));
+      MH_HIP(hipEventRecord(c.copy_ev[0], s));
+      MH_HIP(hipStreamWaitEvent(c.copy_stream, c.copy_ev[0], 0));
       MH_HIP(hipMemcpyAsync(ws.h_ptot.ptr, ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, c.copy_stream));
     }
     hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)ws.pc.ptr,
@@ -610,8 +624,8 @@ struct FbRun {
       MH_HIP(hipMemcpyAsync(ws.blk.ptr, ws.h_blk.ptr, blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, up));
     }
     if (side_copy) {
-      MH_HIP(hipEventRecord(c.copy_ev, c.copy_stream));
-      MH_HIP(hipStreamWaitEvent(s, c.copy_ev, 0));
+      MH_HIP(hipEventRecord(c.copy_ev[1], c.copy_stream));
+      MH_HIP(hipStreamWaitEvent(s, c.copy_ev[1], 0));
     }
     const msmfb::FbWin* fbw = (const msmfb::FbWin*)ws.desc.ptr;
     const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;
@@ -680,7 +694,7 @@ struct FbRun {
     ProfScope ps(c, PF_MSM_STAGES, s);
     hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw,
                        (const F::G1Aff30*)bs.d_table, (const u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr,
-                       (const u32*)ws.pend.ptr, (const u32*)(d_max + 1), (F::G1Xyzz30*)ws.buckets.ptr, nb, (u64)WB);
+                       (u32*)ws.pend.ptr, (const u32*)(d_max + 1), (F::G1Xyzz30*)ws.buckets.ptr, nb, (u64)WB);
     MH_HIP(hipGetLastError());
     // the caller's independent work (Context::side_job) goes to stream2 behind the accumulation: beside the reduction that follows
     if (c.side_job && s == c.stream && c.stream2 && c.side_ev[0] && c.side_ev[1]) {
@@ -751,10 +765,193 @@ struct FbRun {
     };
     std::vector<std::future<HG1>> fut(nj);
     WaitAll wait; 
-    for (int k = 1; k < nj; k++) fut[k] = host_pool().submit([combine, k] { return combine(k); });
+    const bool pool = !(c.diag & 2u);
+    for (int k = 1; k < nj && pool; k++) fut[k] = host_pool().submit([combine, k] { return combine(k); });
     wait.add(fut);
     out[0] = combine(0);
-    for (int k = 1; k < nj; k++) out[k] = fut[k].get();
+    for (int k = 1; k < nj; k++) out[k] = pool ? fut[k].get() : combine(k);
+    return check_result(s, out);
+  }
+
+  // ---- MH_CHECK: the invariants of msm_check.cuh, stage by stage (Context::Check) --------------------------------------------
+  bool chk_skip = false;                         // the batch left this path on the device (skew): nothing after the sort holds results
+  std::string chk_log;
+  int chk_fail(const std::string& stage, const std::string& what) {
+    c.chk.violations++;
+    chk_log += stage + ": VIOLATED: " + what + "\n";
+    c.chk.report = chk_log;
+    return fail(MH_ECHECK, "MH_CHECK: fixed-base MSM batch #" + std::to_string(c.chk.batches) + ", stage " + stage + ": " + what);
+  }
+  std::string chk_shape() const {
+    char b[256];
+    snprintf(b, sizeof(b), "batch #%llu: jobs %d, c %u, windows %u, partitions %u x %u buckets, own {%u, %u}, entries %llu, strided %d",
+             (unsigned long long)c.chk.batches, nj, bs.tab_c, W, nparts, nb, own.first, own.stride, (unsigned long long)ent,
+             (int)(!strides.empty() && strides[0] != 1));
+    return b;
+  }
+  // after sort(): the lists against the scalars
+  int check_sort(hipStream_t s) {
+    namespace K = msmchk;
+    c.chk.batches++;
+    chk_log = chk_shape() + "\n";
+    const size_t sums_b = 3 * (size_t)WT * sizeof(K::Sum), tot_b = 2 * (size_t)WT * 4, bad_b = 64;
+    MH_TRY(c.chk.d.ensure(sums_b + tot_b + bad_b)); MH_TRY(c.chk.h.ensure(sums_b + tot_b + bad_b + 8));
+    K::Sum* d_sum = (K::Sum*)c.chk.d.ptr; u32* d_tot = (u32*)((char*)c.chk.d.ptr + sums_b); u32* d_bad = d_tot + 2 * WT;
+    MH_HIP(hipMemsetAsync(c.chk.d.ptr, 0, sums_b + tot_b + bad_b, s));
+    u64 nmax = 0;
+    for (int k = 0; k < nj; k++) nmax = std::max<u64>(nmax, ns[k]);
+    const unsigned gx = (unsigned)std::min<u64>((nmax + 255) / 256, 2048);
+    hipLaunchKernelGGL(K::recode_kernel, dim3(gx, nj), dim3(256), 0, s, jobs, d_sum, W, win, is_mont, nparts, pshift, (u32)bs.n, own);
+    const msmfb::FbWin* fbw = (const msmfb::FbWin*)ws.desc.ptr;
+    hipLaunchKernelGGL(K::entries_kernel, dim3(64, WT), dim3(256), 0, s, fbw, (const u32*)ws.val.ptr, d_sum + WT);
+    hipLaunchKernelGGL(K::entries_kernel, dim3(64, WT), dim3(256), 0, s, fbw, (const u32*)ws.sorted.ptr, d_sum + 2 * WT);
+    hipLaunchKernelGGL(K::tot_kernel, dim3(WT), dim3(64), 0, s, (const u32*)ws.tot.ptr, (const u32*)ws.base.ptr, nb, d_tot);
+    if (c.chk.level >= 2)
+      hipLaunchKernelGGL(K::lists_kernel, dim3((unsigned)((WB + 127) / 128)), dim3(128), 0, s, fbw, jobs, (const u32*)ws.sorted.ptr, (const u32*)ws.base.ptr,
+                         (const u32*)ws.tot.ptr, nb, (u64)WB, nparts, pshift, W, win, is_mont, (u32)bs.n, d_bad);
+    MH_HIP(hipGetLastError());
+    char* h = (char*)c.chk.h.ptr;
+    MH_HIP(hipMemcpyAsync(h, c.chk.d.ptr, sums_b + tot_b + bad_b, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipMemcpyAsync(h + sums_b + tot_b + bad_b, ws.sums.ptr, 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    const K::Sum* hs = (const K::Sum*)h; const u32* ht = (const u32*)(h + sums_b); const u32* hb = ht + 2 * WT;
+    const u32 largest = *(const u32*)(h + sums_b + tot_b + bad_b);
+    chk_skip = largest > skew_limit;
+    u64 total = 0;
+    for (u32 gw = 0; gw < WT; gw++) {
+      const int k = (int)(gw / nparts);
+      if (alias[k] >= 0) continue;
+      const K::Sum &want = hs[gw], &sp = hs[WT + gw], &sc = hs[2 * WT + gw];
+      auto str = [](const K::Sum& x) { char b[96]; snprintf(b, sizeof(b), "(n %llu, sum %llu, xor %08x)", x.cnt, x.sum, x.x); return std::string(b); };
+      const std::string where = "job " + std::to_string(k) + " partition " + std::to_string(gw % nparts);
+      if (want.cnt != ptot[gw]) return chk_fail("count", where + ": the host read a partition total of " + std::to_string(ptot[gw]) + ", the scalars have " + std::to_string(want.cnt) + " owned non-zero digits there");
+      if (desc[gw].cnt != ptot[gw]) return chk_fail("descriptor", where + ": descriptor count " + std::to_string(desc[gw].cnt) + " != partition total " + std::to_string(ptot[gw]));
+      if (sp.cnt != want.cnt || sp.sum != want.sum || sp.x != want.x) return chk_fail("split", where + ": entries written " + str(sp) + " != entries the scalars give " + str(want));
+      if (sc.cnt != want.cnt || sc.sum != want.sum || sc.x != want.x) return chk_fail("scatter", where + ": sorted lists " + str(sc) + " are not a permutation of the split's entries " + str(sp));
+      if (ht[2 * gw] != ptot[gw]) return chk_fail("bucket sizes", where + ": sizes sum to " + std::to_string(ht[2 * gw]) + ", the window has " + std::to_string(ptot[gw]) + " entries");
+      if (ht[2 * gw + 1] != 0) return chk_fail("bucket starts", where + ": " + std::to_string(ht[2 * gw + 1]) + " bucket(s) do not start at the exclusive scan of the sizes");
+      total += want.cnt;
+    }
+    if (c.chk.level >= 2 && hb[0] != 0) {
+      char b[160]; snprintf(b, sizeof(b), "%u list entr(ies) recode to another bucket or sign; first: bucket slot %u, entry %08x", hb[0], hb[1], hb[2]);
+      return chk_fail("lists", b);
+    }
+    chk_log += "sort: ok (" + std::to_string(total) + " entries: scalars = split = sorted per partition; sizes and starts consistent" +
+               (c.chk.level >= 2 ? "; every entry recodes to its bucket" : "") + (chk_skip ? "; SKEWED: the batch leaves this path" : "") + ")\n";
+    // what the accumulation and the reduction are about to write starts as garbage that is no point of the curve
+    if (!chk_skip) {
+      MH_HIP(hipMemsetAsync(ws.buckets.ptr, 0xA5, WB * sizeof(msmfb::G1Xyzz30), s)); MH_HIP(hipMemsetAsync(ws.pend.ptr, 0xA5, WB * 4, s));
+      MH_HIP(hipMemsetAsync(ws.seg.ptr, 0xA5, (size_t)nj * rs.NS * sizeof(msmfb::G1Xyzz30), s));
+      MH_HIP(hipMemsetAsync(ws.win.ptr, 0xA5, (size_t)nj * rs.nplanes * sizeof(G1Xyzz), s));
+    }
+    c.chk.report = chk_log;
+    return MH_OK;
+  }
+  // after accum(): the buckets
+  int check_accum(hipStream_t s) {
+    namespace K = msmchk;
+    if (chk_skip) return MH_OK;
+    u32* d_bad = (u32*)c.chk.d.ptr;
+    MH_HIP(hipMemsetAsync(d_bad, 0, 64, s));
+    hipLaunchKernelGGL(K::buckets_kernel, dim3((unsigned)((WB + 63) / 64)), dim3(64), 0, s, (const msmfb::FbWin*)ws.desc.ptr, (const msmfb::G1Aff30*)bs.d_table,
+                       (const u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const msmfb::G1Xyzz30*)ws.buckets.ptr,
+                       (const u32*)ws.pend.ptr, nb, (u64)WB, nparts, own, c.chk.level >= 2 ? 1 : 0, d_bad);
+    MH_HIP(hipGetLastError());
+    u32* hb = (u32*)c.chk.h.ptr;
+    MH_HIP(hipMemcpyAsync(hb, d_bad, 64, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    auto where = [&](u32 gid) { return "job " + std::to_string(gid / nbt) + " bucket " + std::to_string(gid % nbt); };
+    if (hb[0]) return chk_fail("accumulate", std::to_string(hb[0]) + " owned bucket(s) are neither the identity nor on the curve; first: " + where(hb[1]));
+    if (hb[2]) return chk_fail("fix-up", std::to_string(hb[2]) + " owned bucket(s) still pending after the fix-up");
+    if (hb[3]) return chk_fail("accumulate", std::to_string(hb[3]) + " bucket(s) are not the sum of their list (32-bit complete law); first: " + where(hb[4]));
+    chk_log += std::string("accumulate: ok (every owned bucket on the curve, none pending") + (c.chk.level >= 2 ? "; every bucket equals the recomputed sum of its list" : "") + ")\n";
+    c.chk.report = chk_log;
+    return MH_OK;
+  }
+  // after reduce(): row / column sums and planes
+  int check_reduce(hipStream_t s) {
+    namespace K = msmchk;
+    if (chk_skip) return MH_OK;
+    const size_t rc_b = (size_t)2 * nj * sizeof(G1Xyzz);
+    MH_TRY(c.chk.d.ensure(128 + rc_b)); MH_TRY(c.chk.h.ensure(128 + rc_b));
+    u32* d_bad = (u32*)c.chk.d.ptr; G1Xyzz* d_rc = (G1Xyzz*)((char*)c.chk.d.ptr + 128);
+    MH_HIP(hipMemsetAsync(d_bad, 0, 128, s));
+    const u64 nsum = (u64)nj * rs.NS, npl = (u64)nj * rs.nplanes;
+    hipLaunchKernelGGL(K::sums_kernel, dim3((unsigned)((nsum + 63) / 64)), dim3(64), 0, s, (const msmfb::G1Xyzz30*)ws.seg.ptr, nsum, d_bad);
+    hipLaunchKernelGGL(K::planes_kernel, dim3((unsigned)((npl + 63) / 64)), dim3(64), 0, s, (const G1Xyzz*)ws.win.ptr, npl, d_bad + 8);
+    hipLaunchKernelGGL(K::rowcol_kernel, dim3(2, (unsigned)nj), dim3(msmfb::PLANE_THREADS), msmfb::PLANE_THREADS * sizeof(msmfb::G1Xyzz30), s,
+                       (const msmfb::G1Xyzz30*)ws.seg.ptr, d_rc, rs);
+    MH_HIP(hipGetLastError());
+    char* h = (char*)c.chk.h.ptr;
+    MH_HIP(hipMemcpyAsync(h, c.chk.d.ptr, 128 + rc_b, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    const u32* hb = (const u32*)h;
+    if (hb[0]) return chk_fail("row / column sums", std::to_string(hb[0]) + " sum(s) off the curve; first: job " + std::to_string(hb[1] / rs.NS) + " sum " + std::to_string(hb[1] % rs.NS));
+    if (hb[8]) return chk_fail("planes", std::to_string(hb[8]) + " plane(s) off the curve; first: job " + std::to_string(hb[9] / rs.nplanes) + " plane " + std::to_string(hb[9] % rs.nplanes));
+    chk_rowcol.assign(2 * nj, HG1::identity());
+    auto xyzz = [](const char* p) {
+      HFq X, Y, ZZ, ZZZ;
+      memcpy(X.v, p, FQ_B); memcpy(Y.v, p + FQ_B, FQ_B); memcpy(ZZ.v, p + 2 * FQ_B, FQ_B); memcpy(ZZZ.v, p + 3 * FQ_B, FQ_B);
+      return HG1::from_xyzz(X, Y, ZZ, ZZZ);
+    };
+    for (int k = 0; k < nj; k++) {
+      const HG1 rows = xyzz(h + 128 + (size_t)(2 * k) * sizeof(G1Xyzz)), cols = xyzz(h + 128 + (size_t)(2 * k + 1) * sizeof(G1Xyzz));
+      if (!rows.add(cols.neg()).is_identity()) return chk_fail("row / column sums", "job " + std::to_string(k) + ": the rows and the columns do not sum to the same point");
+      chk_rowcol[2 * k] = rows;
+    }
+    chk_log += "reduce: ok (every sum and plane on the curve; sum of rows = sum of columns)\n";
+    c.chk.report = chk_log;
+    return MH_OK;
+  }
+  std::vector<HG1> chk_rowcol;
+  // in finish(): the results
+  int check_result(hipStream_t s, const HG1* out) {
+    if (c.chk.level == 0 || chk_skip) return MH_OK;
+    namespace K = msmchk;
+    const size_t npl = rs.nplanes;
+    const uint64_t* sums_h = (const uint64_t*)ws.h_out.ptr;
+    auto on_curve = [](const HG1& p) {
+      if (p.is_identity()) return true;
+      const HFq z2 = p.Z.sqr(), z6 = z2.sqr() * z2;
+      return p.Y.sqr() == p.X.sqr() * p.X + HFq::from_u64(hostff::G1_B) * z6;
+    };
+    for (int k = 0; k < nj; k++) {
+      // the T plane is the sum of all rows
+      const uint64_t* p = sums_h + ((size_t)k * npl + (npl - 1)) * XYZZ_L;
+      HFq X, Y, ZZ, ZZZ;
+      memcpy(X.v, p, FQ_B); memcpy(Y.v, p + FQ_L, FQ_B); memcpy(ZZ.v, p + 2 * FQ_L, FQ_B); memcpy(ZZZ.v, p + 3 * FQ_L, FQ_B);
+      if (!HG1::from_xyzz(X, Y, ZZ, ZZZ).add(chk_rowcol[2 * k].neg()).is_identity()) return chk_fail("planes", "job " + std::to_string(k) + ": the T plane is not the sum of the rows");
+      if (!on_curve(out[k])) return chk_fail("combine", "job " + std::to_string(k) + ": the result is not on the curve");
+    }
+    bool full = false;
+    if (c.chk.level >= 2 && (u64)nj * nbt <= (1ull << 17)) {
+      // the whole reduction again, the classical way, on the host: sum_b (b + 1) B_b over the owned buckets by running sums
+      full = true;
+      const size_t nbk = (size_t)nj * nbt;
+      MH_TRY(c.chk.d.ensure(nbk * sizeof(G1Xyzz)));
+      std::vector<uint64_t> hb(nbk * XYZZ_L);
+      // (buckets of other ranks' partitions were never written: read as whatever they hold, never used below)
+      hipLaunchKernelGGL(K::to_std_kernel, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, s, (const msmfb::G1Xyzz30*)ws.buckets.ptr, (G1Xyzz*)c.chk.d.ptr, (u64)nbk);
+      MH_HIP(hipGetLastError());
+      MH_HIP(hipMemcpyAsync(hb.data(), c.chk.d.ptr, nbk * sizeof(G1Xyzz), hipMemcpyDeviceToHost, s));
+      MH_HIP(hipStreamSynchronize(s));
+      for (int k = 0; k < nj; k++) {
+        HG1 run = HG1::identity(), acc = HG1::identity();
+        for (u32 b = nbt; b-- > 0;) {
+          const u32 v = b >> pshift;
+          if (v % own.stride == own.first) {
+            const uint64_t* q = hb.data() + ((size_t)k * nbt + b) * XYZZ_L;
+            HFq X, Y, ZZ, ZZZ;
+            memcpy(X.v, q, FQ_B); memcpy(Y.v, q + FQ_L, FQ_B); memcpy(ZZ.v, q + 2 * FQ_L, FQ_B); memcpy(ZZZ.v, q + 3 * FQ_L, FQ_B);
+            run = run.add(HG1::from_xyzz(X, Y, ZZ, ZZZ));
+          }
+          acc = acc.add(run);
+        }
+        if (!acc.add(out[k].neg()).is_identity()) return chk_fail("reduce + combine", "job " + std::to_string(k) + ": the result is not sum (b + 1) B_b of the device's buckets (running sums on the host)");
+      }
+    }
+    chk_log += std::string("result: ok (T plane = sum of rows; results on the curve") + (full ? "; results = running-sum reduction of the buckets on the host" : "") + ")\n";
+    c.chk.report = chk_log;
     return MH_OK;
   }
 };
@@ -777,8 +974,22 @@ static int msm_fb_pipeline(Context& c, const BaseSet& bs, int nj, const size_t* 
   }
   MH_TRY(A.prepare(is_mont, shard));
   partial = A.partial;
+  const bool chk = c.chk.level > 0;
+  const int hurt = g_debug_corrupt;             // test hook: damage this batch's own data after one stage, once
+  g_debug_corrupt = 0;
   MH_TRY(A.sort(s0));
-  MH_TRY(A.accum(s0)); MH_TRY(A.reduce(s0));
+  if (hurt == 1 && A.ent) { const u32 x = 0x00000100u; u32 e = 0; u32* p = (u32*)c.fbws.sorted.ptr + A.ent / 2;
+    MH_HIP(hipMemcpyAsync(&e, p, 4, hipMemcpyDeviceToHost, s0)); MH_HIP(hipStreamSynchronize(s0)); e ^= x;
+    MH_HIP(hipMemcpyAsync(p, &e, 4, hipMemcpyHostToDevice, s0)); MH_HIP(hipStreamSynchronize(s0)); }
+  if (chk) MH_TRY(A.check_sort(s0));
+  MH_TRY(A.accum(s0));
+  if (hurt == 2) MH_HIP(hipMemsetAsync((msmfb::G1Xyzz30*)c.fbws.buckets.ptr + 5, 0x5A, sizeof(msmfb::G1Xyzz30), s0));
+  if (hurt == 3) {            // the heaviest bucket and its neighbour certainly differ
+    MH_HIP(hipMemcpyAsync((msmfb::G1Xyzz30*)c.fbws.buckets.ptr + 1, (msmfb::G1Xyzz30*)c.fbws.buckets.ptr, sizeof(msmfb::G1Xyzz30), hipMemcpyDeviceToDevice, s0)); }
+  if (chk) MH_TRY(A.check_accum(s0));
+  MH_TRY(A.reduce(s0));
+  if (hurt == 4) MH_HIP(hipMemcpyAsync((G1Xyzz*)c.fbws.win.ptr + 1, (G1Xyzz*)c.fbws.win.ptr, sizeof(G1Xyzz), hipMemcpyDeviceToDevice, s0));
+  if (chk) MH_TRY(A.check_reduce(s0));
   MH_TRY(A.finish(s0, out));
   if (A.skewed) { skewed = true; partial = false; }
   return MH_OK;
@@ -860,7 +1071,7 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
   // process in groups of at most MAX_JOBS non-empty jobs
   std::vector<int> live;
   for (int j = 0; j < njobs_in; j++) if (ns[j]) { if (ns[j] >= (1ull << 31)) return fail(MH_EINVAL, "msm: n must be < 2^31"); live.push_back(j); }
-  MH_TRY(msm_set_attrs());
+  MH_TRY(msm_set_attrs(c));
   hipStream_t s = c.stream;
   // MH_MSM_ALGO = xyzz | tree forces that accumulation on the variable-base path (and disables the fixed-base tables)
   static const int forced = [] { const char* e = getenv("MH_MSM_ALGO"); return !e ? 0 : (std::string(e) == "tree" ? 2 : 1); }();
@@ -1016,7 +1227,7 @@ int msm_batch_strided_device(Context& c, const BaseSet& bs, int njobs, const siz
       if (first[j] + (ns[j] - 1) * stride >= bs.n) return fail(MH_EINVAL, "strided MSM: selection reaches past the base set");
       live.push_back(j);
     }
-  MH_TRY(msm_set_attrs());
+  MH_TRY(msm_set_attrs(c));
   size_t g_next = 0;
   for (size_t g0 = 0; g0 < live.size(); g0 = g_next) {
     int nj = 0;
@@ -1032,14 +1243,29 @@ int msm_batch_strided_device(Context& c, const BaseSet& bs, int njobs, const siz
     std::vector<HG1> res(nj);
     bool skewed = false, part = false;
     MH_TRY(msm_fb_pipeline(c, bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, nullptr, part, st.data()));
-    // A strided slice has no variable-base fallback (its bases are not a contiguous range).  A skewed batch -- heavily repeated
-    // digits, e.g. a round polynomial with one dominant coefficient value -- is run again as it is with the limit at 2^22 entries
-    // per bucket: one thread then walks a long list (seconds for millions of entries), but a valid sliced proof completes on
-    // every rank, as the replicated and the one-GPU prover do on the same instance.  Beyond that it is refused.
-    if (skewed) MH_TRY(msm_fb_pipeline(c, bs, nj, offs.data(), sc.data(), nn.data(), is_mont, res.data(), skewed, nullptr, part, st.data(), 1u << 22));
-    if (skewed)
-      return fail(MH_EINVAL, "strided MSM: one bucket holds more than 2^22 entries (almost all digits equal); gather the "
-                             "slice into a contiguous vector and use mh_msm_batch_dev, whose variable-base path handles skewed inputs");
+    // A skewed batch -- heavily repeated digits, e.g. a round polynomial with one dominant coefficient value -- leaves the
+    // fixed-base path like a contiguous one does: the bases of every slice are gathered into a contiguous scratch vector and the
+    // group takes the variable-base path, whose pair tree has no long per-thread list.  (Round 5 re-ran the fixed-base pipeline with
+    // the per-bucket limit at 2^22 instead: one thread then walked a list of millions for seconds while the peer ranks sat in the
+    // next collective -- ADVICE r05.)  A valid sliced proof completes on every rank, as the replicated and the one-GPU prover do.
+    if (skewed) {
+      size_t tot = 0;
+      for (int k = 0; k < nj; k++) tot += nn[k];
+      MH_TRY(c.msm_gather.ensure(tot * PT_B));
+      std::vector<const void*> gb(nj);
+      size_t o = 0;
+      for (int k = 0; k < nj; k++) {
+        gb[k] = (const char*)c.msm_gather.ptr + o * PT_B;
+        hipLaunchKernelGGL(gather_strided_kernel, dim3((unsigned)((nn[k] + 255) / 256)), dim3(256), 0, c.stream, (G1Affine*)c.msm_gather.ptr + o,
+                           (const G1Affine*)bs.d_points, (u64)offs[k], (u64)stride, (u64)nn[k]);
+        o += nn[k];
+      }
+      MH_HIP(hipGetLastError());
+      std::vector<uint64_t> xyz((size_t)XYZ_L * nj);
+      MH_TRY(msm_batch_device(c, nj, gb.data(), sc.data(), nn.data(), is_mont, xyz.data(), nullptr, nullptr));
+      for (int k = 0; k < nj; k++) memcpy(out_xyz + XYZ_L * live[g0 + k], xyz.data() + XYZ_L * k, XYZ_L * 8);
+      continue;
+    }
     c.n_fb_groups++;
     for (int k = 0; k < nj; k++) {
       uint64_t* o = out_xyz + XYZ_L * live[g0 + k];
@@ -1063,7 +1289,7 @@ static int msm_g2_device(Context& c, const G2Affine* d_bases, const Fr* d_scalar
   const size_t OW = 4 * Fq::N + 1;
   if (n == 0) { memset(out_words, 0, OW * 4); out_words[OW - 1] = 1; return MH_OK; }
   if (n >= (1ull << 28)) return fail(MH_EINVAL, "mh_g2_msm: n must be < 2^28");
-  MH_TRY(msm_set_attrs());
+  MH_TRY(msm_set_attrs(c));
   hipStream_t s = c.stream;
   msm::Plan p = msm::make_plan(n);
   msm::Jobs jobs;
@@ -1120,9 +1346,8 @@ static int g2_validate(Context& c, const void* d_points, size_t n) {
 // --------------------------------------------------------------------------------
 // SRS generation (KZG10::setup's powers, known-tau test SRS)
 // --------------------------------------------------------------------------------
-static void* g_srs_table = nullptr;   // G1Affine[32][256]
-static int ensure_srs_table(Context& c) {
-  if (g_srs_table) return MH_OK;
+static int ensure_srs_table(Context& c) {       // Context::srs_table: G1Affine[32][256]
+  if (c.srs_table) return MH_OK;
   // T[w][d] = [d * 256^w] G on the host, batch-normalised
   uint64_t gx[FQ_L], gy[FQ_L];
   hostff::g1_generator_canonical(gx, gy);
@@ -1152,8 +1377,8 @@ static int ensure_srs_table(Context& c) {
     HFq x = jac[i].X * zi2, y = jac[i].Y * zi2 * zi;
     memcpy(&host[i * AFF_L], x.v, FQ_B); memcpy(&host[i * AFF_L + FQ_L], y.v, FQ_B);
   }
-  MH_HIP(hipMalloc(&g_srs_table, host.size() * 8));
-  MH_HIP(hipMemcpyAsync(g_srs_table, host.data(), host.size() * 8, hipMemcpyHostToDevice, c.stream));
+  MH_HIP(hipMalloc(&c.srs_table, host.size() * 8));
+  MH_HIP(hipMemcpyAsync(c.srs_table, host.data(), host.size() * 8, hipMemcpyHostToDevice, c.stream));
   MH_HIP(hipStreamSynchronize(c.stream));
   return MH_OK;
 }
@@ -1165,7 +1390,7 @@ int srs_powers_device(Context& c, const uint64_t* tau_mont, const uint64_t* scal
   memcpy(tau.v, tau_mont, 32); memcpy(scale.v, scale_mont, 32);
   if (n == 0) return MH_OK;
   hipLaunchKernelGGL(srs::powers_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c.stream, (G1Affine*)d_out,
-                     (const G1Affine*)g_srs_table, tau, scale, (u64)n, (u64)first);
+                     (const G1Affine*)c.srs_table, tau, scale, (u64)n, (u64)first);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -1177,20 +1402,14 @@ int srs_powers_device(Context& c, const uint64_t* tau_mont, const uint64_t* scal
 // =====================================================================================
 #define LOCKED_CTX()                                                 \
   Context& c = ctx();                                                \
-  std::lock_guard<std::recursive_mutex> _lk(c.mu);                   \
+  CtxLock _lk(c);                                                    \
   if (!c.inited) return fail(MH_ENOINIT, "mh_init has not been called")
 
 extern "C" {
 
 const char* mh_last_error(void) { return g_err.c_str(); }
 
-int mh_init(int device_id) {
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  if (c.inited) {
-    if (c.device == device_id) return MH_OK;
-    return fail(MH_EINVAL, "mh_init: already initialised on another device (one process drives one GPU)");
-  }
+static int ctx_init(Context& c, int device_id) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0) return fail(MH_ENODEV, "no HIP device visible");
@@ -1204,34 +1423,53 @@ int mh_init(int device_id) {
   c.own_stream = true;
   MH_HIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
   MH_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
-  MH_HIP(hipEventCreateWithFlags(&c.copy_ev, hipEventDisableTiming));
+  for (auto& e : c.copy_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  { const char* e = getenv("MH_DIAG"); c.diag = e ? (unsigned)atoi(e) : 0u; }
   for (auto& e : c.side_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   c.device = device_id;
   c.num_simds = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+  { const char* e = getenv("MH_CHECK"); if (e) c.chk.level = atoi(e); }
   c.inited = true;
   return MH_OK;
+}
+
+// the calling thread's current context: the default context unless mh_ctx_set_current chose another (whose device is fixed)
+int mh_init(int device_id) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (c.inited) {
+    if (c.device == device_id) return MH_OK;
+    return fail(MH_EINVAL, "mh_init: this context is already initialised on another device (mh_ctx_create makes a context for another GPU)");
+  }
+  return ctx_init(c, device_id);
 }
 
 extern "C" int mh_marlin_release_all(void);
 int mh_init_devices(const int* device_ids, int n_devices) {
   if (!device_ids || n_devices != 1)
-    return fail(MH_EINVAL, "mh_init_devices: one process drives exactly one GPU (launch one process per GPU; see mh_marlin_set_shard)");
+    return fail(MH_EINVAL, "mh_init_devices: a context drives exactly one GPU (one process per GPU with mh_marlin_set_rccl, or one context per GPU "
+                           "in one process: mh_ctx_create + mh_marlin_set_local_group)");
   return mh_init(device_ids[0]);
 }
 
-int mh_shutdown(void) {
-  Context& c = ctx();
+static int ctx_shutdown(Context& c) {
   std::lock_guard<std::recursive_mutex> lk(c.mu);
   if (!c.inited) return MH_OK;
+  if (g_multi_ctx) (void)hipSetDevice(c.device);
   (void)hipStreamSynchronize(c.stream);
-  (void)mh_marlin_release_all();
+  {                                      // prover keys, the native transport: they belong to THIS context, whichever thread shuts it down
+    Context* saved = t_ctx;
+    t_ctx = &c;
+    (void)mh_marlin_release_all();
+    t_ctx = saved;
+  }
   if (c.tw) (void)hipFree(c.tw);
   if (c.tw30) (void)hipFree(c.tw30);
   if (c.tw30s) (void)hipFree(c.tw30s);
   c.tw = nullptr; c.tw30 = nullptr; c.tw30s = nullptr; c.tw_log = 0;
   c.ntt_tmp[0].release(); c.ntt_tmp[1].release(); c.io.release();
   c.msm_dig.release(); c.msm_sorted.release(); c.msm_bh.release(); c.msm_tot.release(); c.msm_base.release();
-  c.msm_buckets.release(); c.msm_seg.release(); c.msm_win.release(); c.msm_pend.release();
+  c.msm_buckets.release(); c.msm_seg.release(); c.msm_win.release(); c.msm_pend.release(); c.msm_gather.release();
   for (auto& b : c.tr_off) b.release(); for (auto& b : c.tr_cnt) b.release(); for (auto& b : c.tr_p) b.release();
   c.tr_sums.release(); c.tr_ob.release(); c.tr_pre.release(); c.tr_prod.release(); c.tr_scr.release();
   for (auto& kv : c.bases) { if (kv.second.d_points) (void)hipFree(kv.second.d_points); if (kv.second.d_table) (void)hipFree(kv.second.d_table); }
@@ -1239,23 +1477,71 @@ int mh_shutdown(void) {
   for (auto& kv : c.g2_bases) if (kv.second.d_points) (void)hipFree(kv.second.d_points);
   c.g2_bases.clear();
   c.fbws.release_all();
+  c.chk.d.release(); c.chk.h.release();
   for (auto& kv : c.ntt_dist_tabs) kv.second.release();
   c.ntt_dist_tabs.clear();
   c.ntt_dist_buf[0].release(); c.ntt_dist_buf[1].release(); c.sl_send.release(); c.sl_recv.release();
   if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
   if (c.copy_stream) { (void)hipStreamSynchronize(c.copy_stream); (void)hipStreamDestroy(c.copy_stream); c.copy_stream = nullptr; }
-  if (c.copy_ev) { (void)hipEventDestroy(c.copy_ev); c.copy_ev = nullptr; }
+  for (auto& e : c.copy_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   for (auto& e : c.side_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   c.side_job = nullptr; c.side_ran = false;
-  if (g_srs_table) { (void)hipFree(g_srs_table); g_srs_table = nullptr; }
+  if (c.srs_table) { (void)hipFree(c.srs_table); c.srs_table = nullptr; }
   for (auto& r : c.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   c.prof.clear();
   for (auto e : c.ev_pool) (void)hipEventDestroy(e);
   c.ev_pool.clear();
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
   c.stream = nullptr; c.own_stream = false;
+  c.ntt_attr_done = c.msm_attr_done = false;
   c.inited = false; c.device = -1;
   return MH_OK;
+}
+int mh_shutdown(void) { return ctx_shutdown(ctx()); }
+
+// ---- contexts ---------------------------------------------------------------------------------------------------------------
+// The reference proves inside ONE process with rayon threads (/root/reference src/ahp/mod.rs:9-10, benches/bench.rs:1-3).  A
+// context per GPU (or several per GPU) lets one host process do the same here: every context has its own streams, workspaces,
+// base sets, prover keys and shard configuration; a thread binds itself to one with mh_ctx_set_current and then uses the
+// ordinary entry points.  Handles (bases, prover keys, device pointers) belong to the context that made them.
+static std::mutex g_ctx_mu;
+static std::vector<Context*>& all_ctx() { static std::vector<Context*>* v = new std::vector<Context*>(); return *v; }
+int mh_ctx_create(int device_id, mh_ctx_t* ctx_out) {
+  if (!ctx_out) return fail(MH_EINVAL, "mh_ctx_create: null output");
+  *ctx_out = nullptr;
+  Context* c = new Context();
+  g_multi_ctx = true;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  const int rc = ctx_init(*c, device_id);
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc != MH_OK) { delete c; return rc; }
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); all_ctx().push_back(c); }
+  *ctx_out = reinterpret_cast<mh_ctx_t>(c);
+  return MH_OK;
+}
+static Context* find_ctx(mh_ctx_t h) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  for (Context* c : all_ctx()) if (reinterpret_cast<mh_ctx_t>(c) == h) return c;
+  return nullptr;
+}
+int mh_ctx_set_current(mh_ctx_t h) {
+  if (!h) { t_ctx = nullptr; if (g_multi_ctx && default_ctx().inited) (void)hipSetDevice(default_ctx().device); return MH_OK; }
+  Context* c = find_ctx(h);
+  if (!c) return fail(MH_EINVAL, "mh_ctx_set_current: unknown context");
+  t_ctx = c;
+  MH_HIP(hipSetDevice(c->device));
+  return MH_OK;
+}
+mh_ctx_t mh_ctx_get_current(void) { return reinterpret_cast<mh_ctx_t>(t_ctx); }
+int mh_ctx_destroy(mh_ctx_t h) {
+  Context* c = find_ctx(h);
+  if (!c) return fail(MH_EINVAL, "mh_ctx_destroy: unknown context");
+  const int rc = ctx_shutdown(*c);
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); auto& v = all_ctx(); v.erase(std::find(v.begin(), v.end(), c)); }
+  if (t_ctx == c) t_ctx = nullptr;
+  delete c;
+  return rc;
 }
 
 int mh_set_stream(void* hip_stream) {
@@ -1400,7 +1686,7 @@ int mh_bases_upload(int curve, const uint64_t* xy, size_t n, uint64_t* handle_ou
     int rc = bases_validate(c, b.d_points, n);
     if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
   }
-  uint64_t h = c.next_handle++;
+  uint64_t h = g_next_handle++;
   c.bases[h] = b;
   *handle_out = h;
   return MH_OK;
@@ -1433,7 +1719,7 @@ int mh_bases_upload_serialized(int curve, const uint8_t* bytes, size_t n, int co
                              "(SerializationError::InvalidData: coordinate >= p, x^3 + b not a square, bad flags, or the identity)");
     }
   }
-  uint64_t h = c.next_handle++;
+  uint64_t h = g_next_handle++;
   c.bases[h] = b;
   *handle_out = h;
   return MH_OK;
@@ -1452,7 +1738,7 @@ int mh_bases_from_dev(int curve, const void* d_xy, size_t n, uint64_t* handle_ou
     int rc = bases_validate(c, b.d_points, n);
     if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
   }
-  uint64_t h = c.next_handle++;
+  uint64_t h = g_next_handle++;
   c.bases[h] = b;
   *handle_out = h;
   return MH_OK;
@@ -1471,7 +1757,7 @@ int mh_srs_powers(int curve, const uint64_t* tau_mont, const uint64_t* scale_mon
     if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
     MH_HIP(hipStreamSynchronize(c.stream));
   }
-  uint64_t h = c.next_handle++;
+  uint64_t h = g_next_handle++;
   c.bases[h] = b;
   *handle_out = h;
   return MH_OK;
@@ -1638,7 +1924,7 @@ int mh_g2_bases_upload(int curve, const uint64_t* xy, size_t n, uint64_t* handle
     int rc = g2_validate(c, b.d_points, n);
     if (rc != MH_OK) { (void)hipFree(b.d_points); return rc; }
   }
-  uint64_t h = c.next_handle++;
+  uint64_t h = g_next_handle++;
   c.g2_bases[h] = b;
   *handle_out = h;
   return MH_OK;
@@ -1677,7 +1963,7 @@ int mh_g2_srs_powers(int curve, const uint64_t* gen_xy, const uint64_t* tau_mont
     if (le != hipSuccess || ce != hipSuccess || se != hipSuccess) { (void)hipFree(b.d_points); return fail(MH_EHIP, "mh_g2_srs_powers: kernel failed"); }
     if (nz) { (void)hipFree(b.d_points); return fail(MH_EINVAL, "mh_g2_srs_powers: a power is the identity (tau or scale is zero)"); }
   }
-  uint64_t h = c.next_handle++;
+  uint64_t h = g_next_handle++;
   c.g2_bases[h] = b;
   *handle_out = h;
   return MH_OK;
@@ -1715,6 +2001,22 @@ int mh_g2_msm(uint64_t handle, size_t base_offset, const uint64_t* scalars, int 
   return MH_OK;
 }
 
+// MH_CHECK at run time: 0 = off, 1 = the cheap invariants of every fixed-base MSM batch, 2 = plus a second, independent computation
+// of every bucket list, every bucket and (small bucket sets) the result (msm_check.cuh).  A violation fails the call with MH_ECHECK.
+int mh_check_level(int level) {
+  LOCKED_CTX();
+  if (level < 0 || level > 2) return fail(MH_EINVAL, "mh_check_level: level must be 0, 1 or 2");
+  c.chk.level = level;
+  return MH_OK;
+}
+// text of the last checked batch, stage by stage (NUL-terminated, truncated to cap); counts2 (may be NULL): batches checked, violations
+int mh_check_report(char* out, size_t cap, uint64_t* counts2) {
+  LOCKED_CTX();
+  if (out && cap) snprintf(out, cap, "%s", c.chk.report.c_str());
+  if (counts2) { counts2[0] = c.chk.batches; counts2[1] = c.chk.violations; }
+  return MH_OK;
+}
+
 int mh_prof_enable(int on) {
   LOCKED_CTX();
   c.prof_on = on != 0;
@@ -1738,54 +2040,6 @@ int mh_prof_reset(void) {
   for (int i = 0; i < PF_COUNT; i++) { c.prof_ms[i] = 0; c.prof_n[i] = 0; }
   return MH_OK;
 }
-// Test hook: the nth (>= 1) request for device scratch from now on fails with MH_ENOMEM (0 disarms); calls_out (may be NULL)
-// receives the number of such requests the library has made so far.
-int mh_debug_fail_scratch(int nth, uint64_t* calls_out) {
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  if (nth < 0) return fail(MH_EINVAL, "mh_debug_fail_scratch: nth must be >= 0");
-  g_debug_fail_scratch = nth;
-  if (calls_out) *calls_out = g_debug_scratch_calls;
-  return MH_OK;
-}
-// Test hook: on != 0 fills every device allocation made from now on (scratch buffers, prover-key buffers) with 0xA5 bytes
-int mh_debug_poison_scratch(int on) {
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  g_debug_poison_scratch = on;
-  return MH_OK;
-}
-int mh_selftest_fq30(uint64_t n, uint64_t seed, uint64_t* mismatches_out) {
-  LOCKED_CTX();
-  if (!mismatches_out) return fail(MH_EINVAL, "mh_selftest_fq30: null output");
-  if (n == 0 || n > (1ull << 26)) return fail(MH_EINVAL, "mh_selftest_fq30: n must be in [1, 2^26]");
-  // operands: xorshift words with the top limb masked below 2^28 (any value; the kernel reduces them below p)
-  std::vector<u32> h((size_t)(n + 1) * (FQ_L * 2));
-  uint64_t x = seed * 0x9e3779b97f4a7c15ull + 0x1234567ull;
-  for (size_t i = 0; i < h.size(); i++) {
-    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-    h[i] = (u32)(x >> 16);
-    if (i % (FQ_L * 2) == FQ_L * 2 - 1) h[i] &= 0x0fffffffu;
-  }
-  // a few structured operands: 0, 1, small values, all-ones limbs
-  for (size_t k = 0; k < std::min<size_t>(n + 1, 6); k++) {
-    u32* e = h.data() + k * (FQ_L * 2);
-    for (size_t l = 0; l < FQ_L * 2; l++) e[l] = k == 5 ? (l == FQ_L * 2 - 1 ? 0x0fffffffu : 0xffffffffu) : 0;
-    if (k >= 1 && k < 5) e[0] = (u32)k;
-  }
-  MH_TRY(c.io.ensure(h.size() * 4 + 64));
-  u32* d_bad = (u32*)((char*)c.io.ptr + h.size() * 4);
-  MH_HIP(hipMemcpyAsync(c.io.ptr, h.data(), h.size() * 4, hipMemcpyHostToDevice, c.stream));
-  MH_HIP(hipMemsetAsync(d_bad, 0, 4, c.stream));
-  hipLaunchKernelGGL(msmfb::selftest30_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, c.stream, (const Fq*)c.io.ptr, (u64)n, d_bad);
-  MH_HIP(hipGetLastError());
-  u32 bad = 0;
-  MH_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c.stream));
-  MH_HIP(hipStreamSynchronize(c.stream));
-  *mismatches_out = bad;
-  return MH_OK;
-}
-
 int mh_prof_get(int family, double* total_ms_out, uint64_t* launches_out) {
   LOCKED_CTX();
   if (family < 0 || family >= PF_COUNT) return fail(MH_EINVAL, "mh_prof_get: bad family");

@@ -1,12 +1,14 @@
-// Process-wide device context of libmarlin_hip.so: one GPU, one stream, cached
-// twiddle table, scratch buffers, uploaded base sets, HIP-event profiling.
+// Device contexts of libmarlin_hip.so: per context one GPU, its streams, cached twiddle table, scratch buffers, uploaded base sets,
+// prover keys, shard configuration and HIP-event profiling.
 #pragma once
 #include <cstdlib>
 #include <functional>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -42,6 +44,9 @@ inline int fail(int code, const std::string& msg) {
 extern int g_debug_poison_scratch;        // != 0: every fresh device allocation is filled with 0xA5 bytes (mh_debug_poison_scratch): a read of
                                           // memory nothing has written yet then returns garbage for sure instead of whatever the heap held
 extern int g_debug_fail_scratch;          // > 0: calls left until the forced failure
+extern int g_debug_corrupt;               // != 0: the next fixed-base MSM batch damages its own data after that stage, once (mh_debug_corrupt: the
+                                          // fault injection that shows what MH_CHECK catches): 1 = one entry of the sorted lists, 2 = one bucket becomes garbage,
+                                          // 3 = one bucket becomes a copy of its neighbour (a valid point), 4 = one plane becomes a copy of another
 extern uint64_t g_debug_scratch_calls;    // Scratch::ensure calls so far (the test measures a proof with it)
 
 // (the fill runs on the null stream, which the library's non-blocking streams do not wait for: drain the device on both sides, or
@@ -108,8 +113,20 @@ enum ProfFamily { PF_NTT = 0, PF_MSM = 1, PF_MSM_ACCUM = 2, PF_GLUE = 3, PF_MSM_
 
 struct ProfRec { int family; hipEvent_t a, b; };
 
+// What prover.hip keeps per context (prover keys, shard configuration, the job status of a sharded proof, the native transport's
+// communicator): defined there, owned here so that it lives and dies with the context.
+struct ContextExt { virtual ~ContextExt() = default; };
+
+// One context = one GPU's worth of library state: streams, twiddles, workspaces, uploaded base sets, prover keys, shard
+// configuration.  The process has a default context (mh_init); mh_ctx_create makes more -- on the same GPU (two proofs in flight from
+// two threads) or on another one (one host process driving several GPUs: one thread per context) -- and mh_ctx_set_current binds the
+// calling THREAD to one of them; every entry point works on the calling thread's current context and takes that context's lock, so
+// calls into different contexts run side by side and calls into one context are serialised.
 struct Context {
   bool inited = false;
+  std::unique_ptr<ContextExt> ext;   // prover.hip: ProverState
+  void* srs_table = nullptr;         // G1Affine[32][256]: the windowed multiples of the generator behind mh_srs_powers
+  bool ntt_attr_done = false, msm_attr_done = false;   // hipFuncSetAttribute is per device: done once per context
   int device = -1;
   int num_simds = 1024;      // 4 per CU
   hipStream_t stream = nullptr;
@@ -129,8 +146,8 @@ struct Context {
   // MSM
   std::map<uint64_t, BaseSet> bases;
   std::map<uint64_t, G2Set> g2_bases;
-  uint64_t next_handle = 1;
   Scratch msm_dig, msm_sorted, msm_bh, msm_tot, msm_base, msm_buckets, msm_seg, msm_win, msm_pend;
+  Scratch msm_gather;        // the bases of a skewed strided batch, gathered for the variable-base path
   // fixed-base path (msm_fb.cuh): the workspace of one job group
   struct FbWs {
     Scratch dig, val, sorted, pc, ptot, desc, blk, bh, tot, base, pend, buckets, seg, win, sums, perm;
@@ -144,7 +161,10 @@ struct Context {
   // a library-owned stream for small device-to-host copies that must not wait behind the kernels queued on `stream` (the partition
   // totals of the fixed-base sort travel to the host while the split kernel runs), and the event that orders it
   hipStream_t copy_stream = nullptr;
-  hipEvent_t copy_ev = nullptr;
+  hipEvent_t copy_ev[2] = {nullptr, nullptr};   // [0]: main stream -> copy stream (totals are final), [1]: copy stream -> main stream (descriptors are up)
+  // MH_DIAG (bit mask, diagnostics only -- tools/soak_sliced.py bisects with it): 1 = no copy stream (the partition totals and
+  // the descriptors travel on the main stream), 2 = no host pool (the planes of every job are combined on the calling thread)
+  unsigned diag = 0;
   // Work of the CALLER that does not depend on the batch's results, issued on stream2 the moment the batch's accumulation has
   // been launched, behind an event recorded after it: it then runs beside the bucket reduction -- a latency chain at one wave per
   // SIMD that leaves a third of the VALU's issue slots idle -- and through the host round trip that follows.  The prover hands
@@ -157,6 +177,15 @@ struct Context {
   uint64_t n_fb_groups = 0, n_vb_groups = 0;  // job groups that ran on the fixed-base / variable-base path
   Scratch tr_off[3], tr_cnt[2], tr_p[2], tr_sums, tr_ob, tr_pre, tr_prod, tr_scr;   // pair-tree accumulation
 
+  // MH_CHECK / mh_check_level: the invariants of msm_check.cuh, checked per fixed-base batch.  `report` is the text of the last
+  // checked batch (mh_check_report); a violation makes the MSM call return MH_ECHECK with the failing stage in mh_last_error
+  struct Check {
+    int level = 0;
+    uint64_t batches = 0, violations = 0;
+    std::string report;
+    Scratch d; Pinned h;
+  } chk;
+
   // profiling
   bool prof_on = false;
   unsigned prof_mask = ~0u;            // families whose scopes record events (mh_prof_enable)
@@ -167,7 +196,15 @@ struct Context {
   uint64_t prof_n[PF_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-Context& ctx();
+Context& ctx();            // the calling thread's current context (mh_ctx_set_current), the default context otherwise
+Context& default_ctx();
+// true once a second context exists: entry points then select their context's device on the calling thread every time
+extern bool g_multi_ctx;
+extern std::atomic<uint64_t> g_next_handle;   // handles are unique across contexts
+struct CtxLock {           // LOCKED_CTX: the context's lock, and its device current on this thread
+  std::lock_guard<std::recursive_mutex> lk;
+  explicit CtxLock(Context& c) : lk(c.mu) { if (g_multi_ctx && c.inited) (void)hipSetDevice(c.device); }
+};
 
 struct ProfScope {
   Context& c;

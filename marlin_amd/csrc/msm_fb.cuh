@@ -24,7 +24,7 @@
 // collisions, and the reduction of the single bucket set of each MSM (row / column sums, bit planes).
 #pragma once
 #include "msm.cuh"
-#include "fq30.cuh"
+#include "x30.cuh"
 
 namespace msmfb {
 using msm::Windows;
@@ -37,33 +37,6 @@ using msm::Windows;
 // job with the same scalars and a base range `delta` points further into the same base set (MarlinKZG10 commits a
 // degree-bounded polynomial twice: against powers and against shifted_powers(d) = powers[max_degree - d ..])
 struct FbWin { u64 off; u64 bh_off; u32 cnt; u32 ntiles; u32 delta; u32 pad; };
-
-// Table point: affine, coordinates as 30-bit-limb Montgomery residues (fq30.cuh), each coordinate padded to a
-// multiple of four words (BLS12-381: 2 x 64 B, one cache line per coordinate)
-constexpr int LIMB_SLOTS = (Fq30::NL + 3) & ~3;
-struct G1Aff30 { u32 x[LIMB_SLOTS]; u32 y[LIMB_SLOTS]; };
-
-__device__ __forceinline__ Fq30 load30(const u32* __restrict__ p) {
-  u32 w[LIMB_SLOTS];
-#pragma unroll
-  for (int i = 0; i < LIMB_SLOTS; i += 4) {
-    uint4 q = *reinterpret_cast<const uint4*>(p + i);
-    w[i] = q.x; w[i + 1] = q.y; w[i + 2] = q.z; w[i + 3] = q.w;
-  }
-  Fq30 r;
-#pragma unroll
-  for (int i = 0; i < Fq30::NL; i++) r.v[i] = w[i];
-  return r;
-}
-__device__ __forceinline__ void store30(u32* p, const Fq30& a) {
-#pragma unroll
-  for (int i = 0; i < LIMB_SLOTS; i += 4) {
-    uint4 q;
-    q.x = i < Fq30::NL ? a.v[i] : 0; q.y = i + 1 < Fq30::NL ? a.v[i + 1] : 0;
-    q.z = i + 2 < Fq30::NL ? a.v[i + 2] : 0; q.w = i + 3 < Fq30::NL ? a.v[i + 3] : 0;
-    *reinterpret_cast<uint4*>(p + i) = q;
-  }
-}
 
 constexpr int MAX_C = 20;          // 2^19 buckets = 256 partitions x 2^11
 constexpr int PART_BITS = 11;      // buckets per virtual window = 2^11
@@ -402,141 +375,6 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __re
   for (u32 idx = t; idx < cnt; idx += SORT_THREADS) out[gdst[sbkt[idx]] + idx] = stage[idx];
 }
 
-// ---- XYZZ points on 30-bit limbs (buckets between accumulate and the bucket reduction) -------------------------
-// Bounds kept by every operation below (units of p): X <= 6.2, Y <= 3.2, ZZ, ZZZ <= 1.1; the identity is ZZ = 0
-// exactly (a ZZ computed by the formulas is a product of non-zero residues).
-struct X30 { Fq30 x, y, zz, zzz; };
-struct G1Xyzz30 { u32 c[4][LIMB_SLOTS]; };
-
-__device__ __forceinline__ bool x30_is_identity(const X30& a) {
-  u32 o = 0;
-#pragma unroll
-  for (int i = 0; i < Fq30::NL; i++) o |= a.zz.v[i];
-  return o == 0;
-}
-__device__ __forceinline__ X30 x30_identity() {
-  X30 r;
-#pragma unroll
-  for (int i = 0; i < Fq30::NL; i++) { r.x.v[i] = 0; r.y.v[i] = 0; r.zz.v[i] = 0; r.zzz.v[i] = 0; }
-  return r;
-}
-__device__ __forceinline__ X30 x30_load(const G1Xyzz30* p) {
-  X30 r;
-  r.x = load30(p->c[0]); r.y = load30(p->c[1]); r.zz = load30(p->c[2]); r.zzz = load30(p->c[3]);
-  return r;
-}
-__device__ __forceinline__ void x30_store(G1Xyzz30* p, const X30& a) {
-  store30(p->c[0], a.x); store30(p->c[1], a.y); store30(p->c[2], a.zz); store30(p->c[3], a.zzz);
-}
-__device__ __forceinline__ G1Xyzz x30_to_std(const X30& a) {
-  G1Xyzz r;
-  if (x30_is_identity(a)) return G1Xyzz::identity();
-  r.x = f30_to_fq(a.x); r.y = f30_to_fq(a.y); r.zz = f30_to_fq(a.zz); r.zzz = f30_to_fq(a.zzz);
-  return r;
-}
-__device__ __forceinline__ X30 x30_from_std(const G1Xyzz& a) {
-  X30 r;
-  r.x = f30_from_fq(a.x); r.y = f30_from_fq(a.y); r.zz = f30_from_fq(a.zz); r.zzz = f30_from_fq(a.zzz);
-  return r;
-}
-// acc += b   [EFD add-2008-s]  12M + 2S
-__device__ __forceinline__ void x30_add_inl(X30& acc, const X30& b);
-__device__ __noinline__ void x30_dbl(X30& a);
-__device__ __noinline__ void x30_add(X30& acc, const X30& b) { x30_add_inl(acc, b); }
-__device__ __forceinline__ void x30_add_inl(X30& acc, const X30& b) {
-  if (x30_is_identity(b)) return;
-  if (x30_is_identity(acc)) { acc = b; return; }
-  const Fq30 U1 = f30_mul(acc.x, b.zz);
-  const Fq30 S1 = f30_mul(acc.y, b.zzz);
-  const Fq30 P = f30_sub<2>(f30_mul(b.x, acc.zz), U1);
-  const Fq30 R = f30_sub<2>(f30_mul(b.y, acc.zzz), S1);
-  if (__builtin_expect(f30_is_zero(P), 0)) {            // equal x: the same point (doubling) or opposite points (see x30_add_ilp_inl)
-    if (f30_is_zero(R)) x30_dbl(acc); else acc = x30_identity();
-    return;
-  }
-  Fq30 PP = f30_sqr(P);
-  const Fq30 Q = f30_mul(U1, PP);
-  acc.zz = f30_mul(f30_mul(acc.zz, b.zz), PP);
-  PP = f30_mul(P, PP);                                  // PPP
-  acc.zzz = f30_mul(f30_mul(acc.zzz, b.zzz), PP);
-  acc.x = f30_sub2<3>(f30_sub<2>(f30_sqr(R), PP), Q);
-  acc.y = f30_sub<2>(f30_mul(R, f30_sub<8>(Q, acc.x)), f30_mul(S1, PP));
-}
-// a = 2 a   [EFD dbl-2008-s-1, a = 0]; a point of G1 has odd order, so 2 a is never the identity
-__device__ __noinline__ void x30_dbl(X30& a) {
-  if (x30_is_identity(a)) return;
-  const Fq30 U = f30_dbl(a.y);
-  const Fq30 V = f30_sqr(U);
-  const Fq30 W = f30_mul(U, V);
-  const Fq30 S = f30_mul(a.x, V);
-  const Fq30 XX = f30_sqr(a.x);
-  const Fq30 M = f30_add(f30_dbl(XX), XX);
-  const Fq30 X3 = f30_sub2<3>(f30_sqr(M), S);
-  a.y = f30_sub<2>(f30_mul(M, f30_sub<8>(S, X3)), f30_mul(W, a.y));
-  a.zz = f30_mul(V, a.zz);
-  a.zzz = f30_mul(W, a.zzz);
-  a.x = X3;
-}
-
-// ---- the same group law with its independent multiplications side by side (fq30.cuh f30_mul_x3 ...) -------------------
-// Inside a general addition every field multiplication is one chain of ~400 dependent instructions, but the addition's 14
-// multiplications are not all dependent on each other: {U1, S1, ZZ1 ZZ2}, {U2, S2, ZZZ1 ZZZ2}, {P^2, R^2}, {Q, PPP, ZZ3}, {Y3, ZZZ3}
-// -- five steps of 2-3 interleaved chains instead of 14 single ones; the doubling's 10 become 4 steps.  Built in round 4 for the
-// segment reduction, which ran one wave per SIMD (sort + reduce stages 11.85 -> 11.57 ms per proof at 2^20,
-// profiles/r04ef_ab_reduce_ilp_and_called_field_ops.txt); round 5's row / column sums use the same law, and the sweep of their
-// launch shape shows what the interleaving buys: ONE such wave already saturates its SIMD's VALU (one and two resident waves run
-// at the same rate, profiles/r05c_sweep_rsum_threads.txt, r05w_sq_counters_rsum_kernel_wave_cycle_breakdown.json).  (CALLING the
-// multi-chain operations instead of inlining them costs 3.3 ms per proof: the operands travel through scratch.)  Same values mod p
-// (Y3 is taken as ONE reduction of R (Q - X3) + (2p - S1) PPP, so its lazy representative differs from x30_add's: compared through
-// the canonical form by mh_selftest_fq30; bounds: X <= 6.2, Y <= 1.2, ZZ, ZZZ <= 1.1).
-__device__ __noinline__ void x30_dbl_ilp(X30& a);
-__device__ __forceinline__ void x30_add_ilp_inl(X30& acc, const X30& b) {
-  if (x30_is_identity(b)) return;
-  if (x30_is_identity(acc)) { acc = b; return; }
-  Fq30 U1, S1, U2, S2, ZZ12, ZZZ12;
-  f30_mul_x3(U1, acc.x, b.zz, S1, acc.y, b.zzz, ZZ12, acc.zz, b.zz);
-  f30_mul_x3(U2, b.x, acc.zz, S2, b.y, acc.zzz, ZZZ12, acc.zzz, b.zzz);
-  const Fq30 P = f30_sub<2>(U2, U1);
-  const Fq30 R = f30_sub<2>(S2, S1);
-  // Equal x is NOT rare in the bucket reduction: with an empty bucket right after a segment's first non-empty one the running sum
-  // and the accumulator are the same point (acc = running = B), and acc += running is a doubling -- at 2^16 a quarter of the
-  // waves of an H-sized job meet one.  Round 3 sent these through the complete law in the 32-bit representation (four
-  // conversions each way around g1_add, ~5 additions' time, with the whole wave waiting); here the two cases are told apart
-  // by R -- same point: the 30-bit doubling; opposite points: the identity.
-  if (__builtin_expect(f30_is_zero(P), 0)) {
-    if (f30_is_zero(R)) x30_dbl_ilp(acc); else acc = x30_identity();
-    return;
-  }
-  Fq30 PP, RR;
-  f30_sqr_x2(PP, P, RR, R);
-  Fq30 Q, PPP;
-  f30_mul_x3(Q, U1, PP, PPP, P, PP, acc.zz, ZZ12, PP);
-  acc.x = f30_sub2<3>(f30_sub<2>(RR, PPP), Q);
-  Fq30 zero;
-#pragma unroll
-  for (int i = 0; i < Fq30::NL; i++) zero.v[i] = 0;
-  // R <= 4 p, Q - X3 + 8p <= 10 p, (2p - S1) PPP <= 4 p^2: 44 p^2 < 64 p^2
-  f30_mul2_mul(acc.y, R, f30_sub<8>(Q, acc.x), f30_sub<2>(zero, S1), PPP, acc.zzz, ZZZ12, PPP);
-}
-__device__ __noinline__ void x30_add_ilp(X30& acc, const X30& b) { x30_add_ilp_inl(acc, b); }
-__device__ __noinline__ void x30_dbl_ilp(X30& a) {
-  if (x30_is_identity(a)) return;
-  const Fq30 U = f30_dbl(a.y);
-  Fq30 V, XX;
-  f30_sqr_x2(V, U, XX, a.x);
-  const Fq30 M = f30_add(f30_dbl(XX), XX);
-  Fq30 W, S, MM;
-  f30_mul_x3(W, U, V, S, a.x, V, a.zz, V, a.zz);
-  f30_sqr_mul(MM, M, a.zzz, W, a.zzz);
-  const Fq30 X3 = f30_sub2<3>(MM, S);
-  Fq30 zero;
-#pragma unroll
-  for (int i = 0; i < Fq30::NL; i++) zero.v[i] = 0;
-  // M <= 3.7 p, S - X3 + 8p <= 10 p, (2p - W) Y <= 6.4 p^2: 44 p^2 < 64 p^2
-  a.y = f30_mul2(M, f30_sub<8>(S, X3), f30_sub<2>(zero, W), a.y);
-  a.x = X3;
-}
-
 // ---- bucket order: largest first -------------------------------------------------------------------------------
 // A wave of the accumulate kernel runs as long as its largest bucket.  msm::accum_kernel sorts bucket sizes inside each
 // block of 256; here all buckets of the launch are ordered by size with a counting sort (sizes are small integers), so
@@ -647,7 +485,7 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
 // of no deferred bucket at all)
 __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                      const u32* __restrict__ sorted_all, const u32* __restrict__ base,
-                                                     const u32* __restrict__ tot, const u32* __restrict__ pend,
+                                                     const u32* __restrict__ tot, u32* __restrict__ pend,
                                                      const u32* __restrict__ n_deferred, G1Xyzz30* __restrict__ buckets, u32 nb, u64 WB) {
   if (*n_deferred == 0) return;
   for (u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x; gid < WB; gid += (u64)gridDim.x * blockDim.x) {
@@ -665,6 +503,7 @@ __global__ __launch_bounds__(64) void fixup30_kernel(const FbWin* __restrict__ f
     g1_madd(acc, x, y);
   }
   x30_store(buckets + gid, x30_from_std(acc));
+  pend[gid] = 0;                                  // settled (MH_CHECK counts what is still pending afterwards)
   }
 }
 
@@ -784,84 +623,6 @@ __global__ __launch_bounds__(PLANE_THREADS) void plane_kernel(const G1Xyzz30* __
   while (width < count && width < PLANE_THREADS) width <<= 1;
   if (width > 1) block_tree_sum(acc, sh, width);
   if (threadIdx.x == 0) g1_store_xyzz(out_std + (u64)w * p.nplanes + plane, x30_to_std(acc));
-}
-
-// ---- self-test of the 30-bit arithmetic against ff.cuh (mh_selftest_fq30) ----------------------------------------
-// in: n + 1 arbitrary 32-bit-limb integers; every thread checks, for a = in[i], b = in[i + 1] (reduced below p first):
-// a b through both representations; (c + a) - a; (a - b)(a + b) = a^2 - b^2 with the dedicated squaring; a - 2b;
-// XYZZ doubling and addition of a pseudo-point against g1_dbl / g1_add (pure algebra: the formulas never test curve
-// membership); the zero filter on multiples of p.
-__global__ __launch_bounds__(128) void selftest30_kernel(const Fq* __restrict__ in, u64 n, u32* __restrict__ bad) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Fq a = ff_mul(ff_load(in + i), Fq::one()), b = ff_mul(ff_load(in + i + 1), Fq::one());
-  const Fq30 a30 = f30_from_fq(a), b30 = f30_from_fq(b);
-  bool ok = true;
-  auto same = [&](const Fq& x, const Fq& y) { for (int k = 0; k < Fq::N; k++) ok = ok && x.v[k] == y.v[k]; };
-  const Fq30 c30 = f30_mul(a30, b30);
-  same(f30_to_fq(c30), ff_mul(a, b));
-  {
-    const Fq30 cx = f30_mul_cxx(a30, b30), sx = f30_sqr_cxx(a30), sg = f30_sqr(a30);
-    const Fq30 cs = f30_mul_sep(a30, b30), ss = f30_sqr_sep(a30);
-    for (int k = 0; k < Fq30::NL; k++) ok = ok && cx.v[k] == c30.v[k] && sx.v[k] == sg.v[k] && cs.v[k] == c30.v[k] && ss.v[k] == sg.v[k];
-    // lazily reduced operands (up to ~16 p: what the accumulate loop feeds the multiplier) through all three forms
-    const Fq30 wa = f30_add(f30_add(f30_dbl(f30_dbl(a30)), f30_dbl(f30_dbl(b30))), a30), wb = f30_sub<8>(f30_dbl(f30_dbl(b30)), a30);
-    const Fq30 w1 = f30_mul(wa, wb), w2 = f30_mul_sep(wa, wb), w3 = f30_mul_cxx(wa, wb);
-    const Fq30 q1 = f30_sqr(wa), q2 = f30_sqr_sep(wa), q3 = f30_sqr_cxx(wa);
-    for (int k = 0; k < Fq30::NL; k++) ok = ok && w1.v[k] == w2.v[k] && w1.v[k] == w3.v[k] && q1.v[k] == q2.v[k] && q1.v[k] == q3.v[k];
-    // two products under one reduction
-    same(f30_to_fq(f30_mul2(a30, b30, wa, wb)), ff_add(ff_mul(a, b), ff_mul(f30_to_fq(wa), f30_to_fq(wb))));
-    // the interleaved chains against the single ones, limb for limb (reduced and lazily reduced operands, aliased outputs)
-    auto same30 = [&](const Fq30& x, const Fq30& y) { for (int k = 0; k < Fq30::NL; k++) ok = ok && x.v[k] == y.v[k]; };
-    Fq30 r0, r1, r2;
-    f30_mul_x2(r0, a30, b30, r1, wa, wb); same30(r0, c30); same30(r1, w1);
-    f30_mul_x3(r0, wa, wb, r1, a30, b30, r2, b30, wa); same30(r0, w1); same30(r1, c30); same30(r2, f30_mul(b30, wa));
-    f30_sqr_x2(r0, a30, r1, wa); same30(r0, sg); same30(r1, q1);
-    f30_sqr_mul(r0, wa, r1, a30, wb); same30(r0, q1); same30(r1, f30_mul(a30, wb));
-    f30_mul2_mul(r0, a30, b30, wa, wb, r1, wb, b30); same30(r0, f30_mul2(a30, b30, wa, wb)); same30(r1, f30_mul(wb, b30));
-    r0 = a30; r1 = b30;
-    f30_mul_x2(r0, r0, r1, r1, r1, r0); same30(r0, c30); same30(r1, c30);           // outputs alias inputs
-  }
-  same(f30_to_fq(f30_sub<2>(f30_add(c30, a30), a30)), ff_mul(a, b));
-  same(f30_to_fq(f30_mul(f30_sub<2>(a30, b30), f30_add(a30, b30))), f30_to_fq(f30_sub<2>(f30_sqr(a30), f30_sqr(b30))));
-  same(f30_to_fq(f30_sqr(a30)), ff_sqr(a));
-  same(f30_to_fq(f30_sub2<3>(a30, b30)), ff_sub(a, ff_dbl(b)));
-  same(f30_to_fq(f30_sub<8>(f30_dbl(a30), b30)), ff_sub(ff_dbl(a), b));
-  ok = ok && f30_is_zero(f30_sub<2>(a30, a30)) && f30_is_zero(f30_sub<8>(f30_add(a30, a30), f30_dbl(a30)));
-  // group formulas on pseudo-points
-  G1Xyzz p, q;
-  p.x = a; p.y = b; p.zz = ff_sqr(b); p.zzz = ff_mul(p.zz, b);
-  q.x = b; q.y = ff_add(a, b); q.zz = ff_sqr(a); q.zzz = ff_mul(q.zz, a);
-  if (!p.zz.is_zero() && !q.zz.is_zero()) {
-    X30 p30 = x30_from_std(p), q30 = x30_from_std(q);
-    G1Xyzz d = p; g1_dbl(d);
-    X30 d30 = p30; x30_dbl(d30);
-    G1Xyzz ds = x30_to_std(d30);
-    same(ds.x, d.x); same(ds.y, d.y); same(ds.zz, d.zz); same(ds.zzz, d.zzz);
-    G1Xyzz s = p; g1_add(s, q);
-    X30 s30 = p30; x30_add(s30, q30);
-    G1Xyzz ss = x30_to_std(s30);
-    same(ss.x, s.x); same(ss.y, s.y); same(ss.zz, s.zz); same(ss.zzz, s.zzz);
-    // equal x with equal y: the doubling inside the addition
-    X30 e30 = p30; x30_add(e30, p30);
-    G1Xyzz es = x30_to_std(e30);
-    same(es.x, d.x); same(es.y, d.y); same(es.zz, d.zz); same(es.zzz, d.zzz);
-    // the group law with interleaved multiplications: doubling, addition, a chain of both (lazy bounds), equal x
-    X30 di = p30; x30_dbl_ilp(di);
-    G1Xyzz dis = x30_to_std(di);
-    same(dis.x, d.x); same(dis.y, d.y); same(dis.zz, d.zz); same(dis.zzz, d.zzz);
-    X30 si = p30; x30_add_ilp(si, q30);
-    G1Xyzz sis = x30_to_std(si);
-    same(sis.x, s.x); same(sis.y, s.y); same(sis.zz, s.zz); same(sis.zzz, s.zzz);
-    X30 ca = s30, cb = si;
-    for (int it = 0; it < 3; it++) { x30_add(ca, d30); x30_dbl(ca); x30_add(ca, q30); x30_add_ilp(cb, di); x30_dbl_ilp(cb); x30_add_ilp(cb, q30); }
-    G1Xyzz cas = x30_to_std(ca), cbs = x30_to_std(cb);
-    same(cas.x, cbs.x); same(cas.y, cbs.y); same(cas.zz, cbs.zz); same(cas.zzz, cbs.zzz);
-    X30 ei = p30; x30_add_ilp(ei, p30);
-    G1Xyzz eis = x30_to_std(ei);
-    same(eis.x, d.x); same(eis.y, d.y); same(eis.zz, d.zz); same(eis.zzz, d.zzz);
-  }
-  if (!ok) atomicAdd(bad, 1u);
 }
 
 }  // namespace msmfb

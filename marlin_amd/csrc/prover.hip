@@ -117,10 +117,6 @@ struct ProverKey {
   }
 };
 
-// never destroyed: at process exit the HIP runtime may be torn down before this library's statics, and a key's buffers
-// must not be hipFree'd then (mh_shutdown / mh_marlin_pk_free release keys while the runtime is alive)
-std::map<uint64_t, std::unique_ptr<ProverKey>>& g_pks = *new std::map<uint64_t, std::unique_ptr<ProverKey>>();
-uint64_t g_next_pk = 1;
 
 // ---- small launch helpers ------------------------------------------------------------------
 #define KLAUNCH(kern, n, ...)                                                                          \
@@ -307,14 +303,7 @@ struct Shard {
   int rank = 0, world = 1; mh_allgather_fn cb = nullptr; void* user = nullptr; mh_alltoall_fn a2a = nullptr; void* a2a_user = nullptr;
   bool a2a_ordered = false; mh_allgather_dev_fn ag_dev = nullptr; void* ag_dev_user = nullptr; bool native = false;
   double host_ms = 0; uint64_t calls = 0;              // wall time the host spent inside exchanges (mh_marlin_exchange_stats)
-} g_shard;
-// one exchange: HIP events on the library's stream (family PF_EXCHANGE) and the host's wall clock around it
-struct ExchangeScope {
-  ProfScope ps; std::chrono::steady_clock::time_point t0;
-  explicit ExchangeScope(Context& c) : ps(c, PF_EXCHANGE), t0(std::chrono::steady_clock::now()) {}
-  ~ExchangeScope() { g_shard.host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g_shard.calls++; }
 };
-
 // ---- a rank that fails locally fails the JOB instead of hanging it ---------------------------------------
 // Inside a sharded mh_marlin_prove a rank that returned at its first local error would leave its peers blocked in the next
 // collective.  Instead it is POISONED: the remaining local steps of the proof are skipped (PTRY), every collective up to the next
@@ -324,9 +313,114 @@ struct ExchangeScope {
 // can run.  One GPU (world = 1): nothing changes, the first error returns at once.
 struct JobStatus {
   int poison = MH_OK; std::string msg;       // this rank's first local failure
-  bool failed = false;                       // some rank's error word came back from an all-gather: every rank is returning
+  bool failed = false;                       // some rank's error word came back from an all-gather, or a collective itself failed: every rank is returning
   void* buf[2] = {nullptr, nullptr}; size_t buf_bytes = 0;   // stand-in exchange buffers of a poisoned rank
-} g_job;
+};
+// ---- the in-process transport: several contexts of ONE process as the ranks of a sharded prover (mh_group_*) ------------------
+// The reference proves in one process (/root/reference src/lib.rs:151-155, rayon threads: src/ahp/mod.rs:9-10).  With one context
+// per GPU and one host thread per context the same shape reaches N GPUs without RCCL and without a launcher: the three exchanges
+// of a sharded proof become
+//   * all-gather of HOST payloads (partial points, block values): every rank writes its slot of a shared buffer between two
+//     rendezvous of the rank threads;
+//   * all-to-all / all-gather of DEVICE buffers: every rank publishes its send pointer and an event recorded on its stream, then
+//     PULLS its chunks from the peers' buffers with hipMemcpyPeerAsync on its own stream behind those events (xGMI peer-to-peer
+//     between GPUs, a plain device copy between contexts that share one) and publishes a second event that the peers' streams
+//     wait for before they may overwrite what was pulled -- stream-ordered on every GPU, the host threads only rendezvous.
+// A rank that does not arrive within MH_GROUP_TIMEOUT_S (default 300) makes the collective fail on the ranks that wait.
+struct LocalGroup {
+  int world = 0;
+  std::vector<Context*> ctx;                    // the group owns its contexts (mh_group_create / mh_group_destroy)
+  std::mutex mu; std::condition_variable cv; int arrived = 0; uint64_t gen = 0; bool broken = false;
+  std::vector<uint8_t> host;                    // all-gather of host payloads: world slots of `slot` bytes
+  size_t slot = 0;
+  std::vector<const void*> send; std::vector<hipEvent_t> ready, done;   // per rank: published send buffer, its two events
+  double timeout_s = 300;
+  // all ranks arrive, the LAST one runs `last` (under the lock) before anyone leaves
+  int rendezvous(const std::function<void()>& last = nullptr) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (broken) return MH_EHIP;
+    const uint64_t g = gen;
+    if (++arrived == world) { if (last) last(); arrived = 0; gen++; cv.notify_all(); return MH_OK; }
+    if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return gen != g || broken; }) || broken) { broken = true; cv.notify_all(); return MH_EHIP; }
+    return MH_OK;
+  }
+};
+struct LocalMember { std::shared_ptr<LocalGroup> g; int rank; };
+
+// Everything the prover keeps PER CONTEXT (context.h: Context::ext): prover keys, the shard configuration, the status of the sharded
+// proof in flight, the native transport's communicator.  Rounds 1-5 kept these as process globals, which made "one process = one
+// GPU = one proof at a time" a property of the library; now two contexts prove side by side (tests/test_gpu_contexts.py) and one
+// process can drive several GPUs (mh_marlin_set_local_group).
+struct ProverState : mh::ContextExt {
+  std::map<uint64_t, std::unique_ptr<ProverKey>> pks;
+  Shard shard;
+  JobStatus job;
+  rcclnative::State rccl;
+  LocalMember member{nullptr, 0};                                      // mh_group_create: the in-process transport
+  // a context is destroyed while the HIP runtime is alive (mh_shutdown / mh_ctx_destroy); the default context never is
+  ~ProverState() override { for (auto& kv : pks) kv.second->free_all(); }
+};
+inline ProverState& pstate(Context& c) {
+  if (!c.ext) c.ext.reset(new ProverState());
+  return *static_cast<ProverState*>(c.ext.get());
+}
+inline ProverState& pstate() { return pstate(ctx()); }
+// (the names the code below was written with; every use is under the current context's lock)
+#define g_shard (pstate().shard)
+#define g_job (pstate().job)
+#define g_pks (pstate().pks)
+// one exchange: HIP events on the library's stream (family PF_EXCHANGE) and the host's wall clock around it
+struct ExchangeScope {
+  ProfScope ps; std::chrono::steady_clock::time_point t0;
+  explicit ExchangeScope(Context& c) : ps(c, PF_EXCHANGE), t0(std::chrono::steady_clock::now()) {}
+  ~ExchangeScope() { g_shard.host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g_shard.calls++; }
+};
+
+
+inline int group_fail(const char* what) { return fail(MH_EHIP, std::string("in-process transport: ") + what + " (a rank did not arrive, or the group was torn down)"); }
+// mh_allgather_fn
+int local_allgather_host(const void* send, size_t bytes, void* recv, void* user) {
+  LocalMember& m = *static_cast<LocalMember*>(user);
+  LocalGroup& g = *m.g;
+  if (g.rendezvous([&] { if (g.slot != bytes || g.host.size() != bytes * g.world) { g.slot = bytes; g.host.assign(bytes * g.world, 0); } }) != MH_OK) return group_fail("all-gather");
+  if (g.slot != bytes) return fail(MH_EINVAL, "in-process transport: the ranks entered an all-gather with different payload sizes");
+  memcpy(g.host.data() + (size_t)m.rank * bytes, send, bytes);
+  if (g.rendezvous() != MH_OK) return group_fail("all-gather");
+  memcpy(recv, g.host.data(), bytes * g.world);
+  if (g.rendezvous() != MH_OK) return group_fail("all-gather");           // nobody resizes or rewrites the slots before everyone has read them
+  return MH_OK;
+}
+// chunk(p) = what this rank takes from peer p's published buffer, and where it puts it
+static int local_pull(LocalMember& m, const void* d_send, void* d_recv, size_t take, bool a2a) {
+  Context& c = ctx();
+  LocalGroup& g = *m.g;
+  const int r = m.rank, W = g.world;
+  MH_HIP(hipEventRecord(g.ready[r], c.stream));               // my send buffer is final once the stream gets here
+  g.send[r] = d_send;
+  if (g.rendezvous() != MH_OK) return group_fail("device exchange");
+  for (int k = 0; k < W; k++) {
+    const int p = (r + k) % W;                                  // staggered: at any moment every link carries one pull
+    if (p != r) MH_HIP(hipStreamWaitEvent(c.stream, g.ready[p], 0));
+    const char* src = (const char*)g.send[p] + (a2a ? (size_t)r * take : 0);
+    char* dst = (char*)d_recv + (size_t)p * take;
+    if (g.ctx[p]->device == c.device) MH_HIP(hipMemcpyAsync(dst, src, take, hipMemcpyDeviceToDevice, c.stream));
+    else MH_HIP(hipMemcpyPeerAsync(dst, c.device, src, g.ctx[p]->device, take, c.stream));
+  }
+  MH_HIP(hipEventRecord(g.done[r], c.stream));                // I have pulled everything I need
+  if (g.rendezvous() != MH_OK) return group_fail("device exchange");
+  for (int p = 0; p < W; p++) if (p != r) MH_HIP(hipStreamWaitEvent(c.stream, g.done[p], 0));   // my send buffer may be rewritten only behind the peers' pulls
+  return MH_OK;
+}
+int local_alltoall_dev(const void* d_send, size_t bytes_per_peer, void* d_recv, void* user) { return local_pull(*static_cast<LocalMember*>(user), d_send, d_recv, bytes_per_peer, true); }
+int local_allgather_dev(const void* d_send, size_t bytes, void* d_recv, void* user) { return local_pull(*static_cast<LocalMember*>(user), d_send, d_recv, bytes, false); }
+void local_group_leave(Context& c) {
+  if (!c.ext) return;
+  ProverState& ps = pstate(c);
+  if (!ps.member.g) return;
+  { std::lock_guard<std::mutex> lk(ps.member.g->mu); ps.member.g->broken = true; ps.member.g->cv.notify_all(); }
+  if (ps.shard.user == &ps.member) ps.shard = Shard();
+  ps.member.g.reset();
+}
 inline void poison(int rc) { if (g_job.poison == MH_OK) { g_job.poison = rc; g_job.msg = g_err; } }
 inline int job_error() { return g_job.poison != MH_OK ? fail(g_job.poison, g_job.msg) : MH_EHIP; }
 // local step: skipped once poisoned; its failure poisons (sharded) or returns (one GPU)
@@ -391,7 +485,9 @@ int sharded_msm_batch(Context& c, const std::vector<MsmJob>& jobs, std::vector<H
   }
   {
     ExchangeScope xs(c);
-    if (g_shard.cb(send.data(), send.size() * 8, all.data(), g_shard.user) != 0) return fail(MH_EHIP, "sharded prove: all_gather failed: " + g_err);
+    // a collective that FAILS is not a local failure: the communicator is gone for every rank, so the job is marked failed and CTRY
+    // returns at once instead of poisoning this rank and entering the next collective on a dead transport
+    if (g_shard.cb(send.data(), send.size() * 8, all.data(), g_shard.user) != 0) { g_job.failed = true; return fail(MH_EHIP, "sharded prove: all_gather failed: " + g_err); }
   }
   for (int g = 0; g < g_shard.world; g++) if (all[(size_t)g * stride + npts] != 0) g_job.failed = true;
   if (rc != MH_OK) return fail(rc, g_job.msg);
@@ -650,17 +746,21 @@ int ensure_twiddles_public(Context& c, uint32_t log_n);
 // ===========================================================================================
 #define LOCKED_CTX()                                                 \
   Context& c = ctx();                                                \
-  std::lock_guard<std::recursive_mutex> _lk(c.mu);                   \
+  CtxLock _lk(c);                                                    \
   if (!c.inited) return fail(MH_ENOINIT, "mh_init has not been called")
 
 extern "C" {
 
 // called by mh_shutdown: release every prover key
 int mh_marlin_release_all(void) {
+  Context& c = ctx();
+  if (!c.ext) return MH_OK;
   for (auto& kv : g_pks) kv.second->free_all();
   g_pks.clear();
   if (g_shard.native) g_shard = Shard();
-  (void)rcclnative::destroy();
+  (void)rcclnative::destroy(pstate(c).rccl);
+  local_group_leave(c);
+  g_job = JobStatus();
   return MH_OK;
 }
 
@@ -668,13 +768,13 @@ int mh_marlin_set_shard(int rank, int world, mh_allgather_fn allgather, void* us
   if (world < 1 || rank < 0 || rank >= world) return fail(MH_EINVAL, "mh_marlin_set_shard: bad rank/world");
   if (world > 1 && !allgather) return fail(MH_EINVAL, "mh_marlin_set_shard: all_gather callback required for world > 1");
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);     // g_shard is read by a running mh_marlin_prove under this lock
+  CtxLock lk(c);     // g_shard is read by a running mh_marlin_prove under this lock
   // a callback transport replaces the native one (mh_marlin_set_rccl) as a whole: its all-to-all and device all-gather go with
   // it and its communicator is destroyed -- the sliced rounds must never mix a callback all-gather with native all-to-alls
   if (g_shard.native) {
     if (c.inited && c.stream) (void)hipStreamSynchronize(c.stream);
     g_shard.a2a = nullptr; g_shard.a2a_user = nullptr; g_shard.a2a_ordered = false;
-    (void)rcclnative::destroy();
+    (void)rcclnative::destroy(pstate(c).rccl);
   }
   g_shard.rank = rank; g_shard.world = world; g_shard.cb = allgather; g_shard.user = user;
   g_shard.ag_dev = nullptr; g_shard.ag_dev_user = nullptr; g_shard.native = false;
@@ -692,55 +792,136 @@ int mh_rccl_unique_id(uint8_t* id128_out) {
 int mh_marlin_set_rccl(int rank, int world, const uint8_t* id128) {
   if (world < 1 || rank < 0 || rank >= world || !id128) return fail(MH_EINVAL, "mh_marlin_set_rccl: bad rank / world / id");
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  CtxLock lk(c);
   if (!c.inited) return fail(MH_ENOINIT, "mh_init has not been called");
   MH_HIP(hipStreamSynchronize(c.stream));
-  MH_TRY(rcclnative::init(c, rank, world, id128));
-  g_shard.rank = rank; g_shard.world = world; g_shard.cb = rcclnative::allgather_host; g_shard.user = nullptr;
-  g_shard.a2a = rcclnative::alltoall_dev; g_shard.a2a_user = nullptr; g_shard.a2a_ordered = true;
-  g_shard.ag_dev = rcclnative::allgather_dev; g_shard.ag_dev_user = nullptr; g_shard.native = true;
+  MH_TRY(rcclnative::init(c, pstate(c).rccl, rank, world, id128));
+  void* st = &pstate(c).rccl;
+  g_shard.rank = rank; g_shard.world = world; g_shard.cb = rcclnative::allgather_host; g_shard.user = st;
+  g_shard.a2a = rcclnative::alltoall_dev; g_shard.a2a_user = st; g_shard.a2a_ordered = true;
+  g_shard.ag_dev = rcclnative::allgather_dev; g_shard.ag_dev_user = st; g_shard.native = true;
   return MH_OK;
 }
 // sliced != 0 (default after mh_marlin_set_rccl): rounds 2 and 3 and the openings run on slices when the geometry allows it;
 // 0 keeps the AHP rounds replicated (only the MSMs are sharded) -- what a callback transport gets without an all-to-all
 int mh_marlin_rccl_sliced(int sliced) {
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  CtxLock lk(c);
   if (!g_shard.native) return fail(MH_EINVAL, "mh_marlin_rccl_sliced: the native transport is not active");
-  g_shard.a2a = sliced ? rcclnative::alltoall_dev : nullptr;
+  g_shard.a2a = sliced ? rcclnative::alltoall_dev : nullptr; g_shard.a2a_user = &pstate(c).rccl;
   g_shard.a2a_ordered = sliced != 0;
-  g_shard.ag_dev = sliced ? rcclnative::allgather_dev : nullptr; g_shard.ag_dev_user = nullptr;
+  g_shard.ag_dev = sliced ? rcclnative::allgather_dev : nullptr; g_shard.ag_dev_user = &pstate(c).rccl;
   return MH_OK;
 }
 int mh_marlin_rccl_destroy(void) {
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  CtxLock lk(c);
   if (c.inited && c.stream) (void)hipStreamSynchronize(c.stream);
   if (g_shard.native) { g_shard = Shard(); }
-  return rcclnative::destroy();
+  return rcclnative::destroy(pstate(c).rccl);
 }
 // info4: all-gathers of host payloads, all-to-alls, device all-gathers, bytes this rank sent to peers -- since mh_marlin_set_rccl;
 // lib_path (may be NULL): which librccl the symbols came from
 int mh_marlin_rccl_info(uint64_t* info4, char* lib_path, size_t cap) {
-  const rcclnative::State& s = rcclnative::state();
+  const rcclnative::State& s = pstate().rccl;
   if (info4) { info4[0] = s.n_allgather_host; info4[1] = s.n_alltoall; info4[2] = s.n_allgather_dev; info4[3] = s.bytes_moved; }
-  if (lib_path && cap) snprintf(lib_path, cap, "%s", s.api.path.c_str());
+  if (lib_path && cap) snprintf(lib_path, cap, "%s", rcclnative::api().path.c_str());
   return g_shard.native ? 1 : 0;
 }
 // exchanges since the last reset, whatever the transport: count and the host's wall-clock milliseconds inside them
 int mh_marlin_exchange_stats(uint64_t* calls_out, double* host_ms_out, int reset) {
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  CtxLock lk(c);
   if (calls_out) *calls_out = g_shard.calls;
   if (host_ms_out) *host_ms_out = g_shard.host_ms;
   if (reset) { g_shard.calls = 0; g_shard.host_ms = 0; }
   return MH_OK;
 }
 
+// ---- one process, several GPUs: a group of contexts joined by the in-process transport (LocalGroup above) ----------------------
+struct mh_group { std::shared_ptr<LocalGroup> g; std::vector<mh_ctx_t> handles; };
+int mh_group_create(const int* device_ids, int world, mh_group_t* group_out) {
+  if (!device_ids || !group_out || world < 1 || world > 64) return fail(MH_EINVAL, "mh_group_create: bad argument (1 <= world <= 64)");
+  *group_out = nullptr;
+  std::unique_ptr<mh_group> grp(new mh_group());
+  grp->g = std::make_shared<LocalGroup>();
+  LocalGroup& g = *grp->g;
+  g.world = world;
+  { const char* e = getenv("MH_GROUP_TIMEOUT_S"); if (e && atof(e) > 0) g.timeout_s = atof(e); }
+  g.send.assign(world, nullptr); g.ready.assign(world, nullptr); g.done.assign(world, nullptr);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  auto undo = [&](int rc) { for (auto h : grp->handles) (void)mh_ctx_destroy(h); for (auto e : g.ready) if (e) (void)hipEventDestroy(e); for (auto e : g.done) if (e) (void)hipEventDestroy(e);
+                            if (prev >= 0) (void)hipSetDevice(prev); return rc; };
+  for (int r = 0; r < world; r++) {
+    mh_ctx_t h = nullptr;
+    const int rc = mh_ctx_create(device_ids[r], &h);
+    if (rc != MH_OK) return undo(rc);
+    grp->handles.push_back(h);
+    g.ctx.push_back(reinterpret_cast<Context*>(h));
+    if (hipSetDevice(device_ids[r]) != hipSuccess || hipEventCreateWithFlags(&g.ready[r], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g.done[r], hipEventDisableTiming) != hipSuccess) return undo(fail(MH_EHIP, "mh_group_create: hipEventCreate failed"));
+  }
+  // peer-to-peer between the group's GPUs (xGMI): enabled where the hardware allows it; hipMemcpyPeerAsync stages through the host otherwise
+  for (int a = 0; a < world; a++)
+    for (int b = 0; b < world; b++) {
+      const int da = device_ids[a], db = device_ids[b];
+      int can = 0;
+      if (da == db || hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) continue;
+      (void)hipSetDevice(da);
+      const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+      if (e != hipSuccess) (void)hipGetLastError();            // already enabled (another group, the caller): fine
+    }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  const bool pow2 = (world & (world - 1)) == 0 && world <= 8;
+  for (int r = 0; r < world; r++) {
+    Context& c = *g.ctx[r];
+    CtxLock lk(c);
+    ProverState& ps = pstate(c);
+    ps.member = LocalMember{grp->g, r};
+    ps.shard = Shard();
+    ps.shard.rank = r; ps.shard.world = world; ps.shard.cb = local_allgather_host; ps.shard.user = &ps.member;
+    if (pow2 && world > 1) { ps.shard.a2a = local_alltoall_dev; ps.shard.a2a_user = &ps.member; ps.shard.a2a_ordered = true;
+                             ps.shard.ag_dev = local_allgather_dev; ps.shard.ag_dev_user = &ps.member; }
+  }
+  *group_out = grp.release();
+  return MH_OK;
+}
+int mh_group_size(mh_group_t grp) { return grp ? grp->g->world : 0; }
+mh_ctx_t mh_group_ctx(mh_group_t grp, int rank) { return grp && rank >= 0 && rank < grp->g->world ? grp->handles[rank] : nullptr; }
+// fn(rank, user) on `world` threads, thread r bound to the group's context r; returns the first non-zero result (its message in mh_last_error)
+int mh_group_run(mh_group_t grp, mh_group_fn fn, void* user) {
+  if (!grp || !fn) return fail(MH_EINVAL, "mh_group_run: null argument");
+  const int W = grp->g->world;
+  std::vector<int> rc(W, MH_OK); std::vector<std::string> msg(W);
+  std::vector<std::thread> th;
+  for (int r = 0; r < W; r++)
+    th.emplace_back([&, r] {
+      rc[r] = mh_ctx_set_current(grp->handles[r]);
+      if (rc[r] == MH_OK) rc[r] = fn(r, user);
+      if (rc[r] != MH_OK) msg[r] = g_err;
+      (void)mh_ctx_set_current(nullptr);
+    });
+  for (auto& t : th) t.join();
+  for (int r = 0; r < W; r++) if (rc[r] != MH_OK) return fail(rc[r], "rank " + std::to_string(r) + ": " + msg[r]);
+  return MH_OK;
+}
+int mh_group_destroy(mh_group_t grp) {
+  if (!grp) return MH_OK;
+  LocalGroup& g = *grp->g;
+  { std::lock_guard<std::mutex> lk(g.mu); g.broken = true; g.cv.notify_all(); }
+  int rc = MH_OK;
+  for (auto h : grp->handles) { const int r = mh_ctx_destroy(h); if (rc == MH_OK) rc = r; }
+  for (auto e : g.ready) if (e) (void)hipEventDestroy(e);
+  for (auto e : g.done) if (e) (void)hipEventDestroy(e);
+  delete grp;
+  return rc;
+}
+
 // ---- distributed building blocks (the slice-sharded pipeline) ---------------------------------------------
 int mh_marlin_set_alltoall(mh_alltoall_fn alltoall, void* user) {
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  CtxLock lk(c);
   g_shard.a2a = alltoall; g_shard.a2a_user = user; g_shard.a2a_ordered = false;
   g_shard.ag_dev = nullptr; g_shard.ag_dev_user = nullptr;
   return MH_OK;
@@ -749,7 +930,7 @@ int mh_marlin_set_alltoall(mh_alltoall_fn alltoall, void* user) {
 // (otherwise they go through the all-to-all, every rank sending `world` copies of its chunk); follows the all-to-all's mode
 int mh_marlin_set_allgather_dev(mh_allgather_dev_fn allgather_dev, void* user) {
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  CtxLock lk(c);
   g_shard.ag_dev = allgather_dev; g_shard.ag_dev_user = user;
   return MH_OK;
 }
@@ -757,7 +938,7 @@ int mh_marlin_set_allgather_dev(mh_allgather_dev_fn allgather_dev, void* user) {
 // orders itself against it on the device, so the library does not drain the stream before calling it.  Reset by mh_marlin_set_alltoall.
 int mh_marlin_set_alltoall_mode(int stream_ordered) {
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  CtxLock lk(c);
   g_shard.a2a_ordered = stream_ordered != 0;
   return MH_OK;
 }
@@ -783,7 +964,7 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
   if (lrc == MH_OK) L(c.ntt_dist_buf[1].ensure(m * 32));
   Fr* A = (Fr*)c.ntt_dist_buf[0].ptr; Fr* B = (Fr*)c.ntt_dist_buf[1].ptr;
   if (c.ntt_dist_buf[0].cap < m * 32 || c.ntt_dist_buf[1].cap < m * 32) {       // what failed is these very buffers
-    if (g_job.buf_bytes < m * 32) return fail(MH_ENOMEM, "mh_ntt_dist_dev: no exchange buffer (this rank cannot enter the all-to-all)");
+    if (g_job.buf_bytes < m * 32) { g_job.failed = true; return fail(MH_ENOMEM, "mh_ntt_dist_dev: no exchange buffer (this rank cannot enter the all-to-all)"); }
     A = (Fr*)g_job.buf[0]; B = (Fr*)g_job.buf[1];
   }
   // w_n, and the tables of (w_n^(+-rank))^k2 = hi[k2 >> 11] * lo[k2 & 2047], the inverse's lo carrying G^-1
@@ -834,7 +1015,7 @@ int ntt_dist_device(Context& c, const void* d_in, uint64_t in_len, void* d_out, 
   auto exchange = [&](const Fr* send, Fr* recv) -> int {
     if (!g_shard.a2a_ordered) MH_HIP(hipStreamSynchronize(c.stream));
     ExchangeScope xs(c);
-    if (g_shard.a2a(send, (size_t)chunk * 32, recv, g_shard.a2a_user) != 0) return fail(MH_EHIP, "mh_ntt_dist_dev: all_to_all failed: " + g_err);
+    if (g_shard.a2a(send, (size_t)chunk * 32, recv, g_shard.a2a_user) != 0) { g_job.failed = true; return fail(MH_EHIP, "mh_ntt_dist_dev: all_to_all failed: " + g_err); }
     return MH_OK;
   };
   if (!inverse) {
@@ -863,7 +1044,7 @@ inline unsigned grid256(uint64_t n) { return (unsigned)((n + 255) / 256); }
 uint64_t slice_c(Context& c, Fr* dst, const Fr* src, uint64_t len) {
   const uint64_t G = (uint64_t)g_shard.world, r = (uint64_t)g_shard.rank;
   const uint64_t nloc = len > r ? (len - r + G - 1) / G : 0;
-  if (nloc) hipLaunchKernelGGL(nttdist::slice_c_kernel, dim3(grid256(nloc)), dim3(256), 0, c.stream, dst, src, (u64)nloc, (u32)r, (u32)G);
+  if (nloc && g_job.poison == MH_OK) hipLaunchKernelGGL(nttdist::slice_c_kernel, dim3(grid256(nloc)), dim3(256), 0, c.stream, dst, src, (u64)nloc, (u32)r, (u32)G);
   return nloc;
 }
 // all ranks' (a | b) chunks, rank-major: the all-to-all with the same chunk for every peer
@@ -877,7 +1058,7 @@ int allgather2(Context& c, const Fr* a, uint64_t na, const Fr* b, uint64_t nb, c
   if (lrc == MH_OK) L(c.sl_recv.ensure(G * ch * 32));
   void* snd = c.sl_send.ptr; void* rcv = c.sl_recv.ptr;
   if (c.sl_send.cap < copies * ch * 32 || c.sl_recv.cap < G * ch * 32) {
-    if (g_job.buf_bytes < G * ch * 32) return fail(MH_ENOMEM, "sliced prove: no exchange buffer (this rank cannot enter the all-gather)");
+    if (g_job.buf_bytes < G * ch * 32) { g_job.failed = true; return fail(MH_ENOMEM, "sliced prove: no exchange buffer (this rank cannot enter the all-gather)"); }
     snd = g_job.buf[0]; rcv = g_job.buf[1];
   }
   if (lrc == MH_OK) {
@@ -888,8 +1069,9 @@ int allgather2(Context& c, const Fr* a, uint64_t na, const Fr* b, uint64_t nb, c
   {
     ExchangeScope xs(c);
     if (g_shard.ag_dev) {
-      if (g_shard.ag_dev(snd, (size_t)ch * 32, rcv, g_shard.ag_dev_user) != 0) return fail(MH_EHIP, "sliced prove: all_gather failed: " + g_err);
+      if (g_shard.ag_dev(snd, (size_t)ch * 32, rcv, g_shard.ag_dev_user) != 0) { g_job.failed = true; return fail(MH_EHIP, "sliced prove: all_gather failed: " + g_err); }
     } else if (g_shard.a2a(snd, (size_t)ch * 32, rcv, g_shard.a2a_user) != 0) {
+      g_job.failed = true;
       return fail(MH_EHIP, "sliced prove: all_to_all failed: " + g_err);
     }
   }
@@ -897,6 +1079,7 @@ int allgather2(Context& c, const Fr* a, uint64_t na, const Fr* b, uint64_t nb, c
   return lrc == MH_OK ? MH_OK : fail(lrc, g_job.msg);
 }
 void unslice_c(Context& c, Fr* full, const Fr* recv, uint64_t len, uint64_t stride, uint64_t off) {
+  if (g_job.poison != MH_OK || !recv) return;        // a poisoned rank launches nothing more (its receive buffer may not exist)
   hipLaunchKernelGGL(nttdist::unslice_c_kernel, dim3(grid256(len)), dim3(256), 0, c.stream, full, recv, (u64)len, (u32)g_shard.world, (u64)stride, (u64)off);
 }
 
@@ -945,6 +1128,7 @@ int mh_ntt_dist_dev(int field, const void* d_in, void* d_out, uint32_t log_n, in
   if (field != hostff::CURVE_ID) return fail(MH_EINVAL, "mh_ntt_dist_dev: unsupported field");
   if (!d_in || !d_out) return fail(MH_EINVAL, "mh_ntt_dist_dev: null pointer");
   if (g_shard.world == 1) return ntt_device(c, d_in, d_out, log_n, inverse);
+  g_job = JobStatus();                           // a standalone call is its own job
   return ntt_dist_device(c, d_in, (1ull << log_n) / (uint64_t)g_shard.world, d_out, log_n, inverse);
 }
 
@@ -995,7 +1179,10 @@ int mh_msm_batch_sharded_dev(size_t njobs, const uint64_t* handles, const size_t
     jobs[j] = {(const char*)it->second.d_points + base_offsets[j] * PT_B, (const Fr*)d_scalars[j], ns[j]};
   }
   std::vector<HG1> res;
-  MH_TRY(sharded_msm_batch(c, jobs, res, is_mont));
+  g_job = JobStatus();                           // a standalone call is its own job
+  const int rc = sharded_msm_batch(c, jobs, res, is_mont);
+  g_job = JobStatus();
+  MH_TRY(rc);
   for (size_t j = 0; j < njobs; j++) {
     uint64_t* o = out_xyz + XYZ_L * j;
     memcpy(o, res[j].X.v, FQ_B); memcpy(o + FQ_L, res[j].Y.v, FQ_B); memcpy(o + 2 * FQ_L, res[j].Z.v, FQ_B);
@@ -1086,15 +1273,15 @@ int mh_marlin_proof_deserialize(const uint8_t* bytes, size_t len, int pc, uint8_
   return wire_copy_out(v, flat_out, cap, len_out, "mh_marlin_proof_deserialize");
 }
 // host-only hook: runs the registered all_gather once (used by the CPU gloo test of the callback plumbing)
-int mh_marlin_test_allgather(const void* send, size_t bytes, void* recv) {
+int mh_marlin_probe_allgather(const void* send, size_t bytes, void* recv) {
   if (!g_shard.cb) return fail(MH_EINVAL, "no all_gather callback registered");
   return g_shard.cb(send, bytes, recv, g_shard.user);
 }
 // the registered device exchanges, run once on the caller's device buffers and drained (self-tests of a transport: what the
 // sliced sections would call, without a proof around it).  which = 0: all-to-all (bytes = per peer), 1: device all-gather
-int mh_marlin_test_exchange_dev(int which, const void* d_send, size_t bytes, void* d_recv) {
+int mh_marlin_probe_exchange_dev(int which, const void* d_send, size_t bytes, void* d_recv) {
   LOCKED_CTX();
-  if (!d_send || !d_recv) return fail(MH_EINVAL, "mh_marlin_test_exchange_dev: null pointer");
+  if (!d_send || !d_recv) return fail(MH_EINVAL, "mh_marlin_probe_exchange_dev: null pointer");
   if (which == 0) {
     if (!g_shard.a2a) return fail(MH_EINVAL, "no all_to_all registered");
     if (!g_shard.a2a_ordered) MH_HIP(hipStreamSynchronize(c.stream));
@@ -1343,7 +1530,7 @@ int mh_marlin_index_pc(const mh_r1cs_matrices* m, uint64_t srs_g, uint64_t srs_g
   MH_TRY(ensure_twiddles_public(c, std::max(pk.logK + 1, pk.logH + 2)));
   MH_HIP(hipStreamSynchronize(c.stream));
   trace.mark("Marlin::Index: workspace + twiddles");
-  uint64_t h = g_next_pk++;
+  uint64_t h = mh::g_next_handle++;
   g_pks[h] = std::move(pkp);
   *pk_out = h;
   return MH_OK;
@@ -1455,6 +1642,9 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   Trace tr(c);
   Fr* S[8]; for (int i = 0; i < 8; i++) S[i] = pk.S[i].fr();
   g_job = JobStatus();                          // see JobStatus: a rank that fails locally fails the job instead of hanging it
+  // ... and whichever way the proof ends, nothing of its status outlives it: the building blocks below are also reachable through
+  // mh_msm_batch_sharded_dev / mh_ntt_dist_dev, and a stale `failed` or `poison` there would fail or silently skip work
+  struct JobGuard { ~JobGuard() { g_job = JobStatus(); } } job_guard;
   g_job.buf[0] = S[6]; g_job.buf[1] = S[7]; g_job.buf_bytes = std::min(pk.S[6].bytes, pk.S[7].bytes);
   const Fr* tw = (const Fr*)c.tw;
   // sliced sections (rounds 2 and 3 on 1 / G of every 4H- and K-sized vector): with an all-to-all registered and a
@@ -1842,7 +2032,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     memcpy(&snd[0], Eb.v, 32); memcpy(&snd[4], Eg.v, 32);
     {
       ExchangeScope xs(c);
-      if (g_shard.cb(snd.data(), 64, all_e.data(), g_shard.user) != 0) return fail(MH_EHIP, "sliced openings: all_gather failed: " + g_err);
+      if (g_shard.cb(snd.data(), 64, all_e.data(), g_shard.user) != 0) { g_job.failed = true; return fail(MH_EHIP, "sliced openings: all_gather failed: " + g_err); }
     }
     auto carry = [&](int which, const HFr& z, uint64_t L, uint64_t qlen, uint64_t len) {
       HFr acc = HFr::zero();

@@ -17,6 +17,7 @@
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types and prototypes only: every function is reached through dlsym
+#include <mutex>
 #include <string>
 #include "context.h"
 
@@ -41,18 +42,20 @@ struct Api {
   std::string path;
 };
 
+// the function table is the process's; a communicator (and its staging) belongs to a context (prover.hip: ProverState::rccl)
+inline Api& api() { static Api a; return a; }
 struct State {
-  Api api;
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
   mh::Scratch d_send, d_recv;                 // device staging of the host all-gather (partial points: <= a few KB)
   mh::Pinned h_send, h_recv;
   uint64_t n_allgather_host = 0, n_alltoall = 0, n_allgather_dev = 0, bytes_moved = 0;
 };
-inline State& state() { static State s; return s; }
 
 inline int load_api() {
-  Api& a = state().api;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  Api& a = api();
   if (a.lib) return MH_OK;
   // the copy that is already mapped (a torch process) first, then the loader's search path, then the ROCm tree.
   // MH_RCCL_LIB=<path>: that library and no other -- the hook the tests use to run this transport at N > 1 on ONE GPU over a
@@ -97,7 +100,7 @@ inline int load_api() {
     ncclResult_t _r = (call);                                                                                 \
     if (_r != ncclSuccess) {                                                                                  \
       char _b[384];                                                                                           \
-      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, state().api.GetErrorString(_r), __FILE__, __LINE__); \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, api().GetErrorString(_r), __FILE__, __LINE__); \
       return mh::fail(MH_EHIP, _b);                                                                           \
     }                                                                                                         \
   } while (0)
@@ -105,16 +108,15 @@ inline int load_api() {
 inline int unique_id(uint8_t* out128) {
   MH_TRY(load_api());
   ncclUniqueId id;
-  MH_RCCL(state().api.GetUniqueId(&id));
+  MH_RCCL(api().GetUniqueId(&id));
   static_assert(sizeof(id) == NCCL_UNIQUE_ID_BYTES && NCCL_UNIQUE_ID_BYTES == 128, "ncclUniqueId is 128 opaque bytes");
   memcpy(out128, id.internal, sizeof(id));
   return MH_OK;
 }
 
-inline int destroy() {
-  State& s = state();
+inline int destroy(State& s) {
   if (s.comm) {
-    (void)s.api.CommDestroy(s.comm);
+    (void)api().CommDestroy(s.comm);
     s.comm = nullptr;
   }
   s.rank = 0; s.world = 1;
@@ -123,14 +125,13 @@ inline int destroy() {
 }
 
 // collective over all ranks: returns when this rank's communicator exists
-inline int init(Context& c, int rank, int world, const uint8_t* id128) {
+inline int init(Context& c, State& s, int rank, int world, const uint8_t* id128) {
   MH_TRY(load_api());
-  State& s = state();
-  if (s.comm) destroy();
+  if (s.comm) destroy(s);
   ncclUniqueId id;
   memcpy(id.internal, id128, sizeof(id));
   MH_HIP(hipSetDevice(c.device));
-  MH_RCCL(s.api.CommInitRank(&s.comm, world, id, rank));
+  MH_RCCL(api().CommInitRank(&s.comm, world, id, rank));
   s.rank = rank; s.world = world;
   s.d_send.hookable = s.d_recv.hookable = false;          // (mh_debug_fail_scratch never strikes the transport's own staging)
   s.n_allgather_host = s.n_alltoall = s.n_allgather_dev = s.bytes_moved = 0;
@@ -139,15 +140,15 @@ inline int init(Context& c, int rank, int world, const uint8_t* id128) {
 
 // mh_allgather_fn: `bytes` bytes of HOST memory from every rank into recv (rank-major).  The host needs the result (the
 // partial points feed the transcript), so this is the one exchange that ends in a stream synchronisation.
-inline int allgather_host(const void* send, size_t bytes, void* recv, void*) {
+inline int allgather_host(const void* send, size_t bytes, void* recv, void* user) {
   Context& c = mh::ctx();
-  State& s = state();
+  State& s = *static_cast<State*>(user);
   if (!s.comm) return fail(MH_EINVAL, "native RCCL transport: no communicator (mh_marlin_set_rccl)");
   MH_TRY(s.d_send.ensure(bytes)); MH_TRY(s.d_recv.ensure(bytes * s.world));
   MH_TRY(s.h_send.ensure(bytes)); MH_TRY(s.h_recv.ensure(bytes * s.world));
   memcpy(s.h_send.ptr, send, bytes);
   MH_HIP(hipMemcpyAsync(s.d_send.ptr, s.h_send.ptr, bytes, hipMemcpyHostToDevice, c.stream));
-  MH_RCCL(s.api.AllGather(s.d_send.ptr, s.d_recv.ptr, bytes, ncclUint8, s.comm, c.stream));
+  MH_RCCL(api().AllGather(s.d_send.ptr, s.d_recv.ptr, bytes, ncclUint8, s.comm, c.stream));
   MH_HIP(hipMemcpyAsync(s.h_recv.ptr, s.d_recv.ptr, bytes * s.world, hipMemcpyDeviceToHost, c.stream));
   MH_HIP(hipStreamSynchronize(c.stream));
   memcpy(recv, s.h_recv.ptr, bytes * s.world);
@@ -157,19 +158,19 @@ inline int allgather_host(const void* send, size_t bytes, void* recv, void*) {
 
 // mh_alltoall_fn on DEVICE buffers of the library, stream-ordered: chunk q of d_send goes to rank q, chunk q of d_recv comes
 // from rank q.  Returns as soon as the collective is enqueued.
-inline int alltoall_dev(const void* d_send, size_t bytes_per_peer, void* d_recv, void*) {
+inline int alltoall_dev(const void* d_send, size_t bytes_per_peer, void* d_recv, void* user) {
   Context& c = mh::ctx();
-  State& s = state();
+  State& s = *static_cast<State*>(user);
   if (!s.comm) return fail(MH_EINVAL, "native RCCL transport: no communicator (mh_marlin_set_rccl)");
-  if (s.api.AllToAll) {
-    MH_RCCL(s.api.AllToAll(d_send, d_recv, bytes_per_peer, ncclUint8, s.comm, c.stream));
+  if (api().AllToAll) {
+    MH_RCCL(api().AllToAll(d_send, d_recv, bytes_per_peer, ncclUint8, s.comm, c.stream));
   } else {
-    MH_RCCL(s.api.GroupStart());
+    MH_RCCL(api().GroupStart());
     for (int q = 0; q < s.world; q++) {
-      MH_RCCL(s.api.Send((const char*)d_send + (size_t)q * bytes_per_peer, bytes_per_peer, ncclUint8, q, s.comm, c.stream));
-      MH_RCCL(s.api.Recv((char*)d_recv + (size_t)q * bytes_per_peer, bytes_per_peer, ncclUint8, q, s.comm, c.stream));
+      MH_RCCL(api().Send((const char*)d_send + (size_t)q * bytes_per_peer, bytes_per_peer, ncclUint8, q, s.comm, c.stream));
+      MH_RCCL(api().Recv((char*)d_recv + (size_t)q * bytes_per_peer, bytes_per_peer, ncclUint8, q, s.comm, c.stream));
     }
-    MH_RCCL(s.api.GroupEnd());
+    MH_RCCL(api().GroupEnd());
   }
   s.n_alltoall++; s.bytes_moved += bytes_per_peer * (s.world - 1);
   return MH_OK;
@@ -177,11 +178,11 @@ inline int alltoall_dev(const void* d_send, size_t bytes_per_peer, void* d_recv,
 
 // all-gather of DEVICE buffers, stream-ordered (the round polynomials of the sliced sections: the callback transport has
 // to express this as an all-to-all of `world` copies of the same chunk)
-inline int allgather_dev(const void* d_send, size_t bytes, void* d_recv, void*) {
+inline int allgather_dev(const void* d_send, size_t bytes, void* d_recv, void* user) {
   Context& c = mh::ctx();
-  State& s = state();
+  State& s = *static_cast<State*>(user);
   if (!s.comm) return fail(MH_EINVAL, "native RCCL transport: no communicator (mh_marlin_set_rccl)");
-  MH_RCCL(s.api.AllGather(d_send, d_recv, bytes, ncclUint8, s.comm, c.stream));
+  MH_RCCL(api().AllGather(d_send, d_recv, bytes, ncclUint8, s.comm, c.stream));
   s.n_allgather_dev++; s.bytes_moved += bytes * (s.world - 1);
   return MH_OK;
 }

@@ -198,7 +198,7 @@ def selftest_allgather(dist=None):
     n = 600
     send = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(rank + 1)).view(np.uint8)
     recv = np.zeros(send.size * world, dtype=np.uint8)
-    if lib.mh_marlin_test_allgather(send.ctypes.data, send.size, recv.ctypes.data) != 0:
+    if lib.mh_marlin_probe_allgather(send.ctypes.data, send.size, recv.ctypes.data) != 0:
         return False
     want = np.concatenate([(np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(g + 1)).view(np.uint8) for g in range(world)])
     return bool(np.array_equal(recv, want))

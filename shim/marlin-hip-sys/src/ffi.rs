@@ -13,6 +13,17 @@ pub const MH_ENOMEM: c_int = -2;
 pub const MH_EHIP: c_int = -3;
 pub const MH_ENOINIT: c_int = -4;
 pub const MH_ENODEV: c_int = -5;
+pub const MH_ECHECK: c_int = -6;
+
+/// `mh_ctx_t` / `mh_group_t` (marlin_hip.h): opaque handles of a context (one GPU's worth of library state) and of a group of
+/// contexts joined by the in-process transport.
+#[repr(C)]
+pub struct mh_context { _private: [u8; 0] }
+pub type mh_ctx_t = *mut mh_context;
+#[repr(C)]
+pub struct mh_group { _private: [u8; 0] }
+pub type mh_group_t = *mut mh_group;
+pub type mh_group_fn = Option<unsafe extern "C" fn(rank: c_int, user: *mut c_void) -> c_int>;
 
 pub const MH_FIELD_BLS12_381_FR: c_int = 0;
 pub const MH_CURVE_BLS12_381_G1: c_int = 0;
@@ -73,6 +84,15 @@ extern "C" {
     pub fn mh_set_stream(hip_stream: *mut c_void) -> c_int;
     pub fn mh_synchronize() -> c_int;
     pub fn mh_device_info(name_out: *mut c_char, name_cap: usize, cu_count: *mut c_int, hbm_bytes: *mut usize) -> c_int;
+    pub fn mh_ctx_create(device_id: c_int, ctx_out: *mut mh_ctx_t) -> c_int;
+    pub fn mh_ctx_set_current(ctx: mh_ctx_t) -> c_int;
+    pub fn mh_ctx_get_current() -> mh_ctx_t;
+    pub fn mh_ctx_destroy(ctx: mh_ctx_t) -> c_int;
+    pub fn mh_group_create(device_ids: *const c_int, world: c_int, group_out: *mut mh_group_t) -> c_int;
+    pub fn mh_group_size(group: mh_group_t) -> c_int;
+    pub fn mh_group_ctx(group: mh_group_t, rank: c_int) -> mh_ctx_t;
+    pub fn mh_group_run(group: mh_group_t, f: mh_group_fn, user: *mut c_void) -> c_int;
+    pub fn mh_group_destroy(group: mh_group_t) -> c_int;
 
     // ---- device memory
     pub fn mh_alloc(bytes: usize, dptr_out: *mut *mut c_void) -> c_int;
@@ -146,7 +166,7 @@ extern "C" {
     pub fn mh_marlin_set_alltoall(alltoall: mh_alltoall_fn, user: *mut c_void) -> c_int;
     pub fn mh_marlin_set_alltoall_mode(stream_ordered: c_int) -> c_int;
     pub fn mh_marlin_set_allgather_dev(allgather_dev: mh_allgather_dev_fn, user: *mut c_void) -> c_int;
-    pub fn mh_marlin_test_exchange_dev(which: c_int, d_send: *const c_void, bytes: usize, d_recv: *mut c_void) -> c_int;
+    pub fn mh_marlin_probe_exchange_dev(which: c_int, d_send: *const c_void, bytes: usize, d_recv: *mut c_void) -> c_int;
     // native transport: RCCL called by the library on its own stream (marlin_amd/csrc/rccl_native.h)
     pub fn mh_rccl_unique_id(id128_out: *mut u8) -> c_int;
     pub fn mh_marlin_set_rccl(rank: c_int, world: c_int, id128: *const u8) -> c_int;
@@ -157,16 +177,15 @@ extern "C" {
     pub fn mh_ntt_dist_dev(field: c_int, d_in_local: *const c_void, d_out_local: *mut c_void, log_n: u32, inverse: c_int) -> c_int;
     pub fn mh_msm_batch_sliced_dev(bases_handle: u64, njobs: usize, first_index: *const usize, stride: usize, d_scalars_local: *const *const c_void,
                                    ns_local: *const usize, scalars_are_montgomery: c_int, combine: c_int, out_xyz_mont: *mut u64) -> c_int;
-    pub fn mh_marlin_test_allgather(send: *const c_void, bytes: usize, recv: *mut c_void) -> c_int;
+    pub fn mh_marlin_probe_allgather(send: *const c_void, bytes: usize, recv: *mut c_void) -> c_int;
     pub fn mh_marlin_get_poly(pk: u64, label: *const c_char, out: *mut u64, cap_elems: usize, len_out: *mut usize) -> c_int;
 
     // ---- profiling / self-test
     pub fn mh_prof_enable(on: c_int) -> c_int;
     pub fn mh_prof_reset() -> c_int;
     pub fn mh_prof_get(family: c_int, total_ms_out: *mut f64, launches_out: *mut u64) -> c_int;
-    pub fn mh_selftest_fq30(n: u64, seed: u64, mismatches_out: *mut u64) -> c_int;
-    pub fn mh_debug_fail_scratch(nth: c_int, calls_out: *mut u64) -> c_int;
-    pub fn mh_debug_poison_scratch(on: c_int) -> c_int;
+    pub fn mh_check_level(level: c_int) -> c_int;
+    pub fn mh_check_report(out: *mut c_char, cap: usize, counts2: *mut u64) -> c_int;
 }
 
 /// The library's thread-local message for the last failure on this thread.

@@ -246,6 +246,143 @@ impl GpuMarlin {
     }
 }
 
+// ---- N GPUs behind ONE `Marlin::prove` -------------------------------------------------------------
+//
+// The reference has one caller (`src/lib.rs:151-155`) and rayon threads under it (`src/ahp/mod.rs:9-10`).  Two ways to keep that
+// shape with N GPUs:
+//   * `GpuGroup` -- ONE process: a context per GPU joined by the library's in-process transport (`mh_group_create`); `index` and
+//     `prove` run rank r's share on a library thread bound to context r (`mh_group_run`) and hand back rank 0's proof after
+//     checking that every rank produced the same bytes.  No RCCL, no launcher.
+//   * `GpuMarlin::join_rccl(rank, world, id)` -- one PROCESS per GPU (an MPI-style launcher): after it, the ordinary
+//     `GpuMarlin::{index, prove}` of that process are rank `rank` of a sharded prover over the library's own RCCL communicator.
+// Every rank must be given identical arguments (the same circuit, the same `zk_seed`); a rank that fails makes `prove` return
+// `Err` on EVERY rank from the same commit round (the error word travels with the partial points).
+
+/// One process, N GPUs.
+pub struct GpuGroup {
+    group: ffi::mh_group_t,
+    world: usize,
+}
+unsafe impl Send for GpuGroup {}
+unsafe impl Sync for GpuGroup {}
+
+/// Per-rank prover keys of a group (each lives in its rank's context and is freed there).
+pub struct GpuGroupKey<'g> {
+    group: &'g GpuGroup,
+    keys: Vec<Option<GpuIndexProverKey>>,
+    pub index_vk: IndexVerifierKey<Fr, MultiPC>,
+}
+
+impl GpuGroup {
+    /// `devices[r]` = the HIP device of rank r (a device may repeat).
+    pub fn new(devices: &[i32]) -> Result<Self, HipError> {
+        let mut group: ffi::mh_group_t = core::ptr::null_mut();
+        check(unsafe { ffi::mh_group_create(devices.as_ptr(), devices.len() as i32, &mut group) })?;
+        Ok(GpuGroup { group, world: devices.len() })
+    }
+    pub fn world(&self) -> usize { self.world }
+
+    /// `f(rank)` on `world` library threads, thread r bound to context r; the first failing rank's error comes back.
+    fn run<T: Send, F: Fn(usize) -> Result<T, HipError> + Sync>(&self, f: F) -> Result<Vec<T>, HipError> {
+        use core::ffi::c_void;
+        struct Job<'a, T, F> { f: &'a F, out: Vec<std::sync::Mutex<Option<Result<T, HipError>>>> }
+        unsafe extern "C" fn tramp<T: Send, F: Fn(usize) -> Result<T, HipError> + Sync>(rank: i32, user: *mut c_void) -> i32 {
+            let job = &*(user as *const Job<T, F>);
+            // a panic must not unwind into the library's C++ frames
+            let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| (job.f)(rank as usize)))
+                .unwrap_or(Err(HipError::Unsupported("a rank panicked")));
+            let rc = if r.is_ok() { 0 } else { ffi::MH_EHIP };
+            *job.out[rank as usize].lock().unwrap() = Some(r);
+            rc
+        }
+        let job = Job { f: &f, out: (0..self.world).map(|_| std::sync::Mutex::new(None)).collect() };
+        let cb: ffi::mh_group_fn = Some(tramp::<T, F>);
+        let user = &job as *const Job<T, F> as *mut c_void;
+        let rc = unsafe { ffi::mh_group_run(self.group, cb, user) };
+        let mut res = Vec::with_capacity(self.world);
+        for slot in job.out {
+            match slot.into_inner().unwrap() {
+                Some(Ok(v)) => res.push(v),
+                Some(Err(e)) => return Err(e),
+                None => { check(rc)?; return Err(HipError::Unsupported("a rank did not run")); }
+            }
+        }
+        Ok(res)
+    }
+
+    /// `Marlin::index` on every rank (the index is never sharded: every GPU holds the whole key and the whole window table).
+    pub fn index<C: ConstraintSynthesizer<Fr> + Clone + Sync>(
+        &self,
+        srs: &UniversalSRS<Fr, MultiPC>,
+        c: C,
+    ) -> Result<GpuGroupKey<'_>, HipError> {
+        let keys = self.run(|_rank| GpuMarlin::index(srs, c.clone()).map(|(pk, _vk)| pk))?;
+        let index_vk = keys[0].index_vk.clone();
+        Ok(GpuGroupKey { group: self, keys: keys.into_iter().map(Some).collect(), index_vk })
+    }
+
+    /// ONE `Marlin::prove` on all GPUs of the group: bucket-range-sharded MSMs, sliced rounds from 4 ranks on.
+    pub fn prove<C: ConstraintSynthesizer<Fr> + Clone + Sync>(
+        &self,
+        key: &GpuGroupKey<'_>,
+        c: C,
+        zk_seed: [u8; 32],
+    ) -> Result<Proof<Fr, MultiPC>, HipError> {
+        use ark_serialize::CanonicalSerialize;
+        let proofs = self.run(|rank| GpuMarlin::prove(key.keys[rank].as_ref().unwrap(), c.clone(), zk_seed))?;
+        let bytes = |p: &Proof<Fr, MultiPC>| { let mut v = Vec::new(); p.serialize(&mut v).unwrap(); v };
+        let first = bytes(&proofs[0]);
+        if proofs.iter().skip(1).any(|p| bytes(p) != first) {
+            return Err(HipError::Unsupported("the ranks of a sharded proof disagree"));
+        }
+        Ok(proofs.into_iter().next().unwrap())
+    }
+}
+
+impl Drop for GpuGroupKey<'_> {
+    fn drop(&mut self) {
+        // each key is freed inside its own context (handles belong to the context that made them)
+        let keys: Vec<std::sync::Mutex<Option<GpuIndexProverKey>>> = self.keys.drain(..).map(std::sync::Mutex::new).collect();
+        let _ = self.group.run(|rank| { drop(keys[rank].lock().unwrap().take()); Ok(()) });
+    }
+}
+
+impl Drop for GpuGroup {
+    fn drop(&mut self) { unsafe { ffi::mh_group_destroy(self.group); } }
+}
+
+impl GpuMarlin {
+    /// Rank 0 of a process-per-GPU job draws the communicator's id; the caller's launcher hands the 128 bytes to every rank.
+    pub fn rccl_unique_id() -> Result<[u8; 128], HipError> {
+        let mut id = [0u8; 128];
+        check(unsafe { ffi::mh_rccl_unique_id(id.as_mut_ptr()) })?;
+        Ok(id)
+    }
+
+    /// Collective over the `world` processes of the job: afterwards this process's `GpuMarlin::{index, prove}` are rank `rank` of
+    /// a sharded prover (`mh_marlin_set_rccl`).  Call after `mh_init(device)` (`ensure_init`) and before `index`.
+    pub fn join_rccl(rank: usize, world: usize, id: &[u8; 128]) -> Result<(), HipError> {
+        ensure_init();
+        check(unsafe { ffi::mh_marlin_set_rccl(rank as i32, world as i32, id.as_ptr()) })
+    }
+
+    /// `Marlin::prove` as rank `rank` of `world` processes, in one call: joins the communicator if this process has not yet, then
+    /// proves.  Every rank returns the same proof (or every rank returns `Err`).
+    pub fn prove_sharded<C: ConstraintSynthesizer<Fr>>(
+        pk: &GpuIndexProverKey,
+        c: C,
+        zk_seed: [u8; 32],
+        rank: usize,
+        world: usize,
+        id: &[u8; 128],
+    ) -> Result<Proof<Fr, MultiPC>, HipError> {
+        let mut info = [0u64; 4];
+        let active = unsafe { ffi::mh_marlin_rccl_info(info.as_mut_ptr(), core::ptr::null_mut(), 0) };
+        if active == 0 { Self::join_rccl(rank, world, id)?; }
+        Self::prove(pk, c, zk_seed)
+    }
+}
+
 /// `ToBytes` images (uncompressed, with presence bytes) -> upstream commitment structs.
 pub mod wire {
     use ark_bls12_381::{Bls12_381, Fq, G1Affine};

@@ -25,6 +25,27 @@ def test_header_symbols_exported_and_bound():
     assert sorted(_lib.SYMBOLS) == names
 
 
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("mh_"))
+
+
+def test_the_product_library_exports_the_header_and_nothing_else():
+    """the libraries are built with -fvisibility=hidden; `nm -D libmarlin_hip.so` lists exactly the entry
+    points include/marlin_hip.h declares -- no debug hook, no self-test, no internal helper -- on both curves, and the hooks
+    libraries (the same objects + testhooks.hip) add exactly what include/marlin_hip_testhooks.h declares."""
+    names = _declared()
+    hooks_hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "marlin_hip_testhooks.h")).read(), flags=re.S)
+    hooks = sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", hooks_hdr)))
+    assert hooks == sorted(_lib.HOOK_SYMBOLS) and len(hooks) >= 4
+    for lib, hk in (("libmarlin_hip.so", "libmarlin_hip_testhooks.so"), ("libmarlin_hip_bn254.so", "libmarlin_hip_bn254_testhooks.so")):
+        got = _exported(os.path.join(ROOT, "marlin_amd", lib))
+        assert got == names, (lib, set(got) ^ set(names))
+        assert not [n for n in got if "debug" in n or "selftest" in n or "_test_" in n], lib
+        assert _exported(os.path.join(ROOT, "marlin_amd", hk)) == sorted(names + hooks), hk
+
+
 def test_no_device_fails_loudly():
     import torch
     if torch.cuda.is_available():
@@ -60,8 +81,9 @@ def _c_prototypes():
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     hdr = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", hdr, flags=re.S)
     hdr = re.sub(r"typedef\s+int\s*\(\*\w+\)\s*\(.*?\)\s*;", "", hdr, flags=re.S)
+    hdr = re.sub(r"typedef\s+struct\s+\w+\s*\*\s*\w+\s*;", "", hdr)
     out = {}
-    for ret, name, args in re.findall(r"\b(int|const char\s*\*)\s+(mh_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
+    for ret, name, args in re.findall(r"\b(int|const char\s*\*|mh_ctx_t)\s+(mh_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
         params = []
         if args.strip() not in ("", "void"):
             for a in args.split(","):
@@ -77,7 +99,7 @@ def _c_prototypes():
 _C2RUST_BASE = {"int": "c_int", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "char": "c_char", "void": "c_void",
                 "double": "f64", "mh_r1cs_matrices": "mh_r1cs_matrices", "mh_verifier_key": "mh_verifier_key",
                 "mh_allgather_fn": "mh_allgather_fn", "mh_alltoall_fn": "mh_alltoall_fn", "mh_allgather_dev_fn": "mh_allgather_dev_fn",
-                "mh_fiat_shamir": "mh_fiat_shamir"}
+                "mh_fiat_shamir": "mh_fiat_shamir", "mh_ctx_t": "mh_ctx_t", "mh_group_t": "mh_group_t", "mh_group_fn": "mh_group_fn"}
 
 
 def _c_to_rust(ctype):
@@ -129,7 +151,7 @@ def test_rust_and_ctypes_signatures_match_the_header():
                 assert at is getattr(C, _RUST2CTYPES[rt]), (name, k, ct, at)
             else:
                 assert at in (C.c_void_p, C.c_char_p) or issubclass(at, C._Pointer), (name, k, ct, at)
-        assert res is (C.c_char_p if "char" in cret else C.c_int), (name, res)
+        assert res is (C.c_char_p if "char" in cret else (C.c_void_p if cret == "mh_ctx_t" else C.c_int)), (name, res)
     # the callback typedefs and the two structs, field for field
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "marlin_hip.h")).read(), flags=re.S)
     for tname, args in re.findall(r"typedef\s+int\s*\(\*(\w+)\)\s*\(([^)]*)\)\s*;", hdr):

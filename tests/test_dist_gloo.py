@@ -46,7 +46,7 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 D.enable_sharded_prove(dist)
 send = np.arange(18, dtype=np.uint64) + 1000 * rank
 recv = np.zeros(18 * world, dtype=np.uint64)
-rc = _lib.load().mh_marlin_test_allgather(send.ctypes.data, send.nbytes, recv.ctypes.data)
+rc = _lib.load().mh_marlin_probe_allgather(send.ctypes.data, send.nbytes, recv.ctypes.data)
 assert rc == 0
 for g in range(world):
     assert (recv[18 * g: 18 * (g + 1)] == np.arange(18, dtype=np.uint64) + 1000 * g).all()
@@ -55,7 +55,7 @@ for g in range(world):
 for words in (74, 38, 74, 20, 600, 38, 74):
     send = np.arange(words, dtype=np.uint64) * 3 + 1000 * rank
     recv = np.zeros(words * world, dtype=np.uint64)
-    assert _lib.load().mh_marlin_test_allgather(send.ctypes.data, send.nbytes, recv.ctypes.data) == 0
+    assert _lib.load().mh_marlin_probe_allgather(send.ctypes.data, send.nbytes, recv.ctypes.data) == 0
     for g in range(world):
         assert (recv[words * g: words * (g + 1)] == np.arange(words, dtype=np.uint64) * 3 + 1000 * g).all()
 D.disable_sharded_prove()

@@ -656,7 +656,7 @@ send = np.arange(1, 41, dtype=np.uint64)                 # the size of a two-job
 recv = np.zeros(40, dtype=np.uint64)
 for _ in range(3):                                       # persistent staging buffers are reused
     recv[:] = 0
-    _lib.check(_lib.load().mh_marlin_test_allgather(send.ctypes.data, send.nbytes, recv.ctypes.data), "test_allgather")
+    _lib.check(_lib.load().mh_marlin_probe_allgather(send.ctypes.data, send.nbytes, recv.ctypes.data), "test_allgather")
     assert np.array_equal(send, recv)
 t = torch.ones(8, device="cuda"); dist.all_reduce(t); assert float(t.sum()) == 8.0
 # the all-to-all of the distributed transforms: the registered callback on two of the library's own device buffers

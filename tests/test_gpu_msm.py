@@ -2,7 +2,9 @@
 Bit-exact after affine normalisation (the form the reference serialises/hashes)."""
 import os
 import numpy as np
+import os
 import pytest
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from oracle import fields as F
 from oracle import curve as EC
 from tests.util import fr_to_np, points_to_np, jac_np_to_affine, arith_bases, rand_fr, limbs_to_fq
@@ -301,15 +303,15 @@ def test_msm_fixed_base_jobs_sharing_scalars(gpu, bases4k):
 
 def test_fq30_device_selftest(gpu):
     """the 30-bit-limb field / group arithmetic of the fixed-base path agrees with the 32-bit Montgomery arithmetic on
-    2^18 pseudo-random operand pairs plus structured ones (mh_selftest_fq30)."""
-    import ctypes as C
-    from marlin_amd import _lib
-    for seed in (1, 2):
-        bad = C.c_uint64(123)
-        _lib.check(_lib.load().mh_selftest_fq30(1 << 18, seed, C.byref(bad)), "mh_selftest_fq30")
-        assert bad.value == 0
-
-
+    2^18 pseudo-random operand pairs plus structured ones (mh_selftest_fq30: a hook of libmarlin_hip_testhooks.so -- the product's
+    objects + testhooks.hip --, so it runs in a process that loads that library)."""
+    import subprocess, sys
+    from tests.util import hooks_env
+    code = ("import ctypes as C, marlin_amd as M\nfrom marlin_amd import _lib\nM.init(0)\n"
+            "for seed in (1, 2):\n    bad = C.c_uint64(123)\n    _lib.check(_lib.load().mh_selftest_fq30(1 << 18, seed, C.byref(bad)), 'selftest')\n"
+            "    assert bad.value == 0, bad.value\nprint('selftest ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=hooks_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
 
 
 def test_fixed_base_msm_at_2p22_matches_the_c_restatement(gpu):

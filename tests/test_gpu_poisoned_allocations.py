@@ -1,6 +1,6 @@
 """Uninitialised-memory check: a kernel that reads device memory nothing has written yet usually gets zeros on a fresh process -- the
 identity point, the zero polynomial -- and the result is right by accident; after other work has been through the heap it gets
-garbage, once in a while.  With mh_debug_poison_scratch(1) every allocation the library makes is filled with 0xA5 bytes first, so
+garbage, once in a while.  With mh_debug_poison_scratch(1) (a hook of libmarlin_hip_testhooks.so, which the re-run loads) every allocation the library makes is filled with 0xA5 bytes first, so
 such a read fails every time.  The MSM, NTT, golden-proof and sliced building-block tests are run once more that way (the `gpu`
 fixture arms the hook when MARLIN_TEST_POISON is set)."""
 import os
@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import pytest
+from tests.util import hooks_env
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,5 +20,5 @@ def test_msm_ntt_proofs_and_sliced_blocks_with_poisoned_allocations():
                         "tests/test_gpu_msm.py", "tests/test_gpu_ntt.py", "tests/test_gpu_marlin.py", "tests/test_gpu_dist_blocks.py",
                         "-k", "(test_gpu_msm and not 2p22) or (test_gpu_ntt and not large) or proof_bytes_match_golden or zero_matrix "
                               "or sonic_proof or (distributed_ntt and 4-logs1) or skewed"],
-                       cwd=ROOT, env=dict(os.environ, MARLIN_TEST_POISON="1"), capture_output=True, text=True, timeout=900)
+                       cwd=ROOT, env=hooks_env(MARLIN_TEST_POISON="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]

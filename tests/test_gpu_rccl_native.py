@@ -42,7 +42,7 @@ x = np.random.default_rng(5).integers(0, 1 << 62, size=(1 << 14, 4), dtype=np.ui
 a, b = M.DeviceBuffer.from_numpy(x), M.DeviceBuffer(x.nbytes)
 for which in (0, 1, 0, 1):
     b.upload(np.zeros_like(x))
-    _lib.check(lib.mh_marlin_test_exchange_dev(which, a.ptr, x.nbytes, b.ptr), "test_exchange_dev")
+    _lib.check(lib.mh_marlin_probe_exchange_dev(which, a.ptr, x.nbytes, b.ptr), "test_exchange_dev")
     assert np.array_equal(b.download(x.shape), x), which
 info = MD.native_rccl_info()
 assert info["allgather_host"] == 3 and info["alltoall"] == 2 and info["allgather_dev"] == 2, info
@@ -55,7 +55,7 @@ MD.disable_sharded_prove()
 assert MD.native_rccl_info()["active"] is False
 assert MD.enable_native_rccl(None, sliced=False)
 assert MD.selftest_allgather(None)
-rc = lib.mh_marlin_test_exchange_dev(0, a.ptr, x.nbytes, b.ptr)
+rc = lib.mh_marlin_probe_exchange_dev(0, a.ptr, x.nbytes, b.ptr)
 assert rc != 0, "sliced = False must unregister the all-to-all"
 MD.disable_sharded_prove()
 M.shutdown() if hasattr(M, "shutdown") else lib.mh_shutdown()
@@ -97,7 +97,7 @@ x = np.random.default_rng(6).integers(0, 1 << 62, size=(1 << 13, 4), dtype=np.ui
 a, b = M.DeviceBuffer.from_numpy(x), M.DeviceBuffer(x.nbytes)
 for which in (1, 0, 1):
     b.upload(np.zeros_like(x))
-    _lib.check(lib.mh_marlin_test_exchange_dev(which, a.ptr, x.nbytes, b.ptr), "test_exchange_dev")
+    _lib.check(lib.mh_marlin_probe_exchange_dev(which, a.ptr, x.nbytes, b.ptr), "test_exchange_dev")
     assert np.array_equal(b.download(x.shape), x), which
 st = MD._keepalive["a2a_state"]
 assert st["zero_copy"] and st["stream_ordered"] and st["calls"] == 3, st
@@ -320,7 +320,8 @@ def test_a_rank_that_fails_mid_prove_fails_the_job_on_every_rank(gpu, tmp_path, 
     script = tmp_path / "fail_worker.py"
     script.write_text(FAIL_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "sliced": sliced,
                                      "victim": victim, "fracs": fracs})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29871 + world + 10 * enqueued), WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK)
+    from tests.util import hooks_env          # mh_debug_fail_scratch lives in the hooks library (the product's objects + testhooks.hip)
+    env = hooks_env(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29871 + world + 10 * enqueued), WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK)
     if sliced:
         env["MH_SLICED"] = "2"
     if enqueued:

@@ -92,3 +92,14 @@ def auto_window_bits(n):
     if c == 17:
         c = 16
     return min(20, max(8, c))
+
+
+def hooks_env(env=None, **extra):
+    """environment of a subprocess that loads libmarlin_hip[_bn254]_testhooks.so (the product's objects + the test hooks of
+    include/marlin_hip_testhooks.h) instead of the product library, which exports no hook"""
+    import os
+    from marlin_amd import _lib
+    e = dict(os.environ if env is None else env)
+    e["MARLIN_AMD_LIB"] = _lib.HOOKS_LIB_PATH
+    e.update(extra)
+    return e

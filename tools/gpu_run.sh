@@ -14,6 +14,8 @@
 #   configs      the other BASELINE configurations (2^16 Sonic, 2^18, 2^22, BLS Sonic, BN254 Marlin / Sonic)
 #   small        the reference's own bench shape (2^16, SonicKZG10) with a kernel trace of the last prove and its gap analysis
 #   seam         the seam route (host pointers), with and without the short uploads of mh_ntt_len
+#   check        tests/test_gpu_check.py (the MH_CHECK invariants and their fault injection)
+#   soak=N[:D[:s]]  tools/soak_sliced.py: N iterations of the 8-process sliced-MSM scenario at MH_CHECK=2, MH_DIAG=D, s = AMD_SERIALIZE_KERNEL=3
 #   ab=<lib.so>  tools/ab.sh: alternate the in-tree build and another build of the same ABI
 set -u
 TAG=${1:?tag}; shift
@@ -73,6 +75,24 @@ for R in "$@"; do
       timeout 600 python bench.py --workload seam-route --steps 3 --warmup 1 > $O/bench_seam.json 2> $O/bench_seam.err
       BENCH_SEAM_FULL_UPLOAD=1 timeout 600 python bench.py --workload seam-route --steps 3 --warmup 1 > $O/bench_seam_full_upload.json 2>> $O/bench_seam.err
       line $O/bench_seam.json $O/bench_seam_full_upload.json ;;
+    check)          # the MH_CHECK tests by themselves
+      ( timeout 900 python -m pytest tests/test_gpu_check.py -m gpu -q -x --durations=8 -p no:cacheprovider > $O/pytest_check.log 2>&1; echo "pytest rc=$?" >> $O/pytest_check.log ); tail -25 $O/pytest_check.log ;;
+    soak=*)         # tools/soak_sliced.py: soak=<iterations>[:<MH_DIAG>[:serialize]] -- 8 processes on the GPU, MH_CHECK=2
+      IFS=: read -r IT DG SER <<< "${R#soak=}"
+      S=$O/soak_${IT}_diag${DG:-0}${SER:+_serialized}; mkdir -p $S
+      ( export MH_DIAG=${DG:-0}; [ -n "${SER:-}" ] && export AMD_SERIALIZE_KERNEL=3
+        timeout 3000 python tools/soak_sliced.py --world 8 --iters $IT --check 2 --out $S --timeout 2900 > $S/soak.log 2>&1; echo "soak rc=$?" >> $S/soak.log )
+      grep -E "^SOAK|soak rc|soak:" $S/soak.log | tail -12 ;;
+    fresh=*)        # fresh=<launches>: the soak's scenario from a cold start, again and again (a process's FIRST batch runs on fresh allocations)
+      NL=${R#fresh=}; S=$O/fresh_$NL; mkdir -p $S; : > $S/fresh.log
+      for i in $(seq 1 $NL); do timeout 300 python tools/soak_sliced.py --world 8 --iters 3 --check 2 --out $S --port $((29900 + i % 50)) --timeout 200 2>&1 | grep -E "^SOAK" >> $S/fresh.log; done
+      python - $S/fresh.log <<'PY'
+import json, sys
+rows = [json.loads(l[5:]) for l in open(sys.argv[1]) if l.startswith("SOAK ")]
+print("FRESH launches %d, sliced MSMs %d, mismatches %d, errors %d, violations %d" % (len(rows), sum(r["sliced_msms"] for r in rows),
+      sum(r["mismatches"] for r in rows), sum(r["errors"] for r in rows), sum(r["violations"] for r in rows)))
+PY
+      ;;
     ab=*)
       bash tools/ab.sh "${R#ab=}" --no-seam-route > $O/ab.txt 2>&1; cut -c1-330 $O/ab.txt ;;
     *) echo "unknown recipe $R" ;;
