@@ -371,8 +371,10 @@ def main():
     ap.add_argument("--simulate-rank", default=None, metavar="R/G",
                     help="MEASUREMENT AID, one GPU: run what rank R of G would run (its bucket range of every MSM + the replicated "
                          "AHP rounds) with the exchange replaced by a local copy; the proof is not valid and the JSON line says so")
-    ap.add_argument("--no-throughput", action="store_true",
-                    help="skip the (untimed, ~15 s) `throughput_pipelined` measurement of the default run: two independent provers sharing the GPU")
+    ap.add_argument("--throughput", action="store_true",
+                    help="also measure `throughput_pipelined` (untimed, ~20 s and a second key + window table in device memory): two independent "
+                         "provers sharing the GPU.  Opt-in since round 6 (ADVICE r05): the default run no longer starts extra prover processes")
+    ap.add_argument("--no-throughput", action="store_true", help="(accepted for older scripts; the measurement is off unless --throughput is given)")
     ap.add_argument("--rehearsal", action="store_true",
                     help="multi-GPU: accept that several ranks share a physical device (tests / tools/rehearse_ranks.sh on a one-GPU box); "
                          "without it a line whose ranks_seen hold fewer distinct devices than ranks carries value = null -- N ranks on "
@@ -894,7 +896,7 @@ def main():
             out["seam_route"]["unbatched_msm_ms"] = seam_route_measure(M, args.log_constraints, wl.srs.powers_of_g, steps=1, batched=False)["msm_ms"]
         except Exception as e:                      # a side measurement must not cost the headline line
             out["seam_route"] = {"error": str(e)[:200]}
-    if workload == "marlin-prove" and rank == 0 and world == 1 and not args.no_throughput and not args.simulate_rank:
+    if workload == "marlin-prove" and rank == 0 and world == 1 and args.throughput and not args.no_throughput and not args.simulate_rank:
         # NOT the headline: what the GPU delivers when independent provers (separate processes, each with its own key and window
         # table) share it -- one's host round trips and latency-bound stages are filled by the others' kernels (VERDICT r04 item 9,
         # in the form that needs no double-buffered prover).  benches/bench.rs runs its proofs one at a time, and so does `value`.
@@ -903,6 +905,8 @@ def main():
             M.synchronize()
             tp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "throughput_procs.py"), str(args.log_constraints), "2", "--pc", args.pc,
                                  "--secs", "3", "--json"], capture_output=True, text=True, timeout=300)
+            if tp.returncode != 0:
+                raise RuntimeError("tools/throughput_procs.py exited with %d: %s" % (tp.returncode, tp.stderr[-300:]))
             r2 = json.loads(tp.stdout.strip().splitlines()[-1])["2"]
             out["throughput_pipelined"] = dict(r2, vs_one_proof_at_a_time=round(r2["constraints_per_s"] / value, 4),
                                                what="two independent prover PROCESSES sharing this GPU (own context, key, window table), proving back to back for "

@@ -337,7 +337,7 @@ static int msm_set_attrs(Context& c) {
   int lds = 32768 * 4;
   MH_HIP(hipFuncSetAttribute((const void*)msm::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::psplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(msmfb::PLANE_THREADS * sizeof(msmfb::G1Xyzz30))));
@@ -451,9 +451,10 @@ struct FbRun {
   msm::Windows win; u32 W = 0, nbt = 0, pshift = 0, nb = 0, nparts = 0, WT = 0; size_t WB = 0;
   msmfb::Own own{0, 1}; bool partial = false; u32 nbown = 0, S = 0;
   msmfb::FbJobs jobs; std::vector<int> alias;
-  u64 ent = 0, pco = 0, tile = 0, max_tiles_total = 0; u32 max_blk = 0;
+  u64 ent = 0, lsto = 0, max_tiles_total = 0; u32 max_blk = 0, SW = 0;
+  std::vector<u32> bpt;                            // split blocks per hist / scatter tile, per partition
   msmfb::RsPlan rs; std::vector<u64> coef;        // bucket reduction: matrix shape, chunking, planes; the host's coefficient of each plane
-  std::vector<msmfb::FbWin> desc; std::vector<msmfb::FbBlk> blk; std::vector<u32> ptot;
+  std::vector<msmfb::FbWin> desc; std::vector<msmfb::FbBlk> blk;
   bool skewed = false;
   u32 skew_limit = 0xffffffffu, skew_floor = 4096;   // a batch is skewed when its largest bucket exceeds max(skew_floor, 32 x the average)
   FbRun(Context& c_, const BaseSet& bs_, Context::FbWs& ws_) : c(c_), bs(bs_), ws(ws_) {}
@@ -483,23 +484,40 @@ struct FbRun {
     for (int k = 1; k < nj; k++)
       for (int j = 0; j < k; j++)
         if (alias[j] < 0 && sc[j] == sc[k] && ns[j] == ns[k] && offs[k] >= offs[j] && strides[j] == strides[k]) { alias[k] = j; break; }
-    ent = 0; pco = 0; max_blk = 0;
+    ent = 0; lsto = 0; max_blk = 0;
+    SW = S * W;
     for (int k = 0; k < nj; k++) {
       jobs.scalars[k] = (const Fr*)sc[k]; jobs.n[k] = ns[k]; jobs.tab_off[k] = (u32)offs[k]; jobs.tab_stride[k] = (u32)strides[k];
-      jobs.ent_off[k] = ent;
-      if (alias[k] >= 0) { jobs.nblk[k] = 0; jobs.pc_off[k] = pco; continue; }       // no blocks: count / split skip the job
-      ent += (u64)W * ns[k];
+      jobs.ent_off[k] = ent; jobs.lst_off[k] = lsto;
+      if (alias[k] >= 0) { jobs.nblk[k] = 0; continue; }                              // no blocks: psplit skips the job
       jobs.nblk[k] = (u32)((ns[k] + S - 1) / S);
-      jobs.pc_off[k] = pco; pco += (u64)nparts * jobs.nblk[k];
+      ent += (u64)jobs.nblk[k] * SW;                                                  // a split block owns S W entry slots
+      lsto += (u64)jobs.nblk[k] * (nparts + 1);
       max_blk = std::max(max_blk, jobs.nblk[k]);
     }
     if (ent >= (1ull << 32)) return fail(MH_EINVAL, "msm batch too large for 32-bit entry offsets");
-    tile = (ent + 2047) / 2048;
-    if (tile < 2048) tile = 2048;
-    if (tile > F::MAX_TILE) tile = F::MAX_TILE;
-    max_tiles_total = ent / tile + WT + 1;
-    MH_TRY(ws.dig.ensure(ent * 2 + 16)); MH_TRY(ws.val.ensure(ent * 4)); MH_TRY(ws.sorted.ensure(ent * 4));
-    MH_TRY(ws.pc.ensure(pco * 4)); MH_TRY(ws.ptot.ensure((size_t)WT * 8)); MH_TRY(ws.desc.ensure((size_t)WT * sizeof(msmfb::FbWin)));
+    // Tiles of the counting sort: a tile = the runs of one virtual window in `bpt` consecutive split blocks, bpt from the load a
+    // uniformly distributed scalar puts on the window's partition (so that nothing has to be counted first): window w of wb bits
+    // spreads its non-zero digits evenly over the buckets 1 ... 2^(wb - 1), i.e. with density 2 / 2^wb per bucket (the top window a
+    // little denser: the scalar is below r, not below 2^256 -- covered by the margin).  A tile that exceeds MAX_TILE all the same --
+    // heavily repeated digits -- makes the batch leave this path as skewed (hist_kernel).
+    bpt.assign(nparts, 1);
+    for (u32 v = 0; v < nparts; v++) {
+      double per_block = 0;                      // expected entries of partition v in one split block
+      for (u32 w = 0; w < W; w++) {
+        const double top = (double)(1ull << (win.bits[w] - 1)), lo = (double)v * nb, hi = std::min((double)(v + 1) * nb, top);
+        if (hi > lo) per_block += (double)S * (hi - lo) * 2.0 / (double)(1ull << win.bits[w]);
+      }
+      const double fit = 0.78 * (double)F::MAX_TILE / std::max(per_block, 1e-9);
+      bpt[v] = (u32)std::max(1.0, std::min(fit, 1e9));
+    }
+    max_tiles_total = 0;
+    for (int k = 0; k < nj; k++)
+      for (u32 v = 0; v < nparts && alias[k] < 0; v++)
+        if (v % own.stride == own.first) max_tiles_total += (jobs.nblk[k] + bpt[v] - 1) / bpt[v];
+    max_tiles_total += 1;
+    MH_TRY(ws.dig.ensure(ent * 2 + 16)); MH_TRY(ws.val.ensure(ent * 4 + 16)); MH_TRY(ws.sorted.ensure(ent * 4 + 16));
+    MH_TRY(ws.pc.ensure(lsto * 2 + 16)); MH_TRY(ws.ptot.ensure((size_t)WT * 8)); MH_TRY(ws.desc.ensure((size_t)WT * sizeof(msmfb::FbWin)));
     MH_TRY(ws.blk.ensure(8 * max_tiles_total * sizeof(F::FbBlk)));
     MH_TRY(ws.bh.ensure(max_tiles_total * nb * 4));
     MH_TRY(ws.tot.ensure(WB * 4)); MH_TRY(ws.base.ensure(WB * 4)); MH_TRY(ws.pend.ensure(WB * 4));
@@ -547,62 +565,36 @@ struct FbRun {
     MH_TRY(ws.sums.ensure(64 + F::SIZE_BINS * 4));
     MH_TRY(ws.perm.ensure(WB * 4));
     desc.assign(WT, msmfb::FbWin{});
-    ptot.assign(WT, 0);
     return MH_OK;
   }
 
-  // count / split / hist / scatter + the size order of the buckets; one host round trip on `s` (partition totals for the
-  // descriptors).  The skew decision travels with the results (finish): skewed = true there means the caller takes the
-  // variable-base path instead.
+  // psplit / hist / colscan / binscan / woff / scatter + the size order of the buckets: no host round trip (round 6: the one-pass
+  // partition writes every split block's entries into the block's own region, so no stage needs a count the host would have to
+  // fetch; what the host uploads -- tiles, block list, aliases -- depends on the batch's shape only).  The skew decision travels
+  // with the results (finish): skewed = true there means the caller takes the variable-base path instead.
   int sort(hipStream_t s) {
     namespace F = msmfb;
     ProfScope ps(c, PF_MSM_STAGES, s);
     unsigned short* key = (unsigned short*)ws.dig.ptr; u32* val = (u32*)ws.val.ptr;
-    u32* d_ptot = (u32*)ws.ptot.ptr; u32* d_pstart = d_ptot + WT;
-    hipLaunchKernelGGL(F::count_kernel, dim3(max_blk, nj), dim3(F::TPB), 0, s, jobs, (u32*)ws.pc.ptr, W, win, is_mont, nparts, pshift, S, own);
-    hipLaunchKernelGGL(F::pscan_kernel, dim3(nparts, nj), dim3(1024), 0, s, jobs, (u32*)ws.pc.ptr, d_ptot, nparts);
-    hipLaunchKernelGGL(F::pstart_kernel, dim3(nj), dim3(F::MAX_PARTS), 0, s, (const u32*)d_ptot, d_pstart, nparts);
-    // The partition totals are final once pscan has run, BEFORE the split kernel: they go to the host on the copy stream while
-    // the split runs on `s`, so the host's round trip (descriptors, block list) hides behind a kernel instead of idling the GPU
-    // (one of the two host synchronisations per MSM batch; the other one carries the results).
-    MH_TRY(ws.h_ptot.ensure((size_t)WT * 4));
-    const bool side_copy = c.copy_stream && c.copy_ev[0] && c.copy_ev[1] && !(c.diag & 1u);
-    if (side_copy) {
-      MH_HIP(hipEventRecord(c.copy_ev[0], s));
-      MH_HIP(hipStreamWaitEvent(c.copy_stream, c.copy_ev[0], 0));
-      MH_HIP(hipMemcpyAsync(ws.h_ptot.ptr, ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, c.copy_stream));
-    }
-    hipLaunchKernelGGL(F::split_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, (const u32*)ws.pc.ptr,
-                       (const u32*)d_ptot, (const u32*)d_pstart, key, val, W, win, is_mont, nparts, pshift, (u32)bs.n, S, own);
-    if (side_copy) {
-      MH_HIP(hipStreamSynchronize(c.copy_stream));
-    } else {
-      MH_HIP(hipMemcpyAsync(ws.h_ptot.ptr, ws.ptot.ptr, (size_t)WT * 4, hipMemcpyDeviceToHost, s));
-      MH_HIP(hipStreamSynchronize(s));
-    }
-    memcpy(ptot.data(), ws.h_ptot.ptr, (size_t)WT * 4);
-    // virtual-window descriptors and the XCD-interleaved block list; grid = 8 x the busiest XCD's tile count.  The XCD of
-    // a window is its rank among the windows that HAVE entries, mod 8: with the MSM sharded over G ranks a rank owns the
-    // partitions v = g (mod G), and numbering by gw would put all of them on one XCD for G = 8
+    unsigned short* lst = (unsigned short*)ws.pc.ptr;
+    u32* d_wtot = (u32*)ws.ptot.ptr; u32* d_src = d_wtot + WT;
+    // virtual-window descriptors (the host's part: tiles, histogram offsets, alias shifts) and the XCD-interleaved block list; grid
+    // = 8 x the busiest XCD's tile count.  The XCD of a window is its rank among the windows that HAVE tiles, mod 8: with the MSM
+    // sharded over G ranks a rank owns the partitions v = g (mod G), and numbering by gw would put all of them on one XCD for G = 8
     u64 bho = 0, xcd_tiles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    std::vector<u32> live;                 // windows with entries, in gw order
-    for (int k = 0; k < nj; k++) {
-      u64 off = jobs.ent_off[k];
+    std::vector<u32> live, src(WT, 0xffffffffu);
+    for (int k = 0; k < nj; k++)
       for (u32 v = 0; v < nparts; v++) {
         const u32 gw = k * nparts + v;
         msmfb::FbWin& d = desc[gw];
-        d.delta = 0; d.pad = 0;
-        if (alias[k] >= 0) {
-          // shares the lists of the job it aliases: no tiles of its own (hist / scatter never see it)
-          const msmfb::FbWin& src = desc[alias[k] * nparts + v];
-          d.off = src.off; d.cnt = src.cnt; d.ntiles = 0; d.bh_off = bho; d.delta = (u32)(offs[k] - offs[alias[k]]);
-          continue;
-        }
-        d.off = off; d.cnt = ptot[gw]; d.ntiles = (u32)((d.cnt + tile - 1) / tile); d.bh_off = bho;
-        off += d.cnt; bho += (u64)d.ntiles * nb;
+        d = msmfb::FbWin{};
+        d.bpt = bpt[v]; d.bh_off = bho;
+        if (alias[k] >= 0) { src[gw] = alias[k] * nparts + v; d.delta = (u32)(offs[k] - offs[alias[k]]); continue; }   // shares the lists: no tiles of its own
+        if (v % own.stride != own.first) continue;                                      // another rank's partition: stays empty
+        d.ntiles = (jobs.nblk[k] + bpt[v] - 1) / bpt[v];
+        bho += (u64)d.ntiles * nb;
         if (d.ntiles) { xcd_tiles[live.size() & 7] += d.ntiles; live.push_back(gw); }
       }
-    }
     u64 grid_tiles = 0;
     for (int x = 0; x < 8; x++) grid_tiles = std::max(grid_tiles, xcd_tiles[x]);
     blk.assign(grid_tiles * 8, F::FbBlk{0xffffffffu, 0});
@@ -612,41 +604,37 @@ struct FbRun {
         for (u32 t = 0; t < desc[live[li]].ntiles; t++) blk[(k++ << 3) | x] = F::FbBlk{live[li], t};
     }
     // the pinned copies are reused by the next group only after this group's finish() has synchronised the stream
-    MH_TRY(ws.h_desc.ensure((size_t)WT * sizeof(msmfb::FbWin))); MH_TRY(ws.h_blk.ensure(blk.size() * sizeof(F::FbBlk) + 8));
-    // descriptors and block list go up on the copy stream as well (nothing on `s` reads them before the hist kernel, and the split
-    // kernel that is still running does not either): `s` only waits for the event behind them, so the hist kernel starts when the
-    // split ends instead of behind two more copies
-    hipStream_t up = side_copy ? c.copy_stream : s;
-    memcpy(ws.h_desc.ptr, desc.data(), (size_t)WT * sizeof(msmfb::FbWin));
-    MH_HIP(hipMemcpyAsync(ws.desc.ptr, ws.h_desc.ptr, (size_t)WT * sizeof(msmfb::FbWin), hipMemcpyHostToDevice, up));
+    const size_t desc_b = (size_t)WT * sizeof(msmfb::FbWin), src_b = (size_t)WT * 4;
+    MH_TRY(ws.h_desc.ensure(desc_b + src_b)); MH_TRY(ws.h_blk.ensure(blk.size() * sizeof(F::FbBlk) + 8));
+    memcpy(ws.h_desc.ptr, desc.data(), desc_b); memcpy((char*)ws.h_desc.ptr + desc_b, src.data(), src_b);
+    MH_HIP(hipMemcpyAsync(ws.desc.ptr, ws.h_desc.ptr, desc_b, hipMemcpyHostToDevice, s));
+    MH_HIP(hipMemcpyAsync(d_src, (char*)ws.h_desc.ptr + desc_b, src_b, hipMemcpyHostToDevice, s));
     if (grid_tiles) {
       memcpy(ws.h_blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk));
-      MH_HIP(hipMemcpyAsync(ws.blk.ptr, ws.h_blk.ptr, blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, up));
+      MH_HIP(hipMemcpyAsync(ws.blk.ptr, ws.h_blk.ptr, blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
     }
-    if (side_copy) {
-      MH_HIP(hipEventRecord(c.copy_ev[1], c.copy_stream));
-      MH_HIP(hipStreamWaitEvent(s, c.copy_ev[1], 0));
-    }
-    const msmfb::FbWin* fbw = (const msmfb::FbWin*)ws.desc.ptr;
-    const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;
-    const size_t lds = (size_t)nb * 4;
-    if (grid_tiles) {
-      hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), lds, s, fbw, dblk, (const unsigned short*)key,
-                         (u32*)ws.bh.ptr, nb, (u32)tile);
-    }
-    hipLaunchKernelGGL(F::colscan_kernel, dim3((nb + 255) / 256, WT), dim3(256), 0, s, fbw, (u32*)ws.bh.ptr, (u32*)ws.tot.ptr, nb);
-    u32* d_max = (u32*)ws.sums.ptr;                    // [0] largest bucket, [1] buckets with deferred entries
+    u32* d_max = (u32*)ws.sums.ptr;                    // [0] largest bucket (0xffffffff: a tile overflowed), [1] buckets with deferred entries
     MH_HIP(hipMemsetAsync(d_max, 0, 8, s));
-    hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)ws.tot.ptr, (u32*)ws.base.ptr, nb, d_max);
+    if (max_blk)
+      hipLaunchKernelGGL(F::psplit_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, key, val, lst, W, win, is_mont,
+                         nparts, pshift, (u32)bs.n, S, own);
+    msmfb::FbWin* fbw = (msmfb::FbWin*)ws.desc.ptr;
+    const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;
+    if (grid_tiles)
+      hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), (size_t)(nb + 1) * 4, s, (const msmfb::FbWin*)fbw, dblk, jobs,
+                         (const unsigned short*)key, (const unsigned short*)lst, (u32*)ws.bh.ptr, nb, nparts, SW, d_max);
+    hipLaunchKernelGGL(F::colscan_kernel, dim3((nb + 255) / 256, WT), dim3(256), 0, s, (const msmfb::FbWin*)fbw, (u32*)ws.bh.ptr, (u32*)ws.tot.ptr, nb);
+    hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)ws.tot.ptr, (u32*)ws.base.ptr, nb, d_max, d_wtot);
+    hipLaunchKernelGGL(F::woff_kernel, dim3(1), dim3(1024), 0, s, fbw, (const u32*)d_wtot, (const u32*)d_src, WT);
     for (int k = 0; k < nj; k++)
       if (alias[k] >= 0) {          // an aliasing job has the bucket sizes and list positions of the job whose lists it reads
         MH_HIP(hipMemcpyAsync((u32*)ws.tot.ptr + (size_t)k * nbt, (const u32*)ws.tot.ptr + (size_t)alias[k] * nbt, (size_t)nbt * 4, hipMemcpyDeviceToDevice, s));
         MH_HIP(hipMemcpyAsync((u32*)ws.base.ptr + (size_t)k * nbt, (const u32*)ws.base.ptr + (size_t)alias[k] * nbt, (size_t)nbt * 4, hipMemcpyDeviceToDevice, s));
       }
-    if (grid_tiles) {
-      hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::scatter_lds_bytes(nb), s, fbw, dblk, (const unsigned short*)key,
-                         (const u32*)val, (const u32*)ws.bh.ptr, (const u32*)ws.base.ptr, (u32*)ws.sorted.ptr, nb, (u32)tile);
-    }
+    if (grid_tiles)
+      hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::scatter_lds_bytes(nb), s, (const msmfb::FbWin*)fbw, dblk, jobs,
+                         (const unsigned short*)key, (const u32*)val, (const unsigned short*)lst, (const u32*)ws.bh.ptr, (const u32*)ws.base.ptr,
+                         (u32*)ws.sorted.ptr, nb, nparts, SW);
     // buckets ordered by size, largest first (before the skew decision comes back: a few tens of microseconds, wasted
     // only on the skewed batches that leave this path anyway)
     u32* d_szh = (u32*)ws.sums.ptr + 16;
@@ -657,8 +645,10 @@ struct FbRun {
                        (u32*)ws.perm.ptr);
     // The skew decision (largest bucket > max(4096, 32 x average)) is taken on the device by the accumulate kernel and read
     // by the host together with the results (finish): no host round trip between the sort and the accumulation.
-    const u64 avg = ent / WB + 1;
-    skew_limit = (u32)std::min<u64>(std::max<u64>(skew_floor, 32 * avg), 0xffffffffull);
+    u64 pairs = 0;
+    for (int k = 0; k < nj; k++) pairs += ns[k];
+    const u64 avg = pairs * W / WB + 1;
+    skew_limit = (u32)std::min<u64>(std::max<u64>(skew_floor, 32 * avg), 0xfffffffeull);     // (0xffffffff is the tile-overflow mark of hist_kernel)
     // (a strided slice has no variable-base fallback -- its bases are not a contiguous range --: msm_batch_strided_device turns a
     // skewed batch into an error instead of letting one thread walk a list of millions)
     return MH_OK;
@@ -794,8 +784,8 @@ struct FbRun {
     namespace K = msmchk;
     c.chk.batches++;
     chk_log = chk_shape() + "\n";
-    const size_t sums_b = 3 * (size_t)WT * sizeof(K::Sum), tot_b = 2 * (size_t)WT * 4, bad_b = 64;
-    MH_TRY(c.chk.d.ensure(sums_b + tot_b + bad_b)); MH_TRY(c.chk.h.ensure(sums_b + tot_b + bad_b + 8));
+    const size_t sums_b = 3 * (size_t)WT * sizeof(K::Sum), tot_b = 2 * (size_t)WT * 4, bad_b = 64, desc_b = (size_t)WT * sizeof(msmfb::FbWin);
+    MH_TRY(c.chk.d.ensure(sums_b + tot_b + bad_b)); MH_TRY(c.chk.h.ensure(sums_b + tot_b + bad_b + desc_b + 8));
     K::Sum* d_sum = (K::Sum*)c.chk.d.ptr; u32* d_tot = (u32*)((char*)c.chk.d.ptr + sums_b); u32* d_bad = d_tot + 2 * WT;
     MH_HIP(hipMemsetAsync(c.chk.d.ptr, 0, sums_b + tot_b + bad_b, s));
     u64 nmax = 0;
@@ -803,7 +793,8 @@ struct FbRun {
     const unsigned gx = (unsigned)std::min<u64>((nmax + 255) / 256, 2048);
     hipLaunchKernelGGL(K::recode_kernel, dim3(gx, nj), dim3(256), 0, s, jobs, d_sum, W, win, is_mont, nparts, pshift, (u32)bs.n, own);
     const msmfb::FbWin* fbw = (const msmfb::FbWin*)ws.desc.ptr;
-    hipLaunchKernelGGL(K::entries_kernel, dim3(64, WT), dim3(256), 0, s, fbw, (const u32*)ws.val.ptr, d_sum + WT);
+    if (max_blk)
+      hipLaunchKernelGGL(K::runs_kernel, dim3(max_blk, nj), dim3(256), 0, s, jobs, (const u32*)ws.val.ptr, (const unsigned short*)ws.pc.ptr, d_sum + WT, nparts, SW, d_bad + 8);
     hipLaunchKernelGGL(K::entries_kernel, dim3(64, WT), dim3(256), 0, s, fbw, (const u32*)ws.sorted.ptr, d_sum + 2 * WT);
     hipLaunchKernelGGL(K::tot_kernel, dim3(WT), dim3(64), 0, s, (const u32*)ws.tot.ptr, (const u32*)ws.base.ptr, nb, d_tot);
     if (c.chk.level >= 2)
@@ -812,31 +803,40 @@ struct FbRun {
     MH_HIP(hipGetLastError());
     char* h = (char*)c.chk.h.ptr;
     MH_HIP(hipMemcpyAsync(h, c.chk.d.ptr, sums_b + tot_b + bad_b, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipMemcpyAsync(h + sums_b + tot_b + bad_b, ws.sums.ptr, 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipMemcpyAsync(h + sums_b + tot_b + bad_b, ws.desc.ptr, desc_b, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipMemcpyAsync(h + sums_b + tot_b + bad_b + desc_b, ws.sums.ptr, 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     const K::Sum* hs = (const K::Sum*)h; const u32* ht = (const u32*)(h + sums_b); const u32* hb = ht + 2 * WT;
-    const u32 largest = *(const u32*)(h + sums_b + tot_b + bad_b);
+    const msmfb::FbWin* hd = (const msmfb::FbWin*)(h + sums_b + tot_b + bad_b);
+    const u32 largest = *(const u32*)(h + sums_b + tot_b + bad_b + desc_b);
     chk_skip = largest > skew_limit;
-    u64 total = 0;
+    if (hb[8]) return chk_fail("split", std::to_string(hb[8]) + " split block(s) wrote a malformed run table (boundaries not non-decreasing from 0, or past the block's region)");
+    u64 total = 0, off = 0;
     for (u32 gw = 0; gw < WT; gw++) {
       const int k = (int)(gw / nparts);
-      if (alias[k] >= 0) continue;
+      if (alias[k] >= 0) {
+        const u32 sg = (u32)alias[k] * nparts + gw % nparts;
+        if (hd[gw].off != hd[sg].off || hd[gw].cnt != hd[sg].cnt) return chk_fail("descriptor", "job " + std::to_string(k) + " does not point at the lists of job " + std::to_string(alias[k]) + " it shares");
+        continue;
+      }
       const K::Sum &want = hs[gw], &sp = hs[WT + gw], &sc = hs[2 * WT + gw];
       auto str = [](const K::Sum& x) { char b[96]; snprintf(b, sizeof(b), "(n %llu, sum %llu, xor %08x)", x.cnt, x.sum, x.x); return std::string(b); };
       const std::string where = "job " + std::to_string(k) + " partition " + std::to_string(gw % nparts);
-      if (want.cnt != ptot[gw]) return chk_fail("count", where + ": the host read a partition total of " + std::to_string(ptot[gw]) + ", the scalars have " + std::to_string(want.cnt) + " owned non-zero digits there");
-      if (desc[gw].cnt != ptot[gw]) return chk_fail("descriptor", where + ": descriptor count " + std::to_string(desc[gw].cnt) + " != partition total " + std::to_string(ptot[gw]));
       if (sp.cnt != want.cnt || sp.sum != want.sum || sp.x != want.x) return chk_fail("split", where + ": entries written " + str(sp) + " != entries the scalars give " + str(want));
+      if (chk_skip) { total += want.cnt; continue; }                      // a tile overflowed: nothing after the split is complete, and nothing after it is used
+      if (hd[gw].cnt != want.cnt) return chk_fail("descriptor", where + ": the device put " + std::to_string(hd[gw].cnt) + " entries into the window's descriptor, the scalars have " + std::to_string(want.cnt) + " owned non-zero digits there");
+      if (hd[gw].off != off) return chk_fail("descriptor", where + ": list offset " + std::to_string(hd[gw].off) + " is not the sum of the windows before it (" + std::to_string(off) + ")");
+      off += want.cnt;
       if (sc.cnt != want.cnt || sc.sum != want.sum || sc.x != want.x) return chk_fail("scatter", where + ": sorted lists " + str(sc) + " are not a permutation of the split's entries " + str(sp));
-      if (ht[2 * gw] != ptot[gw]) return chk_fail("bucket sizes", where + ": sizes sum to " + std::to_string(ht[2 * gw]) + ", the window has " + std::to_string(ptot[gw]) + " entries");
+      if (ht[2 * gw] != want.cnt) return chk_fail("bucket sizes", where + ": sizes sum to " + std::to_string(ht[2 * gw]) + ", the window has " + std::to_string(want.cnt) + " entries");
       if (ht[2 * gw + 1] != 0) return chk_fail("bucket starts", where + ": " + std::to_string(ht[2 * gw + 1]) + " bucket(s) do not start at the exclusive scan of the sizes");
       total += want.cnt;
     }
-    if (c.chk.level >= 2 && hb[0] != 0) {
+    if (c.chk.level >= 2 && !chk_skip && hb[0] != 0) {
       char b[160]; snprintf(b, sizeof(b), "%u list entr(ies) recode to another bucket or sign; first: bucket slot %u, entry %08x", hb[0], hb[1], hb[2]);
       return chk_fail("lists", b);
     }
-    chk_log += "sort: ok (" + std::to_string(total) + " entries: scalars = split = sorted per partition; sizes and starts consistent" +
+    chk_log += "sort: ok (" + std::to_string(total) + " entries: scalars = split = sorted per partition; descriptors, sizes and starts consistent" +
                (c.chk.level >= 2 ? "; every entry recodes to its bucket" : "") + (chk_skip ? "; SKEWED: the batch leaves this path" : "") + ")\n";
     // what the accumulation and the reduction are about to write starts as garbage that is no point of the curve
     if (!chk_skip) {
@@ -1164,7 +1164,7 @@ int msm_batch_device(Context& c, int njobs_in, const void* const* d_bases, const
       MH_TRY(c.tr_sums.ensure(64));
       u32* d_max = (u32*)c.tr_sums.ptr;
       MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
-      hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, p.nb, d_max);
+      hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, p.nb, d_max, (u32*)nullptr);
       hipLaunchKernelGGL(msm::scatter_kernel, dim3(msm::xcd_grid(max_tiles, WT)), dim3(msm::HIST_THREADS), lds, s, jobs,
                          (const u32*)c.msm_dig.ptr, (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr,
                          p.nb, p.tile, p.W, max_tiles);
@@ -1313,7 +1313,7 @@ static int msm_g2_device(Context& c, const G2Affine* d_bases, const Fr* d_scalar
   hipLaunchKernelGGL(msm::colscan_kernel, dim3((p.nb + 255) / 256, p.W, 1), dim3(256), 0, s, jobs, (u32*)c.msm_bh.ptr, (u32*)c.msm_tot.ptr, p.nb, p.W);
   u32* d_max = (u32*)c.tr_sums.ptr;
   MH_HIP(hipMemsetAsync(d_max, 0, 4, s));
-  hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, p.nb, d_max);
+  hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)c.msm_tot.ptr, (u32*)c.msm_base.ptr, p.nb, d_max, (u32*)nullptr);
   hipLaunchKernelGGL(msm::scatter_kernel, dim3(msm::xcd_grid(p.ntiles, WT)), dim3(msm::HIST_THREADS), lds, s, jobs, (const u32*)c.msm_dig.ptr,
                      (const u32*)c.msm_bh.ptr, (const u32*)c.msm_base.ptr, (u32*)c.msm_sorted.ptr, p.nb, p.tile, p.W, p.ntiles);
   hipLaunchKernelGGL(msmg2::accum_kernel, dim3((unsigned)((WB + 127) / 128)), dim3(128), 0, s, d_bases, (const u32*)c.msm_sorted.ptr, (u64)n,
@@ -1422,8 +1422,6 @@ static int ctx_init(Context& c, int device_id) {
   MH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   c.own_stream = true;
   MH_HIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
-  MH_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
-  for (auto& e : c.copy_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   { const char* e = getenv("MH_DIAG"); c.diag = e ? (unsigned)atoi(e) : 0u; }
   for (auto& e : c.side_ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   c.device = device_id;
@@ -1482,8 +1480,6 @@ static int ctx_shutdown(Context& c) {
   c.ntt_dist_tabs.clear();
   c.ntt_dist_buf[0].release(); c.ntt_dist_buf[1].release(); c.sl_send.release(); c.sl_recv.release();
   if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
-  if (c.copy_stream) { (void)hipStreamSynchronize(c.copy_stream); (void)hipStreamDestroy(c.copy_stream); c.copy_stream = nullptr; }
-  for (auto& e : c.copy_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   for (auto& e : c.side_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   c.side_job = nullptr; c.side_ran = false;
   if (c.srs_table) { (void)hipFree(c.srs_table); c.srs_table = nullptr; }

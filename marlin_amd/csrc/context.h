@@ -151,19 +151,16 @@ struct Context {
   // fixed-base path (msm_fb.cuh): the workspace of one job group
   struct FbWs {
     Scratch dig, val, sorted, pc, ptot, desc, blk, bh, tot, base, pend, buckets, seg, win, sums, perm;
-    Pinned h_ptot, h_desc, h_blk, h_out;      // host side of the partition totals, the descriptors, the block list, the results
+    Pinned h_desc, h_blk, h_out;              // host side of the descriptors (+ alias map), the block list, the results
     void release_all() {
       for (Scratch* b : {&dig, &val, &sorted, &pc, &ptot, &desc, &blk, &bh, &tot, &base, &pend, &buckets, &seg, &win, &sums, &perm}) b->release();
-      for (Pinned* b : {&h_ptot, &h_desc, &h_blk, &h_out}) b->release();
+      for (Pinned* b : {&h_desc, &h_blk, &h_out}) b->release();
     }
   } fbws;
   hipStream_t stream2 = nullptr;     // library-owned side stream: the caller's independent work beside a bucket reduction (side_job)
-  // a library-owned stream for small device-to-host copies that must not wait behind the kernels queued on `stream` (the partition
-  // totals of the fixed-base sort travel to the host while the split kernel runs), and the event that orders it
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t copy_ev[2] = {nullptr, nullptr};   // [0]: main stream -> copy stream (totals are final), [1]: copy stream -> main stream (descriptors are up)
-  // MH_DIAG (bit mask, diagnostics only -- tools/soak_sliced.py bisects with it): 1 = no copy stream (the partition totals and
-  // the descriptors travel on the main stream), 2 = no host pool (the planes of every job are combined on the calling thread)
+  // MH_DIAG (bit mask, diagnostics only -- tools/soak_sliced.py bisects with it): 2 = no host pool (the planes of every job are
+  // combined on the calling thread).  (Bit 1 turned the sort's copy stream off in round 6's first soak; the one-pass sort has no
+  // host round trip and hence no copy stream any more.)
   unsigned diag = 0;
   // Work of the CALLER that does not depend on the batch's results, issued on stream2 the moment the batch's accumulation has
   // been launched, behind an event recorded after it: it then runs beside the bucket reduction -- a latency chain at one wave per

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void colscan_kernel(Jobs jobs, u32* __restrict
 
 // ---- 4. binscan: block per window: exclusive scan of tot -> base -----------------
 // also folds the largest bucket size of the whole launch into *maxout (selects the accumulation algorithm)
-__global__ __launch_bounds__(1024) void binscan_kernel(const u32* __restrict__ tot, u32* __restrict__ base, u32 nb, u32* __restrict__ maxout) {
+__global__ __launch_bounds__(1024) void binscan_kernel(const u32* __restrict__ tot, u32* __restrict__ base, u32 nb, u32* __restrict__ maxout,
+                                                       u32* __restrict__ wtot = nullptr) {
   __shared__ u32 part[1024];
   __shared__ u32 wmax;
   const u32 w = blockIdx.x;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(1024) void binscan_kernel(const u32* __restrict__ t
     if (b < nb) { base[(u64)w * nb + b] = run; run += tot[(u64)w * nb + b]; }
   }
   if (threadIdx.x == 0 && wmax) atomicMax(maxout, wmax);
+  if (wtot && threadIdx.x == 1023) wtot[w] = part[1023];      // the window's entries (fixed-base path: woff_kernel turns them into list offsets)
 }
 
 // ---- 5. scatter -------------------------------------------------------------------

@@ -5,8 +5,9 @@
 //
 //   level 1 (cheap, a few ms per batch at 2^20):
 //     recode   : count / sum / xor of the entries every virtual window MUST hold, straight from the scalars
-//     entries  : the same three numbers of what `split` wrote (val) and of what `scatter` wrote (sorted): sorted is a
-//                permutation of val, val is what the scalars say; the count is also the partition total the host read back
+//     entries  : the same three numbers of what `psplit` wrote (val, run by run; the run tables well-formed) and of what `scatter`
+//                wrote (sorted): sorted is a permutation of val, val is what the scalars say; the count is also what the device
+//                put into the window's descriptor (woff_kernel)
 //     tot/base : sum of a window's bucket sizes = its entries; bucket starts = exclusive scan of the sizes
 //     buckets  : every owned bucket after accumulate + fix-up is the identity or a point of the curve (the buffers are filled
 //                with 0xA5 bytes before the accumulation, so a bucket nothing wrote is caught), no bucket left pending
@@ -53,6 +54,35 @@ __global__ __launch_bounds__(256) void recode_kernel(FbJobs jobs, Sum* __restric
       const u32 val = (w * tab_n + t0) | (e & 0x80000000u);
       atomicAdd(&cnt[v], 1ull); atomicAdd(&sum[v], (unsigned long long)val); atomicXor(&xr[v], val);
     });
+  }
+  __syncthreads();
+  for (u32 v = threadIdx.x; v < nparts; v += blockDim.x)
+    if (cnt[v]) { Sum* d = out + (u64)job * nparts + v; atomicAdd(&d->cnt, cnt[v]); atomicAdd(&d->sum, sum[v]); atomicXor(&d->x, xr[v]); }
+}
+
+// grid (max blocks, njobs): what the split wrote, block by block: the entries of split block b of a job lie at [b S W, ...) grouped by
+// partition, lst holds the nparts + 1 run boundaries
+__global__ __launch_bounds__(256) void runs_kernel(FbJobs jobs, const u32* __restrict__ val, const unsigned short* __restrict__ lst_all,
+                                                   Sum* __restrict__ out, u32 nparts, u32 SW, u32* __restrict__ bad) {
+  __shared__ unsigned long long cnt[msmfb::MAX_PARTS], sum[msmfb::MAX_PARTS];
+  __shared__ u32 xr[msmfb::MAX_PARTS];
+  const u32 job = blockIdx.y, blk = blockIdx.x;
+  if (blk >= jobs.nblk[job]) return;
+  for (u32 v = threadIdx.x; v < msmfb::MAX_PARTS; v += blockDim.x) { cnt[v] = 0; sum[v] = 0; xr[v] = 0; }
+  __syncthreads();
+  const unsigned short* L = lst_all + jobs.lst_off[job] + (u64)blk * (nparts + 1);
+  const u32 total = L[nparts];
+  if (threadIdx.x == 0) {                          // boundaries non-decreasing, the block's region not exceeded
+    bool ok = L[0] == 0 && total <= SW;
+    for (u32 v = 0; v < nparts; v++) ok = ok && L[v] <= L[v + 1];
+    if (!ok) atomicAdd(bad, 1u);
+  }
+  const u32* a = val + jobs.ent_off[job] + (u64)blk * SW;
+  for (u32 i = threadIdx.x; i < total && total <= SW; i += blockDim.x) {
+    u32 lo = 0, hi = nparts;                        // the partition whose run holds entry i: L[lo] <= i < L[lo + 1]
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (L[mid] <= i) lo = mid; else hi = mid; }
+    const u32 e = a[i];
+    atomicAdd(&cnt[lo], 1ull); atomicAdd(&sum[lo], (unsigned long long)e); atomicXor(&xr[lo], e);
   }
   __syncthreads();
   for (u32 v = threadIdx.x; v < nparts; v += blockDim.x)

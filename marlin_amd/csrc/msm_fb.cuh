@@ -10,16 +10,18 @@
 // reduction use the 30-bit-limb field arithmetic of fq30.cuh.
 //
 // Sorting 13 n entries by a 19-bit bucket id is done in two levels:
-//   count/pscan/pstart/split : partition the entries by the top bits of the bucket id into <= 256 "virtual windows"
-//                       of 2^11 buckets (per-block LDS counters, a scan over blocks, then the split proper)
-//   hist/colscan/binscan/scatter : a counting sort inside every virtual window, driven by a descriptor (offset,
-//                       count, tiles) per virtual window because their sizes differ
-// Both split and scatter first sort their block's entries in LDS and then copy the sorted block out, so the lanes
-// of a wave store to consecutive addresses: runs of ~200 B per (block, partition) in split, ~32 B per (tile, bucket)
+//   psplit            : ONE pass over the scalars partitions the entries by the top bits of the bucket id into <= 256 "virtual
+//                       windows" of 2^11 buckets -- per split block, into the block's own region of the entry arrays (round 6;
+//                       rounds 1-5: count / pscan / pstart / split, two passes and a host round trip for the totals)
+//   hist/colscan/binscan/woff/scatter : a counting sort inside every virtual window over tiles of ~13 K entries (a tile = the
+//                       window's runs in consecutive split blocks), the windows' list offsets computed on the device
+// Both psplit and scatter first sort their block's entries in LDS and then copy the sorted block out, so the lanes
+// of a wave store to consecutive addresses: the whole block in psplit, ~32 B per (tile, bucket)
 // in scatter.  Ranking straight into global memory (what the variable-base path's scatter does) issues one 4-byte
 // store per entry to ~random lines; the L2s cannot keep that many partial lines open, and HBM sees ~8x the payload
 // (profiles/pmc_traffic.json; measured the same way for this path before the LDS staging: 2.6 GB written per launch
-// for 0.33 GB of entries).
+// for 0.33 GB of entries).  No stage of the sort waits for the host: the block list and the descriptors' host part depend on the
+// batch's shape only.
 // followed by the ordering of all buckets by size, the accumulate kernel (entries index the table), the fix-up of deferred
 // collisions, and the reduction of the single bucket set of each MSM (row / column sums, bit planes).
 #pragma once
@@ -36,7 +38,9 @@ using msm::Windows;
 // delta: added to every table index of the window's entries -- 0 except for a job that SHARES the sorted lists of another
 // job with the same scalars and a base range `delta` points further into the same base set (MarlinKZG10 commits a
 // degree-bounded polynomial twice: against powers and against shifted_powers(d) = powers[max_degree - d ..])
-struct FbWin { u64 off; u64 bh_off; u32 cnt; u32 ntiles; u32 delta; u32 pad; };
+// off / cnt: where the window's bucket lists start in `sorted` and how many entries they hold -- written on the DEVICE (woff_kernel);
+// bh_off / ntiles / bpt (split blocks per tile) / delta come from the host and depend on the batch's shape only
+struct FbWin { u64 off; u64 bh_off; u32 cnt; u32 ntiles; u32 delta; u32 bpt; };
 
 constexpr int MAX_C = 20;          // 2^19 buckets = 256 partitions x 2^11
 constexpr int PART_BITS = 11;      // buckets per virtual window = 2^11
@@ -45,12 +49,11 @@ inline u32 part_bits(u32 c) { return c - 1 < PART_BITS ? c - 1 : PART_BITS; }
 constexpr int TPB = 1024;          // count kernel: one scalar per thread
 constexpr int SORT_THREADS = 1024; // split / hist / scatter
 constexpr int SPLIT_ENTRIES = 13312;   // entries one split block stages in LDS (13 windows x 1024 scalars)
-constexpr int TILE_EPT = 16;           // scatter: entries per thread -> tiles of <= 16384 entries
-constexpr int MAX_TILE = TILE_EPT * SORT_THREADS;
+constexpr int MAX_TILE = 16 * SORT_THREADS;   // entries one hist / scatter tile stages in LDS
 // scalars per count/split block for W windows
 inline u32 split_scalars(u32 W) { u32 sc = (SPLIT_ENTRIES / W) & ~63u; return sc > 1024 ? 1024 : sc; }
-inline size_t split_lds_bytes(u32 W) { return (size_t)(2 * MAX_PARTS + 32) * 4 + (size_t)split_scalars(W) * W * 7 + 16; }
-inline size_t scatter_lds_bytes(u32 nb) { return (size_t)(2 * nb + 32) * 4 + (size_t)MAX_TILE * 6; }
+inline size_t split_lds_bytes(u32 W) { return (size_t)(MAX_PARTS + 32) * 4 + (size_t)split_scalars(W) * W * 6 + 16; }
+inline size_t scatter_lds_bytes(u32 nb) { return (size_t)(3 * nb + 32) * 4 + (size_t)MAX_TILE * 6; }
 
 // exclusive scan of a[0, n) in LDS for n <= 2 * blockDim.x (blockDim.x a multiple of 64); tmp: 32 words of LDS
 __device__ __forceinline__ void block_excl_scan2(u32* a, u32 n, u32* tmp) {
@@ -78,8 +81,8 @@ __device__ __forceinline__ void block_excl_scan2(u32* a, u32 n, u32* tmp) {
 struct FbJobs {
   const Fr* scalars[msm::MAX_JOBS];
   u64 n[msm::MAX_JOBS];
-  u64 ent_off[msm::MAX_JOBS];    // job's region in key / val / sorted (W * n entries)
-  u64 pc_off[msm::MAX_JOBS];     // job's region in the per-block partition counts (nparts * nblk)
+  u64 ent_off[msm::MAX_JOBS];    // job's region in key / val (nblk blocks of S * W entries)
+  u64 lst_off[msm::MAX_JOBS];    // job's region in the table of per-block partition starts (nblk * (nparts + 1) offsets)
   u32 tab_off[msm::MAX_JOBS];    // index of the job's first base inside the table's base set
   u32 tab_stride[msm::MAX_JOBS]; // scalar i multiplies base tab_off + i * tab_stride (1: a contiguous range; G: rank's cyclic slice)
   u32 nblk[msm::MAX_JOBS];
@@ -153,110 +156,43 @@ struct Own { u32 first, stride; };
 __device__ __forceinline__ bool owns(const Own& o, u32 v) {
   return (o.stride & (o.stride - 1)) == 0 ? (v & (o.stride - 1)) == o.first : v % o.stride == o.first;
 }
-__global__ __launch_bounds__(TPB) void count_kernel(FbJobs jobs, u32* __restrict__ pc, u32 W, Windows win, int is_mont, u32 nparts,
-                                                    u32 pshift, u32 S, Own own) {
-  __shared__ u32 cnt[MAX_PARTS];
-  const u32 job = blockIdx.y, blk = blockIdx.x;
-  if (blk >= jobs.nblk[job]) return;
-  static_assert(TPB >= MAX_PARTS, "one thread per partition counter");
-  if (threadIdx.x < MAX_PARTS) cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const u64 n = jobs.n[job];
-  for (u32 k = threadIdx.x; k < S; k += TPB) {
-    u64 i = (u64)blk * S + k;
-    if (i < n) {
-      Fr s = ff_load(jobs.scalars[job] + i);
-      if (!is_mont) s = ff_to_mont(s);            // the table holds [R^-1] P: the digits of s R are what multiplies it
-      msm::for_each_digit(s, W, win, [&](u32, u32 e) {
-        u32 b = e & 0x7fffffffu;
-        if (b) {
-          const u32 v = (b - 1) >> pshift;
-          if (owns(own, v)) atomicAdd(&cnt[v], 1u);
-        }
-      });
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < nparts) pc[jobs.pc_off[job] + (u64)threadIdx.x * jobs.nblk[job] + blk] = cnt[threadIdx.x];
-}
-
-// block per (partition, job): exclusive scan of the per-block counts in place, total -> ptot[job * nparts + v]
-__global__ __launch_bounds__(1024) void pscan_kernel(FbJobs jobs, u32* __restrict__ pc, u32* __restrict__ ptot, u32 nparts) {
-  __shared__ u32 part[1024];
-  const u32 v = blockIdx.x, job = blockIdx.y;
-  const u32 nblk = jobs.nblk[job];
-  u32* row = pc + jobs.pc_off[job] + (u64)v * nblk;
-  const u32 per = (nblk + 1023) / 1024;
-  const u32 lo = threadIdx.x * per;
-  u32 s = 0;
-  for (u32 k = 0; k < per; k++) if (lo + k < nblk) s += row[lo + k];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (u32 off = 1; off < 1024; off <<= 1) {
-    u32 t = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-    __syncthreads();
-    part[threadIdx.x] += t;
-    __syncthreads();
-  }
-  u32 run = part[threadIdx.x] - s;
-  for (u32 k = 0; k < per; k++)
-    if (lo + k < nblk) { u32 t = row[lo + k]; row[lo + k] = run; run += t; }
-  if (threadIdx.x == 1023) ptot[job * nparts + v] = part[1023];
-}
-
-// block per job: pstart[job * nparts + v] = sum of the job's partition totals below v
-__global__ __launch_bounds__(MAX_PARTS) void pstart_kernel(const u32* __restrict__ ptot, u32* __restrict__ pstart, u32 nparts) {
-  __shared__ u32 sh[MAX_PARTS];
-  const u32 job = blockIdx.x, v = threadIdx.x;
-  const u32 mine = v < nparts ? ptot[job * nparts + v] : 0;
-  sh[v] = mine;
-  __syncthreads();
-  for (u32 off = 1; off < MAX_PARTS; off <<= 1) {
-    u32 t = v >= off ? sh[v - off] : 0;
-    __syncthreads();
-    sh[v] += t;
-    __syncthreads();
-  }
-  if (v < nparts) pstart[job * nparts + v] = sh[v] - mine;
-}
-
-// One block = S scalars (the same S as count_kernel): digits -> LDS counters -> local offsets -> entries placed in
-// LDS grouped by partition -> copied out, consecutive lanes to consecutive addresses of each partition's run.
-__global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const u32* __restrict__ pc, const u32* __restrict__ ptot,
-                                                             const u32* __restrict__ pstart, unsigned short* __restrict__ key,
-                                                             u32* __restrict__ val, u32 W, Windows win, int is_mont, u32 nparts,
-                                                             u32 pshift, u32 tab_n, u32 S, Own own) {
+// One pass over the scalars (round 6; rounds 1-5 counted first -- count / pscan / pstart -- and split second, reading and recoding
+// every scalar twice, with a host round trip for the partition totals in between).  A block takes S scalars, recodes them ONCE from
+// registers in two phases -- LDS counters per partition, a scan, then the entries placed in LDS grouped by partition -- and writes
+// its <= S W entries out to ITS OWN fixed region of the entry arrays (block b of a job: entries [b S W, (b + 1) S W)), fully
+// coalesced, followed by the table of its partition starts (lst: nparts + 1 offsets).  No global position depends on another
+// block, so nothing is counted beforehand and the host learns nothing: a virtual window is no longer one contiguous run but one
+// run per block (~50 entries at c = 20), which the tiles of hist / scatter walk block by block.
+__global__ __launch_bounds__(SORT_THREADS) void psplit_kernel(FbJobs jobs, unsigned short* __restrict__ key, u32* __restrict__ val,
+                                                              unsigned short* __restrict__ lst_all, u32 W, Windows win, int is_mont,
+                                                              u32 nparts, u32 pshift, u32 tab_n, u32 S, Own own) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* cur = lds;                                  // [MAX_PARTS] counts -> local starts -> cursors
-  u32* gdst = lds + MAX_PARTS;                     // [MAX_PARTS] global position of local entry 0 of each partition
-  u32* tmp = lds + 2 * MAX_PARTS;                  // [32]
-  u32* sval = lds + 2 * MAX_PARTS + 32;            // [S * W] table index | sign << 31
+  u32* tmp = lds + MAX_PARTS;                      // [32]
+  u32* sval = lds + MAX_PARTS + 32;                // [S * W] table index | sign << 31
   unsigned short* skey = (unsigned short*)(sval + S * W);   // [S * W] bucket inside the virtual window (< 2^PART_BITS)
-  unsigned char* spart = (unsigned char*)(skey + S * W);
   const u32 job = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   if (blk >= jobs.nblk[job]) return;
-  // this block's entries per partition = difference of consecutive entries of the scanned per-block counts
-  // (count_kernel + pscan_kernel): no second counting pass here
-  u32 my_pre = 0;
-  if (t < MAX_PARTS) {
-    u32 cnt = 0;
-    if (t < nparts) {
-      const u32* row = pc + jobs.pc_off[job] + (u64)t * jobs.nblk[job];
-      my_pre = row[blk];
-      cnt = (blk + 1 < jobs.nblk[job] ? row[blk + 1] : ptot[job * nparts + t]) - my_pre;
-    }
-    cur[t] = cnt;
-  }
-  __syncthreads();
-  block_excl_scan2(cur, MAX_PARTS, tmp);
-  if (t < nparts) gdst[t] = pstart[job * nparts + t] + my_pre - cur[t];
+  if (t < MAX_PARTS) cur[t] = 0;
   __syncthreads();
   const u64 n = jobs.n[job];
   const u64 i = (u64)blk * S + t;
   const bool live = t < S && i < n;
+  Fr s;
   if (live) {
-    Fr s = ff_load(jobs.scalars[job] + i);
-    if (!is_mont) s = ff_to_mont(s);
+    s = ff_load(jobs.scalars[job] + i);
+    if (!is_mont) s = ff_to_mont(s);              // the table holds [R^-1] P: the digits of s R are what multiplies it
+    msm::for_each_digit(s, W, win, [&](u32, u32 e) {
+      const u32 b = e & 0x7fffffffu;
+      if (b) {
+        const u32 v = (b - 1) >> pshift;
+        if (owns(own, v)) atomicAdd(&cur[v], 1u);
+      }
+    });
+  }
+  __syncthreads();
+  block_excl_scan2(cur, MAX_PARTS, tmp);
+  if (live) {
     const u32 t0 = jobs.tab_off[job] + (u32)i * jobs.tab_stride[job];
     msm::for_each_digit(s, W, win, [&](u32 w, u32 e) {
       u32 b = e & 0x7fffffffu;
@@ -267,40 +203,61 @@ __global__ __launch_bounds__(SORT_THREADS) void split_kernel(FbJobs jobs, const 
         const u32 p = atomicAdd(&cur[v], 1u);
         skey[p] = (unsigned short)(b & ((1u << pshift) - 1));
         sval[p] = (w * tab_n + t0) | (e & 0x80000000u);          // table indices stay below 2^31 (mh_bases_precompute checks)
-        spart[p] = (unsigned char)v;
       }
     });
   }
   __syncthreads();
-  const u32 total = cur[MAX_PARTS - 1];             // cursor of the last partition = number of entries of the block
-  unsigned short* kj = key + jobs.ent_off[job];
-  u32* vj = val + jobs.ent_off[job];
+  // cur[v] is now the END of partition v's run = the start of partition v + 1's
+  unsigned short* lst = lst_all + jobs.lst_off[job] + (u64)blk * (nparts + 1);
+  if (t == 0) lst[0] = 0;
+  if (t < nparts) lst[t + 1] = (unsigned short)cur[t];
+  const u32 total = cur[nparts - 1];
+  const u64 base = jobs.ent_off[job] + (u64)blk * S * W;
   for (u32 idx = t; idx < total; idx += SORT_THREADS) {
-    const u32 d = gdst[spart[idx]] + idx;
-    kj[d] = skey[idx];
-    vj[d] = sval[idx];
+    key[base + idx] = skey[idx];
+    val[base + idx] = sval[idx];
   }
 }
 
 // ---- counting sort inside the virtual windows ------------------------------------------------------------
-// Block -> (virtual window, tile) comes from a host-built list, XCD-interleaved: block b runs on XCD b % 8 (see
-// msm::xcd_decode) and XCD x works through the virtual windows x, x + 8, x + 16, ... one after another, so that the
-// partial lines of one window's bucket lists meet in that XCD's L2.  gw = ~0 marks padding.
+// A tile = the runs of ONE virtual window in `bpt` consecutive split blocks (bpt chosen per window from the expected load so that a
+// tile holds ~13 K entries; a tile that would exceed MAX_TILE -- heavily repeated digits -- marks the batch as skewed and it leaves
+// this path like any other skewed batch).  Block -> (virtual window, tile) comes from a host-built list, XCD-interleaved: block b
+// runs on XCD b % 8 (see msm::xcd_decode) and XCD x works through the virtual windows x, x + 8, x + 16, ... one after another, so
+// that the partial lines of one window's bucket lists meet in that XCD's L2.  gw = ~0 marks padding.  The list depends on the
+// batch's shape only -- not on its scalars -- so nothing of it waits for the device.
 struct FbBlk { u32 gw, tile; };
 
-__global__ __launch_bounds__(SORT_THREADS) void hist_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk,
-                                                                 const unsigned short* __restrict__ key, u32* __restrict__ bh, u32 nb, u32 tile) {
-  extern __shared__ __attribute__((aligned(16))) u32 h[];
+// the runs of window (job, v) in split blocks [b0, b1): f(entry index in the key / val arrays), 64 lanes side by side within a run
+template <class F>
+__device__ __forceinline__ u32 for_each_run_entry(const unsigned short* __restrict__ lst, u32 nparts, u32 v, u64 ent_base, u32 SW, u32 b0, u32 b1, F f) {
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  u32 mine = 0;
+  for (u32 b = b0 + wave; b < b1; b += nw) {
+    const unsigned short* L = lst + (u64)b * (nparts + 1);
+    const u32 lo = L[v], hi = L[v + 1];
+    const u64 at = ent_base + (u64)b * SW;
+    for (u32 i = lo + lane; i < hi; i += 64) f(at + i);
+    if (lane == 0) mine += hi - lo;
+  }
+  return mine;                                       // entries this wave's lane 0 saw (summed over waves by the caller)
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void hist_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk, FbJobs jobs,
+                                                            const unsigned short* __restrict__ key, const unsigned short* __restrict__ lst_all,
+                                                            u32* __restrict__ bh, u32 nb, u32 nparts, u32 SW, u32* __restrict__ largest) {
+  extern __shared__ __attribute__((aligned(16))) u32 h[];        // [nb] counters, [nb]: the tile's entries
   const u32 gw = blk[blockIdx.x].gw, tb = blk[blockIdx.x].tile;
   if (gw == 0xffffffffu) return;
   const FbWin d = fbw[gw];
-  for (u32 b = threadIdx.x; b < nb; b += blockDim.x) h[b] = 0;
+  const u32 job = gw / nparts, v = gw % nparts;
+  for (u32 b = threadIdx.x; b <= nb; b += blockDim.x) h[b] = 0;
   __syncthreads();
-  const u32 lo = tb * tile;
-  u32 hi = lo + tile; if (hi > d.cnt) hi = d.cnt;
-  const unsigned short* k = key + d.off;
-  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[k[i]], 1u);
+  const u32 b0 = tb * d.bpt, b1 = b0 + d.bpt < jobs.nblk[job] ? b0 + d.bpt : jobs.nblk[job];
+  const u32 mine = for_each_run_entry(lst_all + jobs.lst_off[job], nparts, v, jobs.ent_off[job], SW, b0, b1, [&](u64 at) { atomicAdd(&h[key[at]], 1u); });
+  if (mine) atomicAdd(&h[nb], mine);
   __syncthreads();
+  if (threadIdx.x == 0 && h[nb] > (u32)MAX_TILE) atomicMax(largest, 0xffffffffu);     // the scatter cannot stage this tile: the batch is skewed
   u32* out = bh + d.bh_off + (u64)tb * nb;
   for (u32 b = threadIdx.x; b < nb; b += blockDim.x) out[b] = h[b];
 }
@@ -321,55 +278,77 @@ __global__ __launch_bounds__(256) void colscan_kernel(const FbWin* __restrict__ 
   tot[(u64)gw * nb + b] = run;
 }
 
-// One block = one tile of <= MAX_TILE entries of one virtual window: local ranks by LDS atomics, local bucket starts by
-// a scan, entries placed in LDS in bucket order, then copied out (global position = where the tile's share of the
-// bucket starts + offset inside the tile's share).
-__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk,
+// one block: where each virtual window's bucket lists start in `sorted` (exclusive scan of the windows' entry counts, which
+// binscan left in wtot) and how many entries it has -- what the descriptors of rounds 1-5 got from the host after a round trip.
+// A window that shares another job's lists (src[gw] != ~0) takes that window's numbers.
+__global__ __launch_bounds__(1024) void woff_kernel(FbWin* __restrict__ fbw, const u32* __restrict__ wtot, const u32* __restrict__ src, u32 WT) {
+  __shared__ u32 part[1024];
+  const u32 per = (WT + 1023) / 1024, lo = threadIdx.x * per;
+  u32 s = 0;
+  for (u32 k = 0; k < per; k++) if (lo + k < WT && src[lo + k] == 0xffffffffu) s += wtot[lo + k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (u32 off = 1; off < 1024; off <<= 1) {
+    const u32 t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  u32 run = part[threadIdx.x] - s;
+  for (u32 k = 0; k < per; k++) {
+    const u32 gw = lo + k;
+    if (gw < WT && src[gw] == 0xffffffffu) { fbw[gw].off = run; fbw[gw].cnt = wtot[gw]; run += wtot[gw]; }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (u32 k = 0; k < per; k++) {
+    const u32 gw = lo + k;
+    if (gw < WT && src[gw] != 0xffffffffu) { fbw[gw].off = fbw[src[gw]].off; fbw[gw].cnt = fbw[src[gw]].cnt; }
+  }
+}
+
+// One block = one tile: bucket counts by LDS atomics over the tile's runs, local bucket starts by a scan, the entries placed in
+// LDS in bucket order (second walk over the runs: keys and values come out of L2), then copied out (global position = where the
+// tile's share of the bucket starts + offset inside the tile's share), consecutive lanes to consecutive addresses.
+__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk, FbJobs jobs,
                                                                const unsigned short* __restrict__ key, const u32* __restrict__ val,
-                                                               const u32* __restrict__ bh, const u32* __restrict__ base,
-                                                               u32* __restrict__ sorted, u32 nb, u32 tile) {
+                                                               const unsigned short* __restrict__ lst_all, const u32* __restrict__ bh,
+                                                               const u32* __restrict__ base, u32* __restrict__ sorted, u32 nb, u32 nparts, u32 SW) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* lcnt = lds;                                 // [nb] counts -> local starts
-  u32* gdst = lds + nb;                            // [nb]
-  u32* tmp = lds + 2 * nb;                         // [32]
-  u32* stage = lds + 2 * nb + 32;                  // [MAX_TILE]
+  u32* cur = lds + nb;                             // [nb] cursors
+  u32* gdst = lds + 2 * nb;                        // [nb]
+  u32* tmp = lds + 3 * nb;                         // [32], tmp[31]: the tile's entries
+  u32* stage = lds + 3 * nb + 32;                  // [MAX_TILE]
   unsigned short* sbkt = (unsigned short*)(stage + MAX_TILE);
   const u32 gw = blk[blockIdx.x].gw, tb = blk[blockIdx.x].tile, t = threadIdx.x;
   if (gw == 0xffffffffu) return;
   const FbWin d = fbw[gw];
+  const u32 job = gw / nparts, v = gw % nparts;
   for (u32 b = t; b < nb; b += SORT_THREADS) lcnt[b] = 0;
+  if (t == 0) tmp[31] = 0;
   __syncthreads();
-  const u32 lo = tb * tile;
-  const u32 cnt = d.cnt - lo < tile ? d.cnt - lo : tile;
-  const unsigned short* k = key + d.off + lo;
-  const u32* v = val + d.off + lo;
-  u32 rk[TILE_EPT], ev[TILE_EPT], bk[TILE_EPT];
-#pragma unroll
-  for (int j = 0; j < TILE_EPT; j++) {
-    const u32 i = j * SORT_THREADS + t;
-    if (i < cnt) {
-      bk[j] = k[i];
-      ev[j] = v[i];
-      rk[j] = atomicAdd(&lcnt[bk[j]], 1u);
-    }
-  }
+  const u32 b0 = tb * d.bpt, b1 = b0 + d.bpt < jobs.nblk[job] ? b0 + d.bpt : jobs.nblk[job];
+  const unsigned short* lst = lst_all + jobs.lst_off[job];
+  const u32 mine = for_each_run_entry(lst, nparts, v, jobs.ent_off[job], SW, b0, b1, [&](u64 at) { atomicAdd(&lcnt[key[at]], 1u); });
+  if (mine) atomicAdd(&tmp[31], mine);
   __syncthreads();
+  const u32 cnt = tmp[31];
+  if (cnt > (u32)MAX_TILE) return;                  // hist_kernel has marked the batch as skewed; nothing below is read
+  __syncthreads();                                   // (tmp is the scan's scratch next)
   block_excl_scan2(lcnt, nb, tmp);
   {
     const u32* pre = bh + d.bh_off + (u64)tb * nb;
     const u32* bs = base + (u64)gw * nb;
-    for (u32 b = t; b < nb; b += SORT_THREADS) gdst[b] = bs[b] + pre[b] - lcnt[b];
+    for (u32 b = t; b < nb; b += SORT_THREADS) { cur[b] = lcnt[b]; gdst[b] = bs[b] + pre[b] - lcnt[b]; }
   }
   __syncthreads();
-#pragma unroll
-  for (int j = 0; j < TILE_EPT; j++) {
-    const u32 i = j * SORT_THREADS + t;
-    if (i < cnt) {
-      const u32 idx = lcnt[bk[j]] + rk[j];
-      stage[idx] = ev[j];
-      sbkt[idx] = (unsigned short)bk[j];
-    }
-  }
+  (void)for_each_run_entry(lst, nparts, v, jobs.ent_off[job], SW, b0, b1, [&](u64 at) {
+    const u32 kb = key[at];
+    const u32 pos = atomicAdd(&cur[kb], 1u);
+    stage[pos] = val[at];
+    sbkt[pos] = (unsigned short)kb;
+  });
   __syncthreads();
   u32* out = sorted + d.off;
   for (u32 idx = t; idx < cnt; idx += SORT_THREADS) out[gdst[sbkt[idx]] + idx] = stage[idx];

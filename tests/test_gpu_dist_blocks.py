@@ -104,7 +104,7 @@ dist.barrier(); dist.destroy_process_group()
 def test_distributed_ntt_and_sliced_msm(gpu, tmp_path, world, logs):
     script = tmp_path / "dist_blocks_worker.py"
     script.write_text(WORKER % {"root": ROOT, "logs": logs, "msm_log": 15, "c": 14})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29833 + world), WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29833 + world), WORLD_SIZE=str(world), MH_CHECK="1")   # the pipeline's invariants stay on in the multi-rank tests
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(world)]
     outs = [p.communicate(timeout=600) for p in procs]

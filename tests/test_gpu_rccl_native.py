@@ -187,7 +187,7 @@ def test_native_transport_at_n_ranks_gives_the_single_gpu_proof(gpu, tmp_path, w
     script = tmp_path / "mock_worker.py"
     script.write_text(MOCK_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "pc": pc, "sliced": sliced})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29913 + world + log_n + 40 * sliced + (7 if pc == "sonic" else 0) + 100 * len(variant)),
-               WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK_NOA2A if "noa2a" in variant else MOCK)
+               WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK_NOA2A if "noa2a" in variant else MOCK, MH_CHECK="1")
     if "async" in variant:
         env["MH_MOCK_RCCL_ASYNC"] = "1"
     if sliced:
@@ -321,7 +321,7 @@ def test_a_rank_that_fails_mid_prove_fails_the_job_on_every_rank(gpu, tmp_path, 
     script.write_text(FAIL_WORKER % {"root": ROOT, "out": str(tmp_path), "tau": TAU, "gamma": GAMMA, "a": a, "b": b, "log_n": log_n, "sliced": sliced,
                                      "victim": victim, "fracs": fracs})
     from tests.util import hooks_env          # mh_debug_fail_scratch lives in the hooks library (the product's objects + testhooks.hip)
-    env = hooks_env(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29871 + world + 10 * enqueued), WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK)
+    env = hooks_env(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29871 + world + 10 * enqueued), WORLD_SIZE=str(world), MH_RCCL_LIB=MOCK, MH_CHECK="1")
     if sliced:
         env["MH_SLICED"] = "2"
     if enqueued:

@@ -38,7 +38,7 @@ PY
 for R in "$@"; do
   case $R in
     suite)
-      ( timeout 2400 python -m pytest tests -m gpu -q --durations=6 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log ); tail -8 $O/pytest.log
+      ( timeout 2400 python -m pytest tests -m gpu -q --durations=45 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log ); tail -8 $O/pytest.log
       python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt ;;
     bench)
       timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; line $O/bench_default.json ;;
@@ -75,6 +75,17 @@ for R in "$@"; do
       timeout 600 python bench.py --workload seam-route --steps 3 --warmup 1 > $O/bench_seam.json 2> $O/bench_seam.err
       BENCH_SEAM_FULL_UPLOAD=1 timeout 600 python bench.py --workload seam-route --steps 3 --warmup 1 > $O/bench_seam_full_upload.json 2>> $O/bench_seam.err
       line $O/bench_seam.json $O/bench_seam_full_upload.json ;;
+    suite_check)    # the whole GPU suite with the pipeline's invariants on in every process (MH_CHECK=1)
+      ( MH_CHECK=1 timeout 2400 python -m pytest tests -m gpu -q --durations=10 -p no:cacheprovider > $O/pytest_mh_check_1.log 2>&1; echo "pytest rc=$?" >> $O/pytest_mh_check_1.log ); tail -8 $O/pytest_mh_check_1.log ;;
+    new)            # the tests of this round's new code, first
+      ( timeout 1500 python -m pytest tests/test_gpu_contexts.py tests/test_gpu_check.py tests/test_capi_symbols.py tests/test_gpu_poisoned_allocations.py tests/test_gpu_reentrancy.py -m gpu -q -x --durations=20 -p no:cacheprovider > $O/pytest_new.log 2>&1; echo "pytest rc=$?" >> $O/pytest_new.log
+        timeout 900 python -m pytest tests/test_gpu_rccl_native.py tests/test_gpu_msm.py -m gpu -q -x -k "fails_mid_prove or selftest or native_rccl_world_1 or skewed" --durations=10 -p no:cacheprovider >> $O/pytest_new.log 2>&1; echo "pytest rc=$?" >> $O/pytest_new.log ); grep -E "passed|failed|rc=|Error|error" $O/pytest_new.log | tail -30 ;;
+    simtrace)       # kernel trace of one simulated rank of 8 at 2^20: where a rank's time goes (tools/prove_kernels.py on the last prove)
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace_sim58 -o t -- python $OLDPWD/bench.py --steps 3 --warmup 1 \
+          --no-cpu-baseline --no-seam-route --no-verify --simulate-rank 5/8 > $O/trace_sim58.log 2>&1 )
+      T=$(find $O/trace_sim58 -name "*kernel_trace.csv" | head -1)
+      [ -n "$T" ] && python tools/prove_kernels.py $T > $O/sim_5_8_last_prove_kernels.txt 2>&1 && python tools/gap_analysis.py $T 4 > $O/sim_5_8_gaps.txt 2>&1
+      rm -rf $O/trace_sim58; head -70 $O/sim_5_8_last_prove_kernels.txt ;;
     check)          # the MH_CHECK tests by themselves
       ( timeout 900 python -m pytest tests/test_gpu_check.py -m gpu -q -x --durations=8 -p no:cacheprovider > $O/pytest_check.log 2>&1; echo "pytest rc=$?" >> $O/pytest_check.log ); tail -25 $O/pytest_check.log ;;
     soak=*)         # tools/soak_sliced.py: soak=<iterations>[:<MH_DIAG>[:serialize]] -- 8 processes on the GPU, MH_CHECK=2

@@ -31,21 +31,33 @@ while time.time() - t0 < %(secs)f:
 print(json.dumps({"proofs": k, "seconds": time.time() - t0}))
 '''
 def run(log_n, procs, secs=4.0, pc="marlin"):
-    import tempfile
+    import shutil, tempfile
     d = tempfile.mkdtemp()
     go = os.path.join(d, "go")
     ps = []
-    for i in range(procs):
-        code = WORKER % {"root": ROOT, "log_n": log_n, "ready": os.path.join(d, "ready%d" % i), "go": go, "secs": secs, "pc": pc}
-        ps.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
-    while not all(os.path.exists(os.path.join(d, "ready%d" % i)) for i in range(procs)):
-        time.sleep(0.01)
-        if any(p.poll() is not None for p in ps):
-            raise SystemExit("a worker died")
-    open(go, "w").write("1")
-    outs = [json.loads(p.communicate(timeout=600)[0].strip().splitlines()[-1]) for p in ps]
-    rate = sum(o["proofs"] / o["seconds"] for o in outs)
-    return rate, outs
+    try:
+        for i in range(procs):
+            code = WORKER % {"root": ROOT, "log_n": log_n, "ready": os.path.join(d, "ready%d" % i), "go": go, "secs": secs, "pc": pc}
+            ps.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        while not all(os.path.exists(os.path.join(d, "ready%d" % i)) for i in range(procs)):
+            time.sleep(0.01)
+            dead = [p for p in ps if p.poll() is not None]
+            if dead:
+                raise SystemExit("a worker died before it was ready (exit %d): %s" % (dead[0].returncode, dead[0].stderr.read()[-600:]))
+        open(go, "w").write("1")
+        outs = []
+        for i, p in enumerate(ps):
+            so, se = p.communicate(timeout=600)
+            if p.returncode != 0 or not so.strip():
+                raise SystemExit("worker %d failed (exit %d): %s" % (i, p.returncode, se[-600:]))
+            outs.append(json.loads(so.strip().splitlines()[-1]))
+        rate = sum(o["proofs"] / o["seconds"] for o in outs)
+        return rate, outs
+    finally:
+        for p in ps:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(d, ignore_errors=True)
 if __name__ == "__main__":
     argv = sys.argv[1:]
     as_json = "--json" in argv
