@@ -338,7 +338,7 @@ static int msm_set_attrs(Context& c) {
   MH_HIP(hipFuncSetAttribute((const void*)msm::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::psplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(msmfb::PLANE_THREADS * sizeof(msmfb::G1Xyzz30))));
   c.msm_attr_done = true;
@@ -500,7 +500,7 @@ struct FbRun {
     // uniformly distributed scalar puts on the window's partition (so that nothing has to be counted first): window w of wb bits
     // spreads its non-zero digits evenly over the buckets 1 ... 2^(wb - 1), i.e. with density 2 / 2^wb per bucket (the top window a
     // little denser: the scalar is below r, not below 2^256 -- covered by the margin).  A tile that exceeds MAX_TILE all the same --
-    // heavily repeated digits -- makes the batch leave this path as skewed (hist_kernel).
+    // digits that repeat -- is worked off in sub-tiles by the scatter.
     bpt.assign(nparts, 1);
     for (u32 v = 0; v < nparts; v++) {
       double per_block = 0;                      // expected entries of partition v in one split block
@@ -508,8 +508,8 @@ struct FbRun {
         const double top = (double)(1ull << (win.bits[w] - 1)), lo = (double)v * nb, hi = std::min((double)(v + 1) * nb, top);
         if (hi > lo) per_block += (double)S * (hi - lo) * 2.0 / (double)(1ull << win.bits[w]);
       }
-      const double fit = 0.78 * (double)F::MAX_TILE / std::max(per_block, 1e-9);
-      bpt[v] = (u32)std::max(1.0, std::min(fit, 1e9));
+      const double fit = 0.90 * (double)F::MAX_TILE / std::max(per_block, 1e-9);     // (0.78 / 0.90 / 0.95: 10.25 / 10.04 / 10.05 ms of sort + reduce, profiles/r06h_*)
+      bpt[v] = (u32)std::max(1.0, std::min(fit, (double)F::MAX_BPT));
     }
     max_tiles_total = 0;
     for (int k = 0; k < nj; k++)
@@ -613,7 +613,7 @@ struct FbRun {
       memcpy(ws.h_blk.ptr, blk.data(), blk.size() * sizeof(F::FbBlk));
       MH_HIP(hipMemcpyAsync(ws.blk.ptr, ws.h_blk.ptr, blk.size() * sizeof(F::FbBlk), hipMemcpyHostToDevice, s));
     }
-    u32* d_max = (u32*)ws.sums.ptr;                    // [0] largest bucket (0xffffffff: a tile overflowed), [1] buckets with deferred entries
+    u32* d_max = (u32*)ws.sums.ptr;                    // [0] largest bucket, [1] buckets with deferred entries
     MH_HIP(hipMemsetAsync(d_max, 0, 8, s));
     if (max_blk)
       hipLaunchKernelGGL(F::psplit_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, key, val, lst, W, win, is_mont,
@@ -621,8 +621,8 @@ struct FbRun {
     msmfb::FbWin* fbw = (msmfb::FbWin*)ws.desc.ptr;
     const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;
     if (grid_tiles)
-      hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), (size_t)(nb + 1) * 4, s, (const msmfb::FbWin*)fbw, dblk, jobs,
-                         (const unsigned short*)key, (const unsigned short*)lst, (u32*)ws.bh.ptr, nb, nparts, SW, d_max);
+      hipLaunchKernelGGL(F::hist_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::hist_lds_bytes(nb), s, (const msmfb::FbWin*)fbw, dblk, jobs,
+                         (const unsigned short*)key, (const unsigned short*)lst, (u32*)ws.bh.ptr, nb, nparts, SW);
     hipLaunchKernelGGL(F::colscan_kernel, dim3((nb + 255) / 256, WT), dim3(256), 0, s, (const msmfb::FbWin*)fbw, (u32*)ws.bh.ptr, (u32*)ws.tot.ptr, nb);
     hipLaunchKernelGGL(msm::binscan_kernel, dim3(WT), dim3(1024), 0, s, (const u32*)ws.tot.ptr, (u32*)ws.base.ptr, nb, d_max, d_wtot);
     hipLaunchKernelGGL(F::woff_kernel, dim3(1), dim3(1024), 0, s, fbw, (const u32*)d_wtot, (const u32*)d_src, WT);
@@ -634,7 +634,7 @@ struct FbRun {
     if (grid_tiles)
       hipLaunchKernelGGL(F::scatter_kernel, dim3((unsigned)(grid_tiles * 8)), dim3(F::SORT_THREADS), F::scatter_lds_bytes(nb), s, (const msmfb::FbWin*)fbw, dblk, jobs,
                          (const unsigned short*)key, (const u32*)val, (const unsigned short*)lst, (const u32*)ws.bh.ptr, (const u32*)ws.base.ptr,
-                         (u32*)ws.sorted.ptr, nb, nparts, SW);
+                         (const u32*)ws.tot.ptr, (u32*)ws.sorted.ptr, nb, nparts, SW);
     // buckets ordered by size, largest first (before the skew decision comes back: a few tens of microseconds, wasted
     // only on the skewed batches that leave this path anyway)
     u32* d_szh = (u32*)ws.sums.ptr + 16;
@@ -648,7 +648,7 @@ struct FbRun {
     u64 pairs = 0;
     for (int k = 0; k < nj; k++) pairs += ns[k];
     const u64 avg = pairs * W / WB + 1;
-    skew_limit = (u32)std::min<u64>(std::max<u64>(skew_floor, 32 * avg), 0xfffffffeull);     // (0xffffffff is the tile-overflow mark of hist_kernel)
+    skew_limit = (u32)std::min<u64>(std::max<u64>(skew_floor, 32 * avg), 0xffffffffull);
     // (a strided slice has no variable-base fallback -- its bases are not a contiguous range --: msm_batch_strided_device turns a
     // skewed batch into an error instead of letting one thread walk a list of millions)
     return MH_OK;
@@ -823,7 +823,6 @@ struct FbRun {
       auto str = [](const K::Sum& x) { char b[96]; snprintf(b, sizeof(b), "(n %llu, sum %llu, xor %08x)", x.cnt, x.sum, x.x); return std::string(b); };
       const std::string where = "job " + std::to_string(k) + " partition " + std::to_string(gw % nparts);
       if (sp.cnt != want.cnt || sp.sum != want.sum || sp.x != want.x) return chk_fail("split", where + ": entries written " + str(sp) + " != entries the scalars give " + str(want));
-      if (chk_skip) { total += want.cnt; continue; }                      // a tile overflowed: nothing after the split is complete, and nothing after it is used
       if (hd[gw].cnt != want.cnt) return chk_fail("descriptor", where + ": the device put " + std::to_string(hd[gw].cnt) + " entries into the window's descriptor, the scalars have " + std::to_string(want.cnt) + " owned non-zero digits there");
       if (hd[gw].off != off) return chk_fail("descriptor", where + ": list offset " + std::to_string(hd[gw].off) + " is not the sum of the windows before it (" + std::to_string(off) + ")");
       off += want.cnt;

@@ -53,7 +53,8 @@ constexpr int MAX_TILE = 16 * SORT_THREADS;   // entries one hist / scatter tile
 // scalars per count/split block for W windows
 inline u32 split_scalars(u32 W) { u32 sc = (SPLIT_ENTRIES / W) & ~63u; return sc > 1024 ? 1024 : sc; }
 inline size_t split_lds_bytes(u32 W) { return (size_t)(MAX_PARTS + 32) * 4 + (size_t)split_scalars(W) * W * 6 + 16; }
-inline size_t scatter_lds_bytes(u32 nb) { return (size_t)(3 * nb + 32) * 4 + (size_t)MAX_TILE * 6; }
+inline size_t scatter_lds_bytes(u32 nb) { return (size_t)(4 * nb + 32) * 4 + (size_t)MAX_TILE * 6 + 4096 * 4; }
+inline size_t hist_lds_bytes(u32 nb) { return (size_t)nb * 4 + 4096 * 4; }
 
 // exclusive scan of a[0, n) in LDS for n <= 2 * blockDim.x (blockDim.x a multiple of 64); tmp: 32 words of LDS
 __device__ __forceinline__ void block_excl_scan2(u32* a, u32 n, u32* tmp) {
@@ -221,43 +222,65 @@ __global__ __launch_bounds__(SORT_THREADS) void psplit_kernel(FbJobs jobs, unsig
 
 // ---- counting sort inside the virtual windows ------------------------------------------------------------
 // A tile = the runs of ONE virtual window in `bpt` consecutive split blocks (bpt chosen per window from the expected load so that a
-// tile holds ~13 K entries; a tile that would exceed MAX_TILE -- heavily repeated digits -- marks the batch as skewed and it leaves
-// this path like any other skewed batch).  Block -> (virtual window, tile) comes from a host-built list, XCD-interleaved: block b
+// tile holds ~13 K entries; the scatter works an overfull tile off in sub-tiles).  Block -> (virtual window, tile) comes from a host-built list, XCD-interleaved: block b
 // runs on XCD b % 8 (see msm::xcd_decode) and XCD x works through the virtual windows x, x + 8, x + 16, ... one after another, so
 // that the partial lines of one window's bucket lists meet in that XCD's L2.  gw = ~0 marks padding.  The list depends on the
 // batch's shape only -- not on its scalars -- so nothing of it waits for the device.
 struct FbBlk { u32 gw, tile; };
 
-// the runs of window (job, v) in split blocks [b0, b1): f(entry index in the key / val arrays), 64 lanes side by side within a run
-template <class F>
-__device__ __forceinline__ u32 for_each_run_entry(const unsigned short* __restrict__ lst, u32 nparts, u32 v, u64 ent_base, u32 SW, u32 b0, u32 b1, F f) {
-  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+// the runs of window (job, v) in split blocks [sb, se) of a tile that starts at block b0.  `lpr` adjacent lanes share a run and a lane
+// takes its entries RUN_BATCH at a time: load(j, entry index) for the whole batch first -- independent loads, all in flight --,
+// then use(j) for each of them.
+constexpr int RUN_BATCH = 4;
+constexpr int MAX_BPT = 4096;                        // split blocks per tile (their run starts and lengths are staged in LDS as 16-bit numbers)
+// stage the tile's runs (start inside the block, length) in LDS; returns this thread's share of the entries
+__device__ __forceinline__ u32 stage_runs(unsigned short* rlo, unsigned short* rlen, const unsigned short* __restrict__ lst, u32 nparts, u32 v, u32 b0, u32 b1) {
   u32 mine = 0;
-  for (u32 b = b0 + wave; b < b1; b += nw) {
+  for (u32 b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
     const unsigned short* L = lst + (u64)b * (nparts + 1);
-    const u32 lo = L[v], hi = L[v + 1];
-    const u64 at = ent_base + (u64)b * SW;
-    for (u32 i = lo + lane; i < hi; i += 64) f(at + i);
-    if (lane == 0) mine += hi - lo;
+    const u32 lo = L[v], r = (u32)L[v + 1] - lo;
+    rlo[b - b0] = (unsigned short)lo; rlen[b - b0] = (unsigned short)r; mine += r;
   }
-  return mine;                                       // entries this wave's lane 0 saw (summed over waves by the caller)
+  return mine;
+}
+template <class LD, class US>
+__device__ __forceinline__ void for_each_run_entry(const unsigned short* rlo, const unsigned short* rlen, u64 ent_base, u32 SW, u32 b0, u32 sb, u32 se, LD load, US use) {
+  const u32 span = se - sb;
+  // lanes per run: at least 16 -- a run is ~100 B of keys and ~200 B of values, and 16 lanes take it in 3-4 coalesced steps (4 lanes
+  // per run, all runs in flight at once, measured 0.9 ms per proof slower at 2^20: every load instruction then touches 16 lines;
+  // profiles/r06h_sweep_lanes_per_run.txt) --, more when the tile has few runs
+  u32 lg = 4;
+  while (lg < 6 && ((2u << lg) * span) <= blockDim.x) lg++;
+  const u32 lpr = 1u << lg, grp = threadIdx.x >> lg, sub = threadIdx.x & (lpr - 1), ngrp = blockDim.x >> lg;
+  for (u32 b = sb + grp; b < se; b += ngrp) {
+    const u32 lo = rlo[b - b0], hi = lo + rlen[b - b0];
+    const u64 at = ent_base + (u64)b * SW;
+    for (u32 i0 = lo + sub; i0 < hi; i0 += lpr * RUN_BATCH) {
+#pragma unroll
+      for (int j = 0; j < RUN_BATCH; j++) { const u32 i = i0 + j * lpr; if (i < hi) load(j, at + i); }
+#pragma unroll
+      for (int j = 0; j < RUN_BATCH; j++) { const u32 i = i0 + j * lpr; if (i < hi) use(j); }
+    }
+  }
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void hist_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk, FbJobs jobs,
                                                             const unsigned short* __restrict__ key, const unsigned short* __restrict__ lst_all,
-                                                            u32* __restrict__ bh, u32 nb, u32 nparts, u32 SW, u32* __restrict__ largest) {
-  extern __shared__ __attribute__((aligned(16))) u32 h[];        // [nb] counters, [nb]: the tile's entries
+                                                            u32* __restrict__ bh, u32 nb, u32 nparts, u32 SW) {
+  extern __shared__ __attribute__((aligned(16))) u32 h[];        // [nb] counters, then the staged runs
+  unsigned short* rlo = (unsigned short*)(h + nb);
+  unsigned short* rlen = rlo + MAX_BPT;
   const u32 gw = blk[blockIdx.x].gw, tb = blk[blockIdx.x].tile;
   if (gw == 0xffffffffu) return;
   const FbWin d = fbw[gw];
   const u32 job = gw / nparts, v = gw % nparts;
-  for (u32 b = threadIdx.x; b <= nb; b += blockDim.x) h[b] = 0;
-  __syncthreads();
+  for (u32 b = threadIdx.x; b < nb; b += blockDim.x) h[b] = 0;
   const u32 b0 = tb * d.bpt, b1 = b0 + d.bpt < jobs.nblk[job] ? b0 + d.bpt : jobs.nblk[job];
-  const u32 mine = for_each_run_entry(lst_all + jobs.lst_off[job], nparts, v, jobs.ent_off[job], SW, b0, b1, [&](u64 at) { atomicAdd(&h[key[at]], 1u); });
-  if (mine) atomicAdd(&h[nb], mine);
+  (void)stage_runs(rlo, rlen, lst_all + jobs.lst_off[job], nparts, v, b0, b1);
   __syncthreads();
-  if (threadIdx.x == 0 && h[nb] > (u32)MAX_TILE) atomicMax(largest, 0xffffffffu);     // the scatter cannot stage this tile: the batch is skewed
+  u32 kk[RUN_BATCH];
+  for_each_run_entry(rlo, rlen, jobs.ent_off[job], SW, b0, b0, b1, [&](int j, u64 at) { kk[j] = key[at]; }, [&](int j) { atomicAdd(&h[kk[j]], 1u); });
+  __syncthreads();
   u32* out = bh + d.bh_off + (u64)tb * nb;
   for (u32 b = threadIdx.x; b < nb; b += blockDim.x) out[b] = h[b];
 }
@@ -309,49 +332,89 @@ __global__ __launch_bounds__(1024) void woff_kernel(FbWin* __restrict__ fbw, con
 
 // One block = one tile: bucket counts by LDS atomics over the tile's runs, local bucket starts by a scan, the entries placed in
 // LDS in bucket order (second walk over the runs: keys and values come out of L2), then copied out (global position = where the
-// tile's share of the bucket starts + offset inside the tile's share), consecutive lanes to consecutive addresses.
+// tile's share of the bucket starts + offset inside the tile's share), consecutive lanes to consecutive addresses.  The tiles are
+// sized on the host for uniformly distributed scalars (~13 K entries); a tile that holds more than the staging area takes (digits
+// that repeat: a window whose top digits are all small, a polynomial with a dominant coefficient) is worked off in SUB-TILES of
+// consecutive split blocks, `done` carrying every bucket's fill level from one to the next -- no input makes the sort leave this
+// path, only the buckets' own sizes do (skew_limit).
+static_assert(SPLIT_ENTRIES <= MAX_TILE, "one split block's run must fit a scatter sub-tile");
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __restrict__ fbw, const FbBlk* __restrict__ blk, FbJobs jobs,
                                                                const unsigned short* __restrict__ key, const u32* __restrict__ val,
                                                                const unsigned short* __restrict__ lst_all, const u32* __restrict__ bh,
-                                                               const u32* __restrict__ base, u32* __restrict__ sorted, u32 nb, u32 nparts, u32 SW) {
+                                                               const u32* __restrict__ base, const u32* __restrict__ tot, u32* __restrict__ sorted,
+                                                               u32 nb, u32 nparts, u32 SW) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* lcnt = lds;                                 // [nb] counts -> local starts
   u32* cur = lds + nb;                             // [nb] cursors
   u32* gdst = lds + 2 * nb;                        // [nb]
-  u32* tmp = lds + 3 * nb;                         // [32], tmp[31]: the tile's entries
-  u32* stage = lds + 3 * nb + 32;                  // [MAX_TILE]
-  unsigned short* sbkt = (unsigned short*)(stage + MAX_TILE);
+  u32* done = lds + 3 * nb;                        // [nb] entries of each bucket the earlier sub-tiles of this tile have written
+  u32* tmp = lds + 4 * nb;                         // [32]; tmp[30], tmp[31]: end block and entries of the sub-tile
+  u32* stage = lds + 4 * nb + 32;                  // [MAX_TILE]
+  unsigned short* sbkt = (unsigned short*)(stage + MAX_TILE);      // [MAX_TILE]
+  unsigned short* rlen = sbkt + MAX_TILE;                           // [MAX_BPT] run lengths of the tile's blocks
+  unsigned short* rlo = rlen + MAX_BPT;                             // [MAX_BPT] where each run starts inside its block
   const u32 gw = blk[blockIdx.x].gw, tb = blk[blockIdx.x].tile, t = threadIdx.x;
   if (gw == 0xffffffffu) return;
   const FbWin d = fbw[gw];
   const u32 job = gw / nparts, v = gw % nparts;
-  for (u32 b = t; b < nb; b += SORT_THREADS) lcnt[b] = 0;
-  if (t == 0) tmp[31] = 0;
-  __syncthreads();
   const u32 b0 = tb * d.bpt, b1 = b0 + d.bpt < jobs.nblk[job] ? b0 + d.bpt : jobs.nblk[job];
   const unsigned short* lst = lst_all + jobs.lst_off[job];
-  const u32 mine = for_each_run_entry(lst, nparts, v, jobs.ent_off[job], SW, b0, b1, [&](u64 at) { atomicAdd(&lcnt[key[at]], 1u); });
-  if (mine) atomicAdd(&tmp[31], mine);
+  for (u32 b = t; b < nb; b += SORT_THREADS) done[b] = 0;
+  if (t == 0) tmp[29] = 0;                           // the tile's entries
   __syncthreads();
-  const u32 cnt = tmp[31];
-  if (cnt > (u32)MAX_TILE) return;                  // hist_kernel has marked the batch as skewed; nothing below is read
-  __syncthreads();                                   // (tmp is the scan's scratch next)
-  block_excl_scan2(lcnt, nb, tmp);
   {
-    const u32* pre = bh + d.bh_off + (u64)tb * nb;
-    const u32* bs = base + (u64)gw * nb;
-    for (u32 b = t; b < nb; b += SORT_THREADS) { cur[b] = lcnt[b]; gdst[b] = bs[b] + pre[b] - lcnt[b]; }
+    u32 mine = stage_runs(rlo, rlen, lst, nparts, v, b0, b1);
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((t & 63) == 0 && mine) atomicAdd(&tmp[29], mine);
   }
-  __syncthreads();
-  (void)for_each_run_entry(lst, nparts, v, jobs.ent_off[job], SW, b0, b1, [&](u64 at) {
-    const u32 kb = key[at];
-    const u32 pos = atomicAdd(&cur[kb], 1u);
-    stage[pos] = val[at];
-    sbkt[pos] = (unsigned short)kb;
-  });
-  __syncthreads();
+  const u32* pre = bh + d.bh_off + (u64)tb * nb;
+  const u32* bs = base + (u64)gw * nb;
   u32* out = sorted + d.off;
-  for (u32 idx = t; idx < cnt; idx += SORT_THREADS) out[gdst[sbkt[idx]] + idx] = stage[idx];
+  const u32* tot_w = tot + (u64)gw * nb;
+  const bool last_tile = tb + 1 == d.ntiles;
+  u32 kk[RUN_BATCH], vv[RUN_BATCH];
+  u32 sb = b0;
+  bool whole = true;                                 // the tile in one piece: its bucket counts are what hist_kernel found
+  while (sb < b1) {                                  // one iteration unless the tile is overfull
+    __syncthreads();
+    if (t == 0) {
+      u32 e = b1, n = tmp[29];
+      if (sb != b0 || n > (u32)MAX_TILE) {             // overfull: as many consecutive blocks as the staging area takes
+        e = sb; n = 0;
+        while (e < b1 && n + rlen[e - b0] <= (u32)MAX_TILE) { n += rlen[e - b0]; e++; }   // (a single run never exceeds S W <= MAX_TILE)
+        if (e == sb) { e = sb + 1; n = 0; }            // unreachable (static_assert above); never spin
+      }
+      tmp[30] = e; tmp[31] = n;
+    }
+    __syncthreads();
+    const u32 se = tmp[30], cnt = tmp[31];
+    whole = whole && sb == b0 && se == b1;
+    if (whole) {
+      // after colscan the histogram rows hold the exclusive prefix over the window's tiles: this tile's count of bucket b is the
+      // next row's prefix (the bucket's total for the last tile) minus its own -- no second walk over the entries
+      for (u32 b = t; b < nb; b += SORT_THREADS) lcnt[b] = (last_tile ? tot_w[b] : pre[nb + b]) - pre[b];
+    } else {
+      for (u32 b = t; b < nb; b += SORT_THREADS) lcnt[b] = 0;
+      __syncthreads();
+      for_each_run_entry(rlo, rlen, jobs.ent_off[job], SW, b0, sb, se, [&](int j, u64 at) { kk[j] = key[at]; }, [&](int j) { atomicAdd(&lcnt[kk[j]], 1u); });
+    }
+    __syncthreads();
+    block_excl_scan2(lcnt, nb, tmp);
+    for (u32 b = t; b < nb; b += SORT_THREADS) {
+      const u32 here = (b + 1 < nb ? lcnt[b + 1] : cnt) - lcnt[b];
+      cur[b] = lcnt[b]; gdst[b] = bs[b] + pre[b] + done[b] - lcnt[b]; done[b] += here;
+    }
+    __syncthreads();
+    for_each_run_entry(rlo, rlen, jobs.ent_off[job], SW, b0, sb, se, [&](int j, u64 at) { kk[j] = key[at]; vv[j] = val[at]; },
+                       [&](int j) {
+                         const u32 pos = atomicAdd(&cur[kk[j]], 1u);
+                         stage[pos] = vv[j];
+                         sbkt[pos] = (unsigned short)kk[j];
+                       });
+    __syncthreads();
+    for (u32 idx = t; idx < cnt; idx += SORT_THREADS) out[gdst[sbkt[idx]] + idx] = stage[idx];
+    sb = se;
+  }
 }
 
 // ---- bucket order: largest first -------------------------------------------------------------------------------
