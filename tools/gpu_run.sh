@@ -118,6 +118,8 @@ print("FRESH launches %d, sliced MSMs %d, mismatches %d, errors %d, violations %
       sum(r["mismatches"] for r in rows), sum(r["errors"] for r in rows), sum(r["violations"] for r in rows)))
 PY
       ;;
+    absim=*)        # absim=<lib.so>: the same alternation for one simulated rank of 8 at 2^20
+      bash tools/ab.sh "${R#absim=}" --no-seam-route --simulate-rank 5/8 > $O/ab_sim_5_8.txt 2>&1; cut -c1-330 $O/ab_sim_5_8.txt ;;
     ab=*)
       bash tools/ab.sh "${R#ab=}" --no-seam-route > $O/ab.txt 2>&1; cut -c1-330 $O/ab.txt ;;
     *) echo "unknown recipe $R" ;;
