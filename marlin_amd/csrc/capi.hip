@@ -337,7 +337,8 @@ static int msm_set_attrs(Context& c) {
   int lds = 32768 * 4;
   MH_HIP(hipFuncSetAttribute((const void*)msm::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::psplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::psplit_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  MH_HIP(hipFuncSetAttribute((const void*)msmfb::psplit_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(msmfb::PLANE_THREADS * sizeof(msmfb::G1Xyzz30))));
@@ -615,8 +616,13 @@ struct FbRun {
     }
     u32* d_max = (u32*)ws.sums.ptr;                    // [0] largest bucket, [1] buckets with deferred entries
     MH_HIP(hipMemsetAsync(d_max, 0, 8, s));
-    if (max_blk)
-      hipLaunchKernelGGL(F::psplit_kernel, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, key, val, lst, W, win, is_mont,
+    // the usual width: recoding unrolled over compile-time windows (msm::for_each_digit_c; the generic kernel -- its scalar's words
+    // indexed at run time, i.e. served from scratch -- costs 0.6 ms more per proof on a rank of 8, profiles/r06m_*)
+    if (max_blk && bs.tab_c == 20)
+      hipLaunchKernelGGL(F::psplit_kernel<20>, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, key, val, lst, W, win, is_mont,
+                         nparts, pshift, (u32)bs.n, S, own);
+    else if (max_blk)
+      hipLaunchKernelGGL(F::psplit_kernel<0>, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, key, val, lst, W, win, is_mont,
                          nparts, pshift, (u32)bs.n, S, own);
     msmfb::FbWin* fbw = (msmfb::FbWin*)ws.desc.ptr;
     const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;
@@ -639,9 +645,10 @@ struct FbRun {
     // only on the skewed batches that leave this path anyway)
     u32* d_szh = (u32*)ws.sums.ptr + 16;
     MH_HIP(hipMemsetAsync(d_szh, 0, F::SIZE_BINS * 4, s));
-    hipLaunchKernelGGL(F::size_hist_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, s, (const u32*)ws.tot.ptr, (u64)WB, d_szh);
+    const u64 OW = (u64)nj * nbown;                    // the owned buckets of all jobs: what is ordered, and what the accumulate kernel is launched over
+    hipLaunchKernelGGL(F::size_hist_kernel, dim3((unsigned)((OW + 1023) / 1024)), dim3(1024), 0, s, (const u32*)ws.tot.ptr, OW, nbown, nbt, pshift, own, d_szh);
     hipLaunchKernelGGL(F::size_scan_kernel, dim3(1), dim3(1024), 0, s, d_szh);
-    hipLaunchKernelGGL(F::size_perm_kernel, dim3((unsigned)((WB + 1023) / 1024)), dim3(1024), 0, s, (const u32*)ws.tot.ptr, (u64)WB, d_szh,
+    hipLaunchKernelGGL(F::size_perm_kernel, dim3((unsigned)((OW + 1023) / 1024)), dim3(1024), 0, s, (const u32*)ws.tot.ptr, OW, nbown, nbt, pshift, own, d_szh,
                        (u32*)ws.perm.ptr);
     // The skew decision (largest bucket > max(4096, 32 x average)) is taken on the device by the accumulate kernel and read
     // by the host together with the results (finish): no host round trip between the sort and the accumulation.
@@ -660,7 +667,7 @@ struct FbRun {
     u32* d_max = (u32*)ws.sums.ptr;
     {
       ProfScope pa(c, PF_MSM_ACCUM, s);
-      const u64 nblk = (WB + msm::ACC_TPB - 1) / msm::ACC_TPB;
+      const u64 OW = (u64)nj * nbown;
       // Resident waves per SIMD of the accumulate kernel (register budget 512 / waves).  With the chip full (one GPU: ~32 equally long waves per SIMD and launch) 2 and 3 run the
       // kernel at the same rate -- it is bound by VALU issue -- and 3 is the default.  A bucket-range shard of 8 ranks leaves
       // only ~4 waves per SIMD: at 3 resident the fourth runs ALONE, and one wave issues at ~2/3 of the rate two or three
@@ -671,15 +678,17 @@ struct FbRun {
       // 14.5 / 16.9.  So: 2 when a launch has at most 6 waves per SIMD, else 3.
       const u64 active = (u64)nj * nbown;                                     // buckets that do work on this rank
       const u64 per_simd = (active / 64 + (u64)c.num_simds - 1) / (u64)c.num_simds;
-      const int acc_waves = per_simd <= 6 ? 2 : 3;
+      const int acc_waves = per_simd <= 6 ? 2 : 3;      // (blocks of 64 or 128 threads instead of 256 on the thin launches: no difference, profiles/r06m_*)
+      const unsigned tpb = (unsigned)msm::ACC_TPB;
+      const u64 nblk = (OW + tpb - 1) / tpb;
       if (acc_waves == 2)
-        hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
+        hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(tpb), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
-                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, OW, (const u32*)d_max, skew_limit);
       else
-        hipLaunchKernelGGL(F::accum30_kernel<3>, dim3((unsigned)nblk), dim3(msm::ACC_TPB), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
+        hipLaunchKernelGGL(F::accum30_kernel<3>, dim3((unsigned)nblk), dim3(tpb), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
-                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (u64)WB, nparts, own, (const u32*)d_max, skew_limit);
+                           (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, OW, (const u32*)d_max, skew_limit);
     }
     ProfScope ps(c, PF_MSM_STAGES, s);
     hipLaunchKernelGGL(F::fixup30_kernel, dim3((unsigned)std::min<u64>((WB + 63) / 64, 1024)), dim3(64), 0, s, fbw,

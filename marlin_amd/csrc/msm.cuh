@@ -123,6 +123,29 @@ __device__ __forceinline__ void for_each_digit(const Fr& s, u32 W, const Windows
   }
 }
 
+// The same recoding for a window width known at compile time (C = the table's c): unrolled, every window's first bit and width are
+// constants, so the scalar's words are addressed as registers.  The generic form above indexes s.v[] with a run-time word number,
+// which the compiler can only serve from scratch memory: 2 x 13 scratch loads per scalar and pass in the partition kernel.
+template <int C, class F>
+__device__ __forceinline__ void for_each_digit_c(const Fr& s, F f) {
+  constexpr u32 W = (256 + C - 1) / C, narrow = W * C - 256;
+  u32 carry = 0;
+#pragma unroll
+  for (u32 w = 0; w < W; w++) {
+    const u32 wb = (w >= W - narrow) ? C - 1 : C;
+    const u32 bit = w * C - (w > W - narrow ? w - (W - narrow) : 0);      // = make_windows' start[w]
+    const u32 half = 1u << (wb - 1), mask = (1u << wb) - 1;
+    const u32 limb = bit >> 5, sh = bit & 31;
+    u64 two = s.v[limb];
+    if (limb + 1 < 8) two |= (u64)s.v[limb + 1] << 32;
+    const u32 raw = ((u32)(two >> sh) & mask) + carry;
+    u32 e;
+    if (raw > half) { e = ((1u << wb) - raw) | 0x80000000u; carry = 1; }
+    else { e = raw; carry = 0; }
+    f(w, e);
+  }
+}
+
 __global__ __launch_bounds__(256) void digits_kernel(Jobs jobs, u32* __restrict__ dig_all, u32 W, Windows win, int is_mont) {
   const u32 job = blockIdx.y;
   const u64 n = jobs.n[job];

@@ -164,6 +164,9 @@ __device__ __forceinline__ bool owns(const Own& o, u32 v) {
 // coalesced, followed by the table of its partition starts (lst: nparts + 1 offsets).  No global position depends on another
 // block, so nothing is counted beforehand and the host learns nothing: a virtual window is no longer one contiguous run but one
 // run per block (~50 entries at c = 20), which the tiles of hist / scatter walk block by block.
+// C: the table's window width when it is the usual one (20: the recoding is unrolled over compile-time windows, see
+// msm::for_each_digit_c), 0: any width (the windows come from `win`)
+template <int C>
 __global__ __launch_bounds__(SORT_THREADS) void psplit_kernel(FbJobs jobs, unsigned short* __restrict__ key, u32* __restrict__ val,
                                                               unsigned short* __restrict__ lst_all, u32 W, Windows win, int is_mont,
                                                               u32 nparts, u32 pshift, u32 tab_n, u32 S, Own own) {
@@ -183,19 +186,20 @@ __global__ __launch_bounds__(SORT_THREADS) void psplit_kernel(FbJobs jobs, unsig
   if (live) {
     s = ff_load(jobs.scalars[job] + i);
     if (!is_mont) s = ff_to_mont(s);              // the table holds [R^-1] P: the digits of s R are what multiplies it
-    msm::for_each_digit(s, W, win, [&](u32, u32 e) {
+    auto count = [&](u32, u32 e) {
       const u32 b = e & 0x7fffffffu;
       if (b) {
         const u32 v = (b - 1) >> pshift;
         if (owns(own, v)) atomicAdd(&cur[v], 1u);
       }
-    });
+    };
+    if constexpr (C > 0) msm::for_each_digit_c<C>(s, count); else msm::for_each_digit(s, W, win, count);
   }
   __syncthreads();
   block_excl_scan2(cur, MAX_PARTS, tmp);
   if (live) {
     const u32 t0 = jobs.tab_off[job] + (u32)i * jobs.tab_stride[job];
-    msm::for_each_digit(s, W, win, [&](u32 w, u32 e) {
+    auto place = [&](u32 w, u32 e) {
       u32 b = e & 0x7fffffffu;
       if (b) {
         b -= 1;
@@ -205,7 +209,8 @@ __global__ __launch_bounds__(SORT_THREADS) void psplit_kernel(FbJobs jobs, unsig
         skey[p] = (unsigned short)(b & ((1u << pshift) - 1));
         sval[p] = (w * tab_n + t0) | (e & 0x80000000u);          // table indices stay below 2^31 (mh_bases_precompute checks)
       }
-    });
+    };
+    if constexpr (C > 0) msm::for_each_digit_c<C>(s, place); else msm::for_each_digit(s, W, win, place);
   }
   __syncthreads();
   // cur[v] is now the END of partition v's run = the start of partition v + 1's
@@ -423,12 +428,21 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const FbWin* __re
 // the 64 lanes of every wave get equal trip counts (to within one), blocks start in longest-first order and the tail
 // of the launch consists of the smallest buckets.
 constexpr int SIZE_BINS = 1024;    // sizes >= 1023 share the last bin
-__global__ __launch_bounds__(1024) void size_hist_kernel(const u32* __restrict__ tot, u64 WB, u32* __restrict__ ghist) {
+// (Only the OWNED buckets are ordered -- slot o of the nj x nbown owned buckets is bucket owned_gid(o) --: a rank of 8 owns an eighth
+// of every job's buckets, and ordering, permuting and launching the other seven eighths as empty buckets cost the size kernels
+// their whole time and the accumulate kernel a tail of thousands of blocks that only find out that they have nothing to do.)
+__device__ __forceinline__ u64 owned_gid(u64 o, u32 nbown, u32 nbt, u32 pshift, const Own& own) {
+  const u64 k = o / nbown;
+  const u32 ob = (u32)(o - k * nbown);
+  const u32 v = own.first + (ob >> pshift) * own.stride;
+  return k * nbt + ((u64)v << pshift) + (ob & ((1u << pshift) - 1));
+}
+__global__ __launch_bounds__(1024) void size_hist_kernel(const u32* __restrict__ tot, u64 OW, u32 nbown, u32 nbt, u32 pshift, Own own, u32* __restrict__ ghist) {
   __shared__ u32 lh[SIZE_BINS];
   lh[threadIdx.x] = 0;
   __syncthreads();
   const u64 g = (u64)blockIdx.x * 1024 + threadIdx.x;
-  if (g < WB) { u32 sz = tot[g]; atomicAdd(&lh[sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1], 1u); }
+  if (g < OW) { u32 sz = tot[owned_gid(g, nbown, nbt, pshift, own)]; atomicAdd(&lh[sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1], 1u); }
   __syncthreads();
   if (lh[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], lh[threadIdx.x]);
 }
@@ -441,18 +455,20 @@ __global__ __launch_bounds__(1024) void size_scan_kernel(u32* __restrict__ ghist
   block_excl_scan2(a, SIZE_BINS, tmp);
   ghist[SIZE_BINS - 1 - threadIdx.x] = a[threadIdx.x];
 }
-__global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__ tot, u64 WB, u32* __restrict__ gcur, u32* __restrict__ perm) {
+__global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__ tot, u64 OW, u32 nbown, u32 nbt, u32 pshift, Own own, u32* __restrict__ gcur,
+                                                         u32* __restrict__ perm) {
   __shared__ u32 lh[SIZE_BINS];
   __shared__ u32 lbase[SIZE_BINS];
   lh[threadIdx.x] = 0;
   __syncthreads();
   const u64 g = (u64)blockIdx.x * 1024 + threadIdx.x;
+  const u64 gid = g < OW ? owned_gid(g, nbown, nbt, pshift, own) : 0;
   u32 bin = 0, rank = 0;
-  if (g < WB) { u32 sz = tot[g]; bin = sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1; rank = atomicAdd(&lh[bin], 1u); }
+  if (g < OW) { u32 sz = tot[gid]; bin = sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1; rank = atomicAdd(&lh[bin], 1u); }
   __syncthreads();
   if (lh[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&gcur[threadIdx.x], lh[threadIdx.x]);
   __syncthreads();
-  if (g < WB) perm[lbase[bin] + rank] = (u32)g;
+  if (g < OW) perm[lbase[bin] + rank] = (u32)gid;
 }
 
 // ---- accumulate: thread per bucket, XYZZ += table point, all in 30-bit limbs -----------------------------------
@@ -466,10 +482,10 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
                                                                const u32* __restrict__ sorted_all, const u32* __restrict__ base,
                                                                const u32* __restrict__ tot, const u32* __restrict__ perm,
                                                                G1Xyzz30* __restrict__ buckets, u32* __restrict__ pend,
-                                                               u32* __restrict__ n_deferred, u32 nb, u64 WB, u32 nparts, Own own,
+                                                               u32* __restrict__ n_deferred, u32 nb, u64 OW,
                                                                const u32* __restrict__ largest, u32 skew_limit) {
-  const u64 slot = (u64)blockIdx.x * msm::ACC_TPB + threadIdx.x;
-  if (slot >= WB) return;
+  const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= OW) return;                     // OW: the owned buckets of all jobs (perm lists exactly those, largest first)
   // a batch whose largest bucket exceeds the limit leaves this path (the host sees the same number with the results and takes
   // the variable-base path): return at once instead of walking a list of millions in one thread
   if (*largest > skew_limit) return;
@@ -478,11 +494,7 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
   const u32* lst = sorted_all + d.off + base[gid];
   const G1Aff30* tab = table + d.delta;
   const u32 cnt = tot[gid];
-  if (cnt == 0) {
-    const u32 v = (u32)(gid / nb) % nparts;         // another rank's buckets are never read: nothing to store
-    if (owns(own, v)) { x30_store(buckets + gid, x30_identity()); pend[gid] = 0; }
-    return;
-  }
+  if (cnt == 0) { x30_store(buckets + gid, x30_identity()); pend[gid] = 0; return; }
   Fq30 zero;
 #pragma unroll
   for (int i = 0; i < Fq30::NL; i++) zero.v[i] = 0;
@@ -633,7 +645,7 @@ __device__ __forceinline__ void block_tree_sum(X30& acc, G1Xyzz30* sh, u32 nthre
     if (threadIdx.x < off) {
       X30 a = x30_load(sh + threadIdx.x);
       const X30 b = x30_load(sh + threadIdx.x + off);
-      x30_add_ilp(a, b);
+      x30_add_ilp_inl(a, b);
       if (off > 1) x30_store(sh + threadIdx.x, a); else acc = a;
     }
     __syncthreads();
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void plane_kernel(const G1Xyzz30* __
     else if (plane < p.lgC + p.lgM) { q = insert_one(k, plane - p.lgC); if (q >= p.R_own) continue; }   // rows m with bit (plane - lgC)
     else q = k;                                                            // every row: the rows cover every bucket once
     const X30 t = x30_load(S + q);
-    x30_add_ilp(acc, t);
+    x30_add_ilp_inl(acc, t);
   }
   u32 width = 1;
   while (width < count && width < PLANE_THREADS) width <<= 1;

@@ -143,7 +143,8 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
   // MH_MOCK_RCCL_CORRUPT_RANK=<r>: rank r receives a damaged byte -- lets a test see a transport self-test FAIL on one rank
   // and the caller fall back on all of them
   if (const char* e = getenv("MH_MOCK_RCCL_CORRUPT_RANK"))
-    if (atoi(e) == c->rank && hipMemset(recv, 0xA5, 1) != hipSuccess) return ncclUnhandledCudaError;
+    if (atoi(e) == c->rank && (hipMemsetAsync(recv, 0xA5, 1, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))   // on the caller's
+      return ncclUnhandledCudaError;       // stream: a hipMemset of device memory may return before it lands, and the caller's copy-back is on `s`
   return ncclSuccess;
 }
 #ifndef MOCK_NO_ALLTOALL

@@ -246,7 +246,7 @@ def test_bench_falls_back_to_the_callbacks_when_one_rank_fails_the_native_self_t
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearsal", "--steps", "1", "--warmup", "1", "--transport", "native",
                           "--log-constraints", "14", "--no-cpu-baseline", "--no-throughput"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    assert "native RCCL transport unavailable" in out.stderr
+    assert "native RCCL transport unavailable" in out.stderr, out.stderr[-4000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["transport"]["kind"] == "callback-torch.distributed-gloo" and rec["transport"]["native_rccl"] is None, rec["transport"]
     assert rec["proof"]["verified"] is True and rec["proof"]["identical_on_all_ranks"] is True and "slices" in rec["config"]["parallelism"]

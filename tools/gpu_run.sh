@@ -85,7 +85,10 @@ for R in "$@"; do
           --no-cpu-baseline --no-seam-route --no-verify --simulate-rank 5/8 > $O/trace_sim58.log 2>&1 )
       T=$(find $O/trace_sim58 -name "*kernel_trace.csv" | head -1)
       [ -n "$T" ] && python tools/prove_kernels.py $T > $O/sim_5_8_last_prove_kernels.txt 2>&1 && python tools/gap_analysis.py $T 4 > $O/sim_5_8_gaps.txt 2>&1
+      [ -n "$T" ] && python tools/prove_timeline.py $T 4 > $O/sim_5_8_timeline.txt 2>&1
       rm -rf $O/trace_sim58; head -70 $O/sim_5_8_last_prove_kernels.txt ;;
+    one=*)          # one=<pytest node id or -k expression file::test>: a single test, verbose
+      ( timeout 900 python -m pytest "${R#one=}" -m gpu -x -q -p no:cacheprovider > $O/pytest_one.log 2>&1; echo "pytest rc=$?" >> $O/pytest_one.log ); tail -60 $O/pytest_one.log ;;
     msmtests)       # the MSM / check / golden-proof tests (after a change to the fixed-base pipeline), invariants on
       ( MH_CHECK=2 timeout 1500 python -m pytest tests/test_gpu_msm.py tests/test_gpu_check.py tests/test_gpu_dist_blocks.py tests/test_gpu_reentrancy.py -m gpu -q -x --durations=8 -p no:cacheprovider > $O/pytest_msm.log 2>&1; echo "pytest rc=$?" >> $O/pytest_msm.log
         MH_CHECK=1 timeout 1500 python -m pytest tests/test_gpu_marlin.py tests/test_gpu_parity_pins.py -m gpu -q -x -k "golden or sharded or zero_matrix or sonic_proof or full_size" --durations=8 -p no:cacheprovider >> $O/pytest_msm.log 2>&1; echo "pytest rc=$?" >> $O/pytest_msm.log ); grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_msm.log | tail -30 ;;
@@ -100,6 +103,12 @@ for R in "$@"; do
       for rep in 1 2; do for V in ${VALS//,/ }; do
         env $VAR=$V $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); b=d['breakdown_ms_per_step']; print('$VAR=$V', d['ms_per_step'], 'accum', b['msm_accum'], 'sort+reduce', b['msm_sort_and_reduce_stages'])"
       done; done | tee -a $O/sweep_$VAR.txt ;;
+    sweepsim=*)     # sweepsim=VAR:v1,v2,...: one simulated rank of 8 at 2^20 under each value of one environment variable (twice; "-" = unset)
+      IFS=: read -r VAR VALS <<< "${R#sweepsim=}"
+      for rep in 1 2; do for V in ${VALS//,/ }; do
+        ( if [ "$V" = "-" ]; then unset $VAR; else export $VAR=$V; fi
+          $B --simulate-rank 5/8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); b=d['breakdown_ms_per_step']; print('$VAR=$V', d['ms_per_step'], 'accum', b['msm_accum'], 'sort+reduce', b['msm_sort_and_reduce_stages'], 'glue', b['glue'], 'host', b['host_and_other'])" )
+      done; done | tee -a $O/sweepsim_$VAR.txt ;;
     check)          # the MH_CHECK tests by themselves
       ( timeout 900 python -m pytest tests/test_gpu_check.py -m gpu -q -x --durations=8 -p no:cacheprovider > $O/pytest_check.log 2>&1; echo "pytest rc=$?" >> $O/pytest_check.log ); tail -25 $O/pytest_check.log ;;
     soak=*)         # tools/soak_sliced.py: soak=<iterations>[:<MH_DIAG>[:serialize]] -- 8 processes on the GPU, MH_CHECK=2
