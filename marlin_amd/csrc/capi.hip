@@ -456,6 +456,7 @@ struct FbRun {
   std::vector<u32> bpt;                            // split blocks per hist / scatter tile, per partition
   msmfb::RsPlan rs; std::vector<u64> coef;        // bucket reduction: matrix shape, chunking, planes; the host's coefficient of each plane
   std::vector<msmfb::FbWin> desc; std::vector<msmfb::FbBlk> blk;
+  bool vmode = false; u32 vT0 = 0, vTs0 = 0, vcap = 0;       // thin launch: buckets accumulated in parts over virtual slots (msm_fb.cuh: VTab)
   bool skewed = false;
   u32 skew_limit = 0xffffffffu, skew_floor = 4096;   // a batch is skewed when its largest bucket exceeds max(skew_floor, 32 x the average)
   FbRun(Context& c_, const BaseSet& bs_, Context::FbWs& ws_) : c(c_), bs(bs_), ws(ws_) {}
@@ -565,6 +566,25 @@ struct FbRun {
     MH_TRY(ws.win.ensure((size_t)nj * rs.nplanes * sizeof(G1Xyzz)));
     MH_TRY(ws.sums.ensure(64 + F::SIZE_BINS * 4));
     MH_TRY(ws.perm.ensure(WB * 4));
+    // The accumulate kernel runs over virtual slots, buckets above Ts entries in parts of T (msm_fb.cuh: VTab): T = half, Ts = two
+    // thirds of the entries a lane gets when the launch's entries are spread evenly over the 2 x 64 lanes of every SIMD, for
+    // uniformly distributed digits (a rank of 8 at 2^20: 7.31-7.37 ms of accumulation per proof at 50 / 66 % and at 33 / 33 %,
+    // 7.5-8.1 at 25 / 50 % and at 50 / 100 %, 8.0 with the hardware's dispatch: profiles/r06u_*); the device doubles both until the
+    // parts fit the buffer.  MH_ACC_PARTS=0: the one-thread-per-bucket kernel of rounds 1-5 (cross-check).
+    {
+      static const bool parts_env = [] { const char* e = getenv("MH_ACC_PARTS"); return !e || atoi(e) != 0; }();
+      vmode = parts_env;
+      if (vmode) {
+        double ent_own = 0;
+        for (int k = 0; k < nj; k++) ent_own += (double)ns[k] * W * (double)nbown / (double)nbt;
+        const double per_lane = ent_own / (128.0 * (double)c.num_simds);
+        vT0 = (u32)std::max(8.0, per_lane * 0.50);
+        vTs0 = (u32)std::max((double)vT0, per_lane * 0.66);
+        vcap = (u32)(4 * 128 * c.num_simds);           // parts of cut buckets <= entries (1 / T + 1 / Ts) = 3.5 per lane for the expected entries
+        MH_TRY(ws.vtab.ensure(sizeof(F::VTab)));
+        MH_TRY(ws.aux.ensure((size_t)vcap * sizeof(F::G1Xyzz30)));
+      }
+    }
     desc.assign(WT, msmfb::FbWin{});
     return MH_OK;
   }
@@ -647,7 +667,8 @@ struct FbRun {
     MH_HIP(hipMemsetAsync(d_szh, 0, F::SIZE_BINS * 4, s));
     const u64 OW = (u64)nj * nbown;                    // the owned buckets of all jobs: what is ordered, and what the accumulate kernel is launched over
     hipLaunchKernelGGL(F::size_hist_kernel, dim3((unsigned)((OW + 1023) / 1024)), dim3(1024), 0, s, (const u32*)ws.tot.ptr, OW, nbown, nbt, pshift, own, d_szh);
-    hipLaunchKernelGGL(F::size_scan_kernel, dim3(1), dim3(1024), 0, s, d_szh);
+    if (vmode) hipLaunchKernelGGL(F::size_vscan_kernel, dim3(1), dim3(1024), 0, s, d_szh, (F::VTab*)ws.vtab.ptr, vT0, vTs0, vcap);
+    else hipLaunchKernelGGL(F::size_scan_kernel, dim3(1), dim3(1024), 0, s, d_szh);
     hipLaunchKernelGGL(F::size_perm_kernel, dim3((unsigned)((OW + 1023) / 1024)), dim3(1024), 0, s, (const u32*)ws.tot.ptr, OW, nbown, nbt, pshift, own, d_szh,
                        (u32*)ws.perm.ptr);
     // The skew decision (largest bucket > max(4096, 32 x average)) is taken on the device by the accumulate kernel and read
@@ -668,20 +689,24 @@ struct FbRun {
     {
       ProfScope pa(c, PF_MSM_ACCUM, s);
       const u64 OW = (u64)nj * nbown;
-      // Resident waves per SIMD of the accumulate kernel (register budget 512 / waves).  With the chip full (one GPU: ~32 equally long waves per SIMD and launch) 2 and 3 run the
-      // kernel at the same rate -- it is bound by VALU issue -- and 3 is the default.  A bucket-range shard of 8 ranks leaves
-      // only ~4 waves per SIMD: at 3 resident the fourth runs ALONE, and one wave issues at ~2/3 of the rate two or three
-      // reach together; at 4 resident (128 VGPRs, 224 B of scratch) every wave pays for its spills.  Measured on a simulated
-      // rank of 8 (profiles/r03j_sim_*): 8.2 / 9.1 / 10.5 ms of accumulation per proof at 2 / 3 / 4 waves at 2^20, 32.5 / 36.6 /
-      // 41.5 ms at 2^22 -- 2 also wins where 3 would leave no lone wave (round 3: 3 waves per SIMD), so part of it is the 3-wave
-      // build's 28 B of scratch, which a full chip hides and a thin launch does not --; rank of 4 (8 waves per SIMD): 14.9 /
-      // 14.5 / 16.9.  So: 2 when a launch has at most 6 waves per SIMD, else 3.
+      // (MH_ACC_PARTS=0, the cross-check: one thread per bucket, the hardware's dispatch.  Resident waves per SIMD there: 3 with the
+      // chip full, 2 -- no spills, no lone fourth wave -- when a launch has at most 6 waves per SIMD: 8.2 / 9.1 / 10.5 ms of
+      // accumulation per proof on a simulated rank of 8 at 2 / 3 / 4 waves, profiles/r03j_sim_*.)
       const u64 active = (u64)nj * nbown;                                     // buckets that do work on this rank
       const u64 per_simd = (active / 64 + (u64)c.num_simds - 1) / (u64)c.num_simds;
       const int acc_waves = per_simd <= 6 ? 2 : 3;      // (blocks of 64 or 128 threads instead of 256 on the thin launches: no difference, profiles/r06m_*)
       const unsigned tpb = (unsigned)msm::ACC_TPB;
       const u64 nblk = (OW + tpb - 1) / tpb;
-      if (acc_waves == 2)
+      if (vmode) {
+        MH_HIP(hipMemsetAsync(ws.pend.ptr, 0, WB * 4, s));
+        const unsigned grid = (unsigned)(2 * c.num_simds * 64 / tpb);            // two waves per SIMD, resident for the whole launch
+        hipLaunchKernelGGL(F::accum30v_kernel, dim3(grid), dim3(tpb), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
+                           (const u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
+                           (F::G1Xyzz30*)ws.buckets.ptr, (F::G1Xyzz30*)ws.aux.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (F::VTab*)ws.vtab.ptr,
+                           (const u32*)d_max, skew_limit);
+        hipLaunchKernelGGL(F::merge_parts_kernel, dim3((unsigned)std::min<u64>((OW + 127) / 128, 2048)), dim3(128), 0, s, (const F::VTab*)ws.vtab.ptr,
+                           (const u32*)ws.perm.ptr, (const F::G1Xyzz30*)ws.aux.ptr, (F::G1Xyzz30*)ws.buckets.ptr, (const u32*)d_max, skew_limit);
+      } else if (acc_waves == 2)
         hipLaunchKernelGGL(F::accum30_kernel<2>, dim3((unsigned)nblk), dim3(tpb), 0, s, fbw, (const F::G1Aff30*)bs.d_table,
                            (u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
                            (F::G1Xyzz30*)ws.buckets.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, OW, (const u32*)d_max, skew_limit);

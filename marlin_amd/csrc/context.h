@@ -150,10 +150,10 @@ struct Context {
   Scratch msm_gather;        // the bases of a skewed strided batch, gathered for the variable-base path
   // fixed-base path (msm_fb.cuh): the workspace of one job group
   struct FbWs {
-    Scratch dig, val, sorted, pc, ptot, desc, blk, bh, tot, base, pend, buckets, seg, win, sums, perm;
+    Scratch dig, val, sorted, pc, ptot, desc, blk, bh, tot, base, pend, buckets, seg, win, sums, perm, vtab, aux;
     Pinned h_desc, h_blk, h_out;              // host side of the descriptors (+ alias map), the block list, the results
     void release_all() {
-      for (Scratch* b : {&dig, &val, &sorted, &pc, &ptot, &desc, &blk, &bh, &tot, &base, &pend, &buckets, &seg, &win, &sums, &perm}) b->release();
+      for (Scratch* b : {&dig, &val, &sorted, &pc, &ptot, &desc, &blk, &bh, &tot, &base, &pend, &buckets, &seg, &win, &sums, &perm, &vtab, &aux}) b->release();
       for (Pinned* b : {&h_desc, &h_blk, &h_out}) b->release();
     }
   } fbws;

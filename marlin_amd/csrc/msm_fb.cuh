@@ -455,6 +455,64 @@ __global__ __launch_bounds__(1024) void size_scan_kernel(u32* __restrict__ ghist
   block_excl_scan2(a, SIZE_BINS, tmp);
   ghist[SIZE_BINS - 1 - threadIdx.x] = a[threadIdx.x];
 }
+// ---- accumulate over virtual slots: persistent waves, long buckets cut into PARTS (round 6) ------------------------------------
+// Through round 5 the accumulate kernel was one thread per bucket in blocks of 256, dispatched by the hardware in size order.  Two
+// things were lost that way.  (1) A bucket-range shard of G ranks has 1 / G of the buckets with lists as long as on one GPU: a rank
+// of 8 has ~4 waves per SIMD in a launch, and the launch lasts as long as its LONGEST buckets (the mask polynomial's, 3 H
+// coefficients: 102 entries where the launch's average is 37) while the other wave slots stand empty -- 63-75 % of the slots
+// occupied over the three commit rounds of a proof at 2^20 (profiles/r06r_*).  (2) On one GPU a block's four waves end at
+// different times and their slots wait for a whole new block.  Now the kernel is persistent -- two waves per SIMD (the group law
+// with its multiplications interleaved fills a SIMD from two waves: x30.cuh), each taking the next 64 VIRTUAL slots from a counter
+// until none is left -- and a bucket larger than Ts entries is accumulated in ceil(size / T) parts by as many lanes (T, Ts from the
+// host: half and two thirds of a lane's share of the launch's entries, so on one GPU nothing is cut; doubled on the device until
+// the parts fit the buffer that holds them); slots go in size order, largest first, so a wave's lanes run equally long, and a
+// small kernel adds a bucket's parts up (one general addition per extra part).  Virtual slot -> (size class s, bucket r of the
+// class, part j): the classes' first slots (voff) are searched in LDS; class s starts at pos[s] in `perm`.  The cut buckets are
+// the largest, so their slots come first: slot = index into the parts' buffer.
+struct VTab {
+  u32 voff[SIZE_BINS + 1];   // [i]: first virtual slot of size class SIZE_BINS - 1 - i (descending sizes); [SIZE_BINS] = V
+  u32 pos[SIZE_BINS + 1];    // [i]: first position in perm of that class; [SIZE_BINS] = owned buckets
+  u32 V, T, Ts, nsplit, counter; // virtual slots, entries per part, largest uncut size, buckets with more than one part (= perm's first nsplit), next free slot
+};
+// parts of a bucket of size class s: one up to Ts entries, else ceil(s / T) -- Ts > T keeps the many buckets just above the part
+// size whole (each extra part is one general addition in merge_parts_kernel and buys nothing there)
+__device__ __forceinline__ u32 vparts(u32 s, u32 T, u32 Ts) { return s <= Ts ? 1u : (s + T - 1) / T; }
+// one block of SIZE_BINS threads, after size_hist: ghist (counts) -> ghist (first positions, descending sizes: what size_perm
+// counts up from) and the table above.  vcap: slots of the parts' buffer (the parts of the CUT buckets must fit).
+__global__ __launch_bounds__(1024) void size_vscan_kernel(u32* __restrict__ ghist, VTab* __restrict__ vt, u32 T0, u32 Ts0, u32 vcap) {
+  __shared__ u32 a[SIZE_BINS];
+  __shared__ u32 b[SIZE_BINS];
+  __shared__ u32 tmp[32];
+  __shared__ u32 sT;
+  const u32 i = threadIdx.x, s = SIZE_BINS - 1 - i;
+  const u32 cnt = ghist[s];
+  u32 T = T0 < 1 ? 1 : T0, Ts = Ts0 < T ? T : Ts0;
+  for (;;) {                                  // a coarser cut until the parts fit (block-uniform loop; ends at the latest with Ts >= every class)
+    b[i] = s > Ts ? cnt * vparts(s, T, Ts) : 0;
+    __syncthreads();
+    for (u32 off = SIZE_BINS / 2; off > 0; off >>= 1) { if (i < off) b[i] += b[i + off]; __syncthreads(); }
+    if (i == 0) sT = b[0] <= vcap ? 1 : 0;
+    __syncthreads();
+    if (sT) break;
+    T = T * 2; Ts = Ts * 2;
+    __syncthreads();
+  }
+  a[i] = cnt; b[i] = cnt * vparts(s, T, Ts);
+  __syncthreads();
+  block_excl_scan2(a, SIZE_BINS, tmp);
+  block_excl_scan2(b, SIZE_BINS, tmp);
+  ghist[s] = a[i];
+  vt->pos[i] = a[i]; vt->voff[i] = b[i];
+  if (i == SIZE_BINS - 1) { vt->pos[SIZE_BINS] = a[i] + cnt; vt->voff[SIZE_BINS] = b[i] + cnt * vparts(s, T, Ts); vt->V = b[i] + cnt * vparts(s, T, Ts); vt->T = T; vt->Ts = Ts; vt->counter = 0; }
+  // buckets with more than one part: the classes s > Ts -- the first position of class Ts in the descending order
+  if (s == (Ts < SIZE_BINS - 1 ? Ts : SIZE_BINS - 1)) vt->nsplit = Ts < SIZE_BINS - 1 ? a[i] : 0;
+}
+// the last index i with tab[i] <= x (tab ascending, tab[0] = 0 <= x < tab[SIZE_BINS]): empty classes repeat their neighbour's value
+__device__ __forceinline__ u32 vclass_of(const u32* tab, u32 x) {
+  u32 lo = 0, hi = SIZE_BINS;                 // invariant: tab[lo] <= x < tab[hi]
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (tab[mid] <= x) lo = mid; else hi = mid; }
+  return lo;
+}
 __global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__ tot, u64 OW, u32 nbown, u32 nbt, u32 pshift, Own own, u32* __restrict__ gcur,
                                                          u32* __restrict__ perm) {
   __shared__ u32 lh[SIZE_BINS];
@@ -477,6 +535,7 @@ __global__ __launch_bounds__(1024) void size_perm_kernel(const u32* __restrict__
 // p (a product of u and v is below 1 + u v / 630): table x < 1, +-y <= 2, zz, zzz <= 1.1; X1 <= 6.2, Y1 <= 2 are
 // loop invariants: P = U2 - X1 + 8p <= 9.1, R = S2 - Y1 + 4p <= 5.1, PP, PPP, Q, R^2 <= 1.2,
 // X3 = (R^2 - PPP + 2p) - 2Q + 3p <= 6.2, Y3 = (R (Q - X3 + 8p) + (4p - Y1) PPP) / R' <= 1 + (5.1 x 9.2 + 4 x 1.2) / 630 < 1.1.
+// (Since round 6 this kernel is the cross-check, MH_ACC_PARTS=0; the default is accum30v_kernel below.)
 template <int WAVES>
 __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void accum30_kernel(const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table,
                                                                const u32* __restrict__ sorted_all, const u32* __restrict__ base,
@@ -532,6 +591,93 @@ __global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(WA
   }
   store30(buckets[gid].c[0], X1); store30(buckets[gid].c[1], Y1); store30(buckets[gid].c[2], ZZ); store30(buckets[gid].c[3], ZZZ);
   pend[gid] = 0;
+}
+
+// The same accumulation over VIRTUAL slots (see VTab): persistent waves, a bucket of more than T entries in parts.  A part's sum goes
+// to aux[slot] (merge_parts_kernel adds a bucket's parts up), an uncut bucket's straight to `buckets`.  `pend` is zeroed by the host
+// beforehand -- a part that meets an equal-x pair marks the whole bucket for the fix-up, the other parts must not unmark it.
+__global__ __launch_bounds__(msm::ACC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void accum30v_kernel(
+    const FbWin* __restrict__ fbw, const G1Aff30* __restrict__ table, const u32* __restrict__ sorted_all, const u32* __restrict__ base,
+    const u32* __restrict__ tot, const u32* __restrict__ perm, G1Xyzz30* __restrict__ buckets, G1Xyzz30* __restrict__ aux, u32* __restrict__ pend,
+    u32* __restrict__ n_deferred, u32 nb, VTab* __restrict__ vt, const u32* __restrict__ largest, u32 skew_limit) {
+  __shared__ u32 s_voff[SIZE_BINS + 1];
+  __shared__ u32 s_pos[SIZE_BINS + 1];
+  if (*largest > skew_limit) return;
+  for (u32 i = threadIdx.x; i <= SIZE_BINS; i += blockDim.x) { s_voff[i] = vt->voff[i]; s_pos[i] = vt->pos[i]; }
+  __syncthreads();
+  const u32 V = vt->V, T = vt->T, Ts = vt->Ts, lane = threadIdx.x & 63u;
+  Fq30 zero;
+#pragma unroll
+  for (int i = 0; i < Fq30::NL; i++) zero.v[i] = 0;
+  for (;;) {
+    u32 first = 0;
+    if (lane == 0) first = atomicAdd(&vt->counter, 64u);
+    first = (u32)__shfl((int)first, 0);
+    if (first >= V) break;
+    const u32 slot = first + lane;
+    if (slot >= V) continue;
+    const u32 ci = vclass_of(s_voff, slot);
+    const u32 p = vparts(SIZE_BINS - 1 - ci, T, Ts);
+    const u32 rel = slot - s_voff[ci], r = rel / p, j = rel - r * p;
+    const u32 gid = perm[s_pos[ci] + r];
+    const FbWin d = fbw[gid / nb];
+    const u32 cnt = tot[gid];
+    const u32 lo = (u32)((u64)cnt * j / p), hi = (u32)((u64)cnt * (j + 1) / p);
+    G1Xyzz30* dst = p == 1 ? buckets + gid : aux + slot;
+    if (hi == lo) { x30_store(dst, x30_identity()); continue; }
+    const u32* lst = sorted_all + d.off + base[gid];
+    const G1Aff30* tab = table + d.delta;
+    Fq30 X1, Y1, ZZ, ZZZ;
+    {
+      const u32 e = lst[lo];
+      const G1Aff30* q = tab + (e & 0x7fffffffu);
+      X1 = load30(q->x);
+      Y1 = load30(q->y);
+      if (e & 0x80000000u) Y1 = f30_sub<2>(zero, Y1);
+#pragma unroll
+      for (int i = 0; i < Fq30::NL; i++) { ZZ.v[i] = Fq30Params::ONE[i]; ZZZ.v[i] = Fq30Params::ONE[i]; }
+    }
+    u32 e_next = lo + 1 < hi ? lst[lo + 1] : 0;
+    bool deferred = false;
+    for (u32 k = lo + 1; k < hi; k++) {
+      const u32 e = e_next;
+      if (k + 1 < hi) e_next = lst[k + 1];
+      const G1Aff30* q = tab + (e & 0x7fffffffu);
+      const Fq30 x2 = load30(q->x);
+      Fq30 y2 = load30(q->y);
+      if (e & 0x80000000u) y2 = f30_sub<2>(zero, y2);
+      // accum30_kernel's group law (value bounds there) with its ten multiplications as four groups of interleaved chains -- {U2, S2},
+      // {PP, R^2}, {Q, PPP, ZZ3}, {Y3, ZZZ3}: fq30.cuh f30_mul_x2 ... -- so that two resident waves fill the SIMD
+      Fq30 U2, S2;
+      f30_mul_x2(U2, x2, ZZ, S2, y2, ZZZ);
+      const Fq30 P = f30_sub<8>(U2, X1);
+      if (__builtin_expect(f30_is_zero(P), 0)) { deferred = true; break; }
+      const Fq30 R = f30_sub<4>(S2, Y1);
+      Fq30 PP, RR, Q, PPP;
+      f30_sqr_x2(PP, P, RR, R);
+      f30_mul_x3(Q, X1, PP, PPP, P, PP, ZZ, ZZ, PP);
+      const Fq30 nY1 = f30_sub<4>(zero, Y1);
+      X1 = f30_sub2<3>(f30_sub<2>(RR, PPP), Q);
+      f30_mul2_mul(Y1, R, f30_sub<8>(Q, X1), nY1, PPP, ZZZ, ZZZ, PPP);
+    }
+    if (deferred) { pend[gid] = 1; atomicAdd(n_deferred, 1u); continue; }     // the fix-up recomputes the WHOLE bucket
+    store30(dst->c[0], X1); store30(dst->c[1], Y1); store30(dst->c[2], ZZ); store30(dst->c[3], ZZZ);
+  }
+}
+// the buckets that were accumulated in parts (perm's first nsplit): bucket = sum of its parts.  (A bucket marked for the fix-up has
+// parts nobody wrote; what is formed of them here is overwritten by the fix-up, which runs after this.)
+__global__ __launch_bounds__(128) void merge_parts_kernel(const VTab* __restrict__ vt, const u32* __restrict__ perm, const G1Xyzz30* __restrict__ aux,
+                                                          G1Xyzz30* __restrict__ buckets, const u32* __restrict__ largest, u32 skew_limit) {
+  if (*largest > skew_limit) return;
+  const u32 n = vt->nsplit, T = vt->T, Ts = vt->Ts;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u32 ci = vclass_of(vt->pos, i);
+    const u32 p = vparts(SIZE_BINS - 1 - ci, T, Ts);
+    const G1Xyzz30* part = aux + vt->voff[ci] + (u64)(i - vt->pos[ci]) * p;
+    X30 acc = x30_load(part);
+    for (u32 j = 1; j < p; j++) { const X30 b = x30_load(part + j); x30_add_ilp_inl(acc, b); }
+    x30_store(buckets + perm[i], acc);
+  }
 }
 
 // buckets that met an equal-x pair (pend != 0): recomputed from their whole list with the complete group law in the

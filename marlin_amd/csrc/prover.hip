@@ -1992,6 +1992,23 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   const bool fuse_g = off_g == 1;            // see below
   const uint64_t wb_len = mask_len - 1, swb_len = g1_len - 1, wg_len = K - 1, swg_len = g2_len - 1;
   const uint64_t mb_len = std::max(wb_len, off_b + swb_len), mg_len = std::max(wg_len, off_g + swg_len);
+  // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b); its witness and the shifted
+  // one are multiplied on host threads while the device runs the batch -- submitted before EITHER form of the batch below (through
+  // round 6's first half the sliced form ran its batch first and then waited ~0.3 ms for these two with the GPU idle)
+  std::vector<HFr> r;
+  host_axpy(r, HFr::one(), rd_g1.rand.blind);
+  {
+    std::vector<HFr> r_outer; host_axpy(r_outer, c_za_lc, rd_za.rand.blind); host_axpy(r_outer, c_w_lc, rd_w.rand.blind);
+    host_axpy(r, xi_pow(2), r_outer);
+  }
+  host_axpy(r, xi_pow(4), rd_zb.rand.blind);
+  const bool r_nonzero = !host_is_zero(r);
+  const std::vector<HFr> rw = r_nonzero ? host_div_linear(r, beta) : std::vector<HFr>();
+  std::vector<HFr> srw; host_axpy(srw, xi_pow(1), host_div_linear(rd_g1.shifted.blind, beta));
+  const HG1Affine* gp_open = pk.gamma_g;
+  std::future<HG1> f_rw, f_srw = host_pool().submit([gp_open, &srw] { return small_msm(gp_open, srw); });
+  if (r_nonzero) f_rw = host_pool().submit([gp_open, &rw] { return small_msm(gp_open, rw); });
+  WaitAll wait_open{&f_rw, &f_srw};       // `rw` and `srw` live in this frame: no return below may leave a worker reading them
   std::vector<HG1> om;                       // [0] witness at beta (+ shifted), [1] witness at gamma (+ shifted)
   if (sliced_open) {
     // Point-sharded openings.  The two merged witness vectors (index spaces [0, mb_len) and [0, mg_len) of the SRS) are cut
@@ -2102,22 +2119,6 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     PTRY(lincomb(c, S[6], g2_len - 1, {{S[3], g2_len - 1, xi_pow(1)}}));
   }
   }
-  // randomness: r = xi^0 rand(g_1) + xi^2 (c_za rand(z_a) + c_w rand(w)) + xi^4 rand(z_b); its witness and the shifted
-  // one are multiplied on host threads while the device runs the batch
-  std::vector<HFr> r;
-  host_axpy(r, HFr::one(), rd_g1.rand.blind);
-  {
-    std::vector<HFr> r_outer; host_axpy(r_outer, c_za_lc, rd_za.rand.blind); host_axpy(r_outer, c_w_lc, rd_w.rand.blind);
-    host_axpy(r, xi_pow(2), r_outer);
-  }
-  host_axpy(r, xi_pow(4), rd_zb.rand.blind);
-  const bool r_nonzero = !host_is_zero(r);
-  const std::vector<HFr> rw = r_nonzero ? host_div_linear(r, beta) : std::vector<HFr>();
-  std::vector<HFr> srw; host_axpy(srw, xi_pow(1), host_div_linear(rd_g1.shifted.blind, beta));
-  const HG1Affine* gp_open = pk.gamma_g;
-  std::future<HG1> f_rw, f_srw = host_pool().submit([gp_open, &srw] { return small_msm(gp_open, srw); });
-  if (r_nonzero) f_rw = host_pool().submit([gp_open, &rw] { return small_msm(gp_open, rw); });
-  WaitAll wait_open{&f_rw, &f_srw};       // `rw` and `srw` live in this frame: no return below may leave a worker reading them
   // The reference multiplies witness and shifted witness separately (kzg10::open on powers and on shifted_powers) and
   // adds the two commitments (marlin_pc open: w = w + shifted_w).  shifted_powers(d) is the same SRS array from index
   // max_degree - d, so the sum is ONE multi-scalar multiplication with the shifted witness's coefficients added at

@@ -226,12 +226,13 @@ sys.stdout.write(pk.vk_bytes().hex() + " " + GM.prove(pk, inst, wit, bytes(range
 '''
 
 
-@pytest.mark.parametrize("env,pc", [({"MH_FB": "0"}, "marlin"), ({"MH_FB": "0"}, "sonic"), ({"MH_NTT": "32"}, "marlin")],
+@pytest.mark.parametrize("env,pc", [({"MH_FB": "0"}, "marlin"), ({"MH_FB": "0"}, "sonic"), ({"MH_NTT": "32"}, "marlin"), ({"MH_ACC_PARTS": "0"}, "marlin")],
                          ids=lambda v: v if isinstance(v, str) else ",".join("%s=%s" % kv for kv in v.items()))
 def test_alternative_paths_give_the_same_bytes(gpu, env, pc):
-    """The two cross-check paths the library keeps behind switches -- variable-base MSM for every commitment (what serves a key
-    whose window table does not fit) and the 32-bit-limb NTT kernel -- produce the same index commitments and the same proof, byte
-    for byte, as the default path (fixed-base MSM, 30-bit NTT with Shoup twiddle products).  (2^13 constraints: the bucket sets
+    """The cross-check paths the library keeps behind switches -- variable-base MSM for every commitment (what serves a key
+    whose window table does not fit), the 32-bit-limb NTT kernel and the one-thread-per-bucket accumulate kernel of rounds 1-5
+    (MH_ACC_PARTS=0) -- produce the same index commitments and the same proof, byte
+    for byte, as the default path (fixed-base MSM over virtual slots, 30-bit NTT with Shoup twiddle products).  (2^13 constraints: the bucket sets
     have empty buckets.)  The tuning switches of rounds 3-4 (two-stream pipeline, quad-lane reduction, resident-wave override,
     unshared sorts, ...) are gone with the paths they selected."""
     import subprocess, sys

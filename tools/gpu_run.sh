@@ -89,6 +89,15 @@ for R in "$@"; do
       rm -rf $O/trace_sim58; head -70 $O/sim_5_8_last_prove_kernels.txt ;;
     one=*)          # one=<pytest node id or -k expression file::test>: a single test, verbose
       ( timeout 900 python -m pytest "${R#one=}" -m gpu -x -q -p no:cacheprovider > $O/pytest_one.log 2>&1; echo "pytest rc=$?" >> $O/pytest_one.log ); tail -60 $O/pytest_one.log ;;
+    hosttrace)      # HIP API + kernel trace of the timed proves at 2^20 and of one simulated rank of 8: where the HOST spends its time
+      for cfg in "2p20:" "sim58:--simulate-rank 5/8"; do
+        name=${cfg%%:*}; extra=${cfg#*:}
+        ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/ht_$name -o t -- python $OLDPWD/bench.py --steps 3 --warmup 1 \
+            --no-cpu-baseline --no-seam-route --no-verify $extra > $O/ht_$name.log 2>&1 )
+        A=$(find $O/ht_$name -name "*hip_api_trace.csv" | head -1); T=$(find $O/ht_$name -name "*kernel_trace.csv" | head -1)
+        [ -n "$A" ] && [ -n "$T" ] && python tools/host_gaps.py $A $T 4 12 > $O/host_gaps_$name.txt 2>&1
+        rm -rf $O/ht_$name; tail -45 $O/host_gaps_$name.txt
+      done ;;
     msmtests)       # the MSM / check / golden-proof tests (after a change to the fixed-base pipeline), invariants on
       ( MH_CHECK=2 timeout 1500 python -m pytest tests/test_gpu_msm.py tests/test_gpu_check.py tests/test_gpu_dist_blocks.py tests/test_gpu_reentrancy.py -m gpu -q -x --durations=8 -p no:cacheprovider > $O/pytest_msm.log 2>&1; echo "pytest rc=$?" >> $O/pytest_msm.log
         MH_CHECK=1 timeout 1500 python -m pytest tests/test_gpu_marlin.py tests/test_gpu_parity_pins.py -m gpu -q -x -k "golden or sharded or zero_matrix or sonic_proof or full_size" --durations=8 -p no:cacheprovider >> $O/pytest_msm.log 2>&1; echo "pytest rc=$?" >> $O/pytest_msm.log ); grep -E "passed|failed|rc=|Error|error|assert" $O/pytest_msm.log | tail -30 ;;
@@ -97,6 +106,7 @@ for R in "$@"; do
           --no-cpu-baseline --no-seam-route --no-verify > $O/trace_2p20.log 2>&1 )
       T=$(find $O/trace_2p20 -name "*kernel_trace.csv" | head -1)
       [ -n "$T" ] && python tools/prove_kernels.py $T > $O/last_prove_kernels_2p20.txt 2>&1 && python tools/gap_analysis.py $T 4 > $O/gaps_2p20.txt 2>&1
+      [ -n "$T" ] && python tools/prove_timeline.py $T 4 > $O/timeline_2p20.txt 2>&1
       rm -rf $O/trace_2p20; head -40 $O/last_prove_kernels_2p20.txt; head -8 $O/gaps_2p20.txt ;;
     sweep=*)        # sweep=VAR:v1,v2,...: the default bench at 2^20 under each value of one environment variable (same box, back to back, twice)
       IFS=: read -r VAR VALS <<< "${R#sweep=}"

@@ -25,7 +25,9 @@ with tempfile.TemporaryDirectory() as td:
                    check=True, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
 # rsum_kernel: the bucket reduction's row / column sums (msm_fb.cuh); its loop body is one GENERAL addition (XYZZ += XYZZ)
-for kern in ("accum30_kernel", "accum_kernel", "rsum_kernel"):
+# accum30v_kernel: the accumulate kernel over virtual slots (round 6, the default; interleaved multiplication chains); accum30_kernel: the
+# one-thread-per-bucket kernel of rounds 1-5 (MH_ACC_PARTS=0)
+for kern in ("accum30v_kernel", "accum30_kernel", "accum_kernel", "rsum_kernel"):
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN\d+msm(fb)?\d+%s\w*:" % kern, l)]
     if len(starts) > 1:
         print("%s: %d instantiations, the first is shown" % (kern, len(starts)))
@@ -55,7 +57,7 @@ for kern in ("accum30_kernel", "accum_kernel", "rsum_kernel"):
         print("    %-22s %5d" % (k, v))
     half = sum(v for k, v in c.items() if k.startswith("v_") and k.split("_e")[0] in HALF)
     mad = c["v_mad_u64_u32"]
-    mixes[{"accum30_kernel": "fixed-base", "accum_kernel": "variable-base", "rsum_kernel": "reduce"}[kern]] = {"mad_u64": mad, "half_rate_other": half, "full_rate": valu - mad - half}
+    mixes[{"accum30v_kernel": "fixed-base", "accum30_kernel": "fixed-base, one thread per bucket", "accum_kernel": "variable-base", "rsum_kernel": "reduce"}[kern]] = {"mad_u64": mad, "half_rate_other": half, "full_rate": valu - mad - half}
     print("  classes: v_mad_u64_u32 %d, other half-rate %d, full-rate %d" % (mad, half, valu - mad - half))
 if json_out:
     cur = json.load(open(json_out)) if os.path.exists(json_out) else {}
