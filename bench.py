@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # v_lshrrev_b64 / v_lshl_add_u64 / v_addc_co_u32 35-36.  (The guide's 2-cycle wave64 issue is the 63 T/s class.)
 VALU_CLASS_RATE_T = {"mad_u64": 33.0, "half_rate_other": 35.5, "full_rate": 63.1}
 # instruction mix of ONE bucket addition (XYZZ += affine table point: 8 M + 2 S, Y3 as two products under one reduction,
-# on 13 x 30-bit limbs) in the loop body of msmfb::accum30_kernel, counted in the ISA (tools/loop_isa_stats.py ->
+# on 13 x 30-bit limbs) in the loop body of msmfb::accum30v_kernel, counted in the ISA (tools/loop_isa_stats.py ->
 # profiles/r02b_accum_loop_isa.txt): 4214 VALU = 3055 v_mad_u64_u32 + 497 other half-rate (274 v_lshrrev_b64, 118
 # v_mul_lo_u32, 58 v_lshl_add_u64, 47 v_add3_u32) + 662 full-rate; the variable-base kernel (32-bit limbs): 7839 VALU
 # = 2880 mad + 2880 addc + 2079 others.
@@ -753,7 +753,7 @@ def main():
         mix, bound_adds = {"mad_u64": 0, "half_rate_other": 0, "full_rate": 0}, float("nan")
     else:
         bound_adds = valu_bound_adds_per_s(mix)
-    valu = {"bound": "valu-issue", "kernel": "msmfb::accum30_kernel" if tab_w else "msm::accum_kernel",
+    valu = {"bound": "valu-issue", "kernel": "msmfb::accum30v_kernel" if tab_w else "msm::accum_kernel",
             "achieved": round(madds_per_s / 1e9, 3), "peak": round(bound_adds / 1e9, 3) if bound_adds == bound_adds else None, "unit": "G bucket additions/s",
             "frac": round(madds_per_s / bound_adds, 4) if bound_adds == bound_adds else None, "windows": W_windows, "window_bits": tab_c or 16,
             "instr_mix_source": "profiles/accum_isa_mix.json [%s]" % _Lc.CURVE if mixes else "built-in constants",

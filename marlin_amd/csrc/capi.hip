@@ -337,8 +337,11 @@ static int msm_set_attrs(Context& c) {
   int lds = 32768 * 4;
   MH_HIP(hipFuncSetAttribute((const void*)msm::hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   MH_HIP(hipFuncSetAttribute((const void*)msm::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#define MH_PSPLIT_WIDTHS(X) X(14) X(15) X(16) X(17) X(18) X(19) X(20)      /* the widths mh_bases_precompute picks for 2^14 ... 2^22 points */
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::psplit_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::psplit_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+#define MH_PSPLIT_ATTR(C) MH_HIP(hipFuncSetAttribute((const void*)msmfb::psplit_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  MH_PSPLIT_WIDTHS(MH_PSPLIT_ATTR)
+#undef MH_PSPLIT_ATTR
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(msmfb::PLANE_THREADS * sizeof(msmfb::G1Xyzz30))));
@@ -456,7 +459,7 @@ struct FbRun {
   std::vector<u32> bpt;                            // split blocks per hist / scatter tile, per partition
   msmfb::RsPlan rs; std::vector<u64> coef;        // bucket reduction: matrix shape, chunking, planes; the host's coefficient of each plane
   std::vector<msmfb::FbWin> desc; std::vector<msmfb::FbBlk> blk;
-  bool vmode = false; u32 vT0 = 0, vTs0 = 0, vcap = 0;       // thin launch: buckets accumulated in parts over virtual slots (msm_fb.cuh: VTab)
+  bool vmode = false, vcut = false; u32 vT0 = 0, vTs0 = 0, vcap = 0;       // thin launch: buckets accumulated in parts over virtual slots (msm_fb.cuh: VTab)
   bool skewed = false;
   u32 skew_limit = 0xffffffffu, skew_floor = 4096;   // a batch is skewed when its largest bucket exceeds max(skew_floor, 32 x the average)
   FbRun(Context& c_, const BaseSet& bs_, Context::FbWs& ws_) : c(c_), bs(bs_), ws(ws_) {}
@@ -566,23 +569,31 @@ struct FbRun {
     MH_TRY(ws.win.ensure((size_t)nj * rs.nplanes * sizeof(G1Xyzz)));
     MH_TRY(ws.sums.ensure(64 + F::SIZE_BINS * 4));
     MH_TRY(ws.perm.ensure(WB * 4));
-    // The accumulate kernel runs over virtual slots, buckets above Ts entries in parts of T (msm_fb.cuh: VTab): T = half, Ts = two
-    // thirds of the entries a lane gets when the launch's entries are spread evenly over the 2 x 64 lanes of every SIMD, for
-    // uniformly distributed digits (a rank of 8 at 2^20: 7.31-7.37 ms of accumulation per proof at 50 / 66 % and at 33 / 33 %,
-    // 7.5-8.1 at 25 / 50 % and at 50 / 100 %, 8.0 with the hardware's dispatch: profiles/r06u_*); the device doubles both until the
-    // parts fit the buffer.  MH_ACC_PARTS=0: the one-thread-per-bucket kernel of rounds 1-5 (cross-check).
+    // The accumulate kernel runs over virtual slots (msm_fb.cuh: VTab) -- persistent waves instead of the hardware's dispatch of
+    // blocks -- when the launch fills the chip (more than 6 waves of buckets per SIMD) or belongs to a bucket-range shard; a shard
+    // also has its buckets above Ts entries accumulated in parts of T: T = half, Ts = two thirds of the entries a lane gets when the
+    // launch's entries are spread evenly over the 2 x 64 lanes of every SIMD, for uniformly distributed digits (a rank of 8 at
+    // 2^20: 7.31-7.37 ms of accumulation per proof at 50 / 66 % and at 33 / 33 %, 7.5-8.1 at 25 / 50 % and at 50 / 100 %, 8.0 with the
+    // hardware's dispatch: profiles/r06u_*), Ts at least 1.25 x the average bucket; the device doubles both until the parts fit
+    // the buffer.  Not cut on one GPU: merging the parts costs 7-8 % of the launch at 2^16, as much as the cut buys there, and at
+    // 2^20 nothing is above Ts; and the thin launches of a small proof on one GPU (2^16: one round of waves) keep the hardware's
+    // dispatch, which is 4 % faster there (profiles/r06z_*).  MH_ACC_PARTS=0: the one-thread-per-bucket kernel everywhere (cross-check).
     {
       static const bool parts_env = [] { const char* e = getenv("MH_ACC_PARTS"); return !e || atoi(e) != 0; }();
-      vmode = parts_env;
+      const u64 active = (u64)nj * nbown;
+      const u64 per_simd = (active / 64 + (u64)c.num_simds - 1) / (u64)c.num_simds;
+      vmode = parts_env && (partial || per_simd > 6);
+      vcut = vmode && partial;
       if (vmode) {
         double ent_own = 0;
         for (int k = 0; k < nj; k++) ent_own += (double)ns[k] * W * (double)nbown / (double)nbt;
         const double per_lane = ent_own / (128.0 * (double)c.num_simds);
+        const double avg = ent_own / (double)std::max<u64>(active, 1);      // expected entries per owned bucket
         vT0 = (u32)std::max(8.0, per_lane * 0.50);
-        vTs0 = (u32)std::max((double)vT0, per_lane * 0.66);
+        vTs0 = vcut ? (u32)std::max(std::max((double)vT0, per_lane * 0.66), 1.25 * avg) : 0x7fffffffu;
         vcap = (u32)(4 * 128 * c.num_simds);           // parts of cut buckets <= entries (1 / T + 1 / Ts) = 3.5 per lane for the expected entries
         MH_TRY(ws.vtab.ensure(sizeof(F::VTab)));
-        MH_TRY(ws.aux.ensure((size_t)vcap * sizeof(F::G1Xyzz30)));
+        if (vcut) MH_TRY(ws.aux.ensure((size_t)vcap * sizeof(F::G1Xyzz30)));
       }
     }
     desc.assign(WT, msmfb::FbWin{});
@@ -636,14 +647,18 @@ struct FbRun {
     }
     u32* d_max = (u32*)ws.sums.ptr;                    // [0] largest bucket, [1] buckets with deferred entries
     MH_HIP(hipMemsetAsync(d_max, 0, 8, s));
-    // the usual width: recoding unrolled over compile-time windows (msm::for_each_digit_c; the generic kernel -- its scalar's words
-    // indexed at run time, i.e. served from scratch -- costs 0.6 ms more per proof on a rank of 8, profiles/r06m_*)
-    if (max_blk && bs.tab_c == 20)
-      hipLaunchKernelGGL(F::psplit_kernel<20>, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, key, val, lst, W, win, is_mont,
-                         nparts, pshift, (u32)bs.n, S, own);
-    else if (max_blk)
-      hipLaunchKernelGGL(F::psplit_kernel<0>, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, key, val, lst, W, win, is_mont,
-                         nparts, pshift, (u32)bs.n, S, own);
+    // the usual widths: recoding unrolled over compile-time windows (msm::for_each_digit_c; the generic kernel -- its scalar's words
+    // indexed at run time, i.e. served from scratch -- costs 0.6 ms more per proof on a rank of 8 at 2^20, profiles/r06m_*)
+    if (max_blk) {
+      switch (bs.tab_c) {
+#define MH_PSPLIT_CASE(C) case C: hipLaunchKernelGGL(F::psplit_kernel<C>, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, key, val, lst, W, win, \
+                                                     is_mont, nparts, pshift, (u32)bs.n, S, own); break;
+        MH_PSPLIT_WIDTHS(MH_PSPLIT_CASE)
+#undef MH_PSPLIT_CASE
+        default: hipLaunchKernelGGL(F::psplit_kernel<0>, dim3(max_blk, nj), dim3(F::SORT_THREADS), F::split_lds_bytes(W), s, jobs, key, val, lst, W, win, is_mont,
+                                    nparts, pshift, (u32)bs.n, S, own);
+      }
+    }
     msmfb::FbWin* fbw = (msmfb::FbWin*)ws.desc.ptr;
     const F::FbBlk* dblk = (const F::FbBlk*)ws.blk.ptr;
     if (grid_tiles)
@@ -704,6 +719,7 @@ struct FbRun {
                            (const u32*)ws.sorted.ptr, (const u32*)ws.base.ptr, (const u32*)ws.tot.ptr, (const u32*)ws.perm.ptr,
                            (F::G1Xyzz30*)ws.buckets.ptr, (F::G1Xyzz30*)ws.aux.ptr, (u32*)ws.pend.ptr, d_max + 1, nb, (F::VTab*)ws.vtab.ptr,
                            (const u32*)d_max, skew_limit);
+        if (vcut)
         hipLaunchKernelGGL(F::merge_parts_kernel, dim3((unsigned)std::min<u64>((OW + 127) / 128, 2048)), dim3(128), 0, s, (const F::VTab*)ws.vtab.ptr,
                            (const u32*)ws.perm.ptr, (const F::G1Xyzz30*)ws.aux.ptr, (F::G1Xyzz30*)ws.buckets.ptr, (const u32*)d_max, skew_limit);
       } else if (acc_waves == 2)

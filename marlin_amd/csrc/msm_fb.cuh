@@ -494,7 +494,7 @@ __global__ __launch_bounds__(1024) void size_vscan_kernel(u32* __restrict__ ghis
     if (i == 0) sT = b[0] <= vcap ? 1 : 0;
     __syncthreads();
     if (sT) break;
-    T = T * 2; Ts = Ts * 2;
+    T = T * 2; Ts = Ts < 0x40000000u ? Ts * 2 : Ts;
     __syncthreads();
   }
   a[i] = cnt; b[i] = cnt * vparts(s, T, Ts);

@@ -139,6 +139,14 @@ PY
       ;;
     absim=*)        # absim=<lib.so>: the same alternation for one simulated rank of 8 at 2^20
       bash tools/ab.sh "${R#absim=}" --no-seam-route --simulate-rank 5/8 > $O/ab_sim_5_8.txt 2>&1; cut -c1-330 $O/ab_sim_5_8.txt ;;
+    abcfg=*)        # abcfg=<lib.so>: the in-tree build and another build of the same ABI on the other BASELINE configurations, back to back
+      OTHER=${R#abcfg=}
+      for cfg in "--log-constraints 16 --pc sonic --steps 20" "--log-constraints 18" "--log-constraints 22 --steps 5 --warmup 2" "--pc sonic"; do
+        for v in new old; do
+          ( if [ $v = old ]; then export MARLIN_AMD_LIB=$OTHER; fi
+            $B $cfg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); b=d['breakdown_ms_per_step']; print('$v', '$cfg', d['ms_per_step'], 'accum', b['msm_accum'], 'sort+reduce', b['msm_sort_and_reduce_stages'], 'golden', ((d.get('proof') or {}).get('oracle_golden') or {}).get('byte_identical'))" )
+        done
+      done | tee $O/ab_configs.txt ;;
     ab=*)
       bash tools/ab.sh "${R#ab=}" --no-seam-route > $O/ab.txt 2>&1; cut -c1-330 $O/ab.txt ;;
     *) echo "unknown recipe $R" ;;

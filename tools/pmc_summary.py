@@ -57,7 +57,7 @@ def last_n(fn, key, name, n):
     return sum(vals) / len(vals) if vals else None
 
 
-for name in ("accum30_kernel", "msm::accum_kernel"):
+for name in ("accum30", "msm::accum_kernel"):
     f = last_n("pmc_fetch.csv", "FETCH_SIZE", name, LAUNCHES)
     w = last_n("pmc_write.csv", "WRITE_SIZE", name, LAUNCHES)
     if f is not None and w is not None:

@@ -19,14 +19,14 @@ out = sys.argv[1]
 rows = []
 for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "accum30_kernel" in r["Kernel_Name"] or "msm::accum_kernel" in r["Kernel_Name"]:
+        if "accum30" in r["Kernel_Name"] or "msm::accum_kernel" in r["Kernel_Name"]:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 rows.sort()
 d = [x[1] / 1e6 for x in rows]
 steps = 2
 per_prove = 4            # the 4 MSM groups of a prove (rounds 1-3, openings)
 timed = d[-per_prove * steps:]
-json.dump({"kernel": "bucket accumulation (msmfb::accum30_kernel)", "dispatch_ms_in_launch_order": [round(x, 3) for x in d],
+json.dump({"kernel": "bucket accumulation (msmfb::accum30v_kernel)", "dispatch_ms_in_launch_order": [round(x, 3) for x in d],
            "avg_ms_all_dispatches": round(sum(d) / max(1, len(d)), 3),
            "avg_ms_timed_region": round(sum(timed) / max(1, len(timed)), 3),
            "note": "timed region = the last 4 x %d dispatches (4 MSM groups per prove: rounds 1-3 and the openings); "
@@ -49,7 +49,7 @@ out, tag, lpp = sys.argv[1], sys.argv[2], int(sys.argv[3])
 sys.path.insert(0, os.getcwd())
 from marlin_amd import workload as W
 d = json.load(open(out + "/pmc_summary.json"))
-po = d.get("prove_only:accum30_kernel")
+po = d.get("prove_only:accum30")
 if po:
     pairs = sum(n for n, _ in W.msm_executed(1 << 20))
     try:
@@ -58,7 +58,7 @@ if po:
     except Exception:
         dev = []
     json.dump({"source": "profiles/%s_pmc_summary_marlin_prove_2p20.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, of "
-                         "`bench.py --steps 1 --warmup 0`; PROVE ONLY: the last %d dispatches of msmfb::accum30_kernel = the launches "
+                         "`bench.py --steps 1 --warmup 0`; PROVE ONLY: the last %d dispatches of msmfb::accum30v_kernel = the launches "
                          "of the one timed prove)" % (tag, lpp),
                "box": {"hostname": socket.gethostname(), "device": dev},
                "build": {"libmarlin_hip.so_sha256_16": hashlib.sha256(open("marlin_amd/libmarlin_hip.so", "rb").read()).hexdigest()[:16]},

@@ -3,7 +3,7 @@
 # SQ / GRBM counters of one kernel over ONE prove (default: the accumulate kernel; SQ_KERNEL=rsum_kernel: the
 # row / column sums of the bucket reduction): rocprofv3 --pmc in its own run (with
 # --kernel-trace only), per dispatch; the summary keeps the prove's own dispatches (the last 4 launches of
-# msmfb::accum30_kernel: commit rounds 1-3 and the openings) apart from Marlin::index's.
+# msmfb::accum30v_kernel: commit rounds 1-3 and the openings) apart from Marlin::index's.
 #   gpurun_out/prof_<tag>/sq_counters.json
 set -u
 TAG=${1:-r02}; shift || true
@@ -20,7 +20,7 @@ timeout 900 rocprofv3 --pmc $SQ_COUNTERS GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD1 > $OUT/pmc_sq.log 2>&1
 find $OUT/pmc_sq -name "*counter_collection.csv" -exec cp {} $OUT/pmc_sq.csv \;
 cd $REPO
-python3 - "$OUT" "${SQ_KERNEL:-accum30_kernel}" <<'PY'
+python3 - "$OUT" "${SQ_KERNEL:-accum30v_kernel}" <<'PY'
 import csv, json, sys, collections
 out, kname = sys.argv[1], sys.argv[2]
 rows = collections.defaultdict(dict)          # dispatch id -> counters
@@ -63,7 +63,7 @@ res = {"kernel": "msmfb::" + kname, "all_dispatches": summarise(acc), "prove_onl
        "per_dispatch": [dict(rows[d], dispatch=d, ms=dur.get(d)) for d in acc],
        "note": "counters summed over SEs/XCDs as rocprofv3 reports them; prove_only = the last 4 dispatches of the run "
                "(bench.py --steps 1 --warmup 0: index first, then one prove)"}
-json.dump(res, open(out + ("/sq_counters.json" if kname == "accum30_kernel" else "/sq_counters_%s.json" % kname), "w"), indent=1)
+json.dump(res, open(out + ("/sq_counters.json" if kname.startswith("accum30") else "/sq_counters_%s.json" % kname), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("all_dispatches", "prove_only_last4")}, indent=1))
 PY
 rm -rf $OUT/pmc_sq
