@@ -28,11 +28,11 @@ def test_bn254_marlin_and_sonic_provers():
     """The whole prover on BN254 with both PC schemes: byte-identical proofs vs the oracle (fresh runs), polynomial
     parity, general R1CS, proofs up to 2^16 verified by the oracle (the 2^20 proofs of BASELINE.json configs[4] are byte-pinned by
     test_bn254_whole_golden_proofs_of_the_cpu_oracle and recomputed by test_bn254_sonic_2p20_whole_proof_pinned)."""
-    # (the multi-rank cases are transport and sharding logic, which is curve-independent and runs in full on BLS12-381: three of
-    #  them -- replicated, sliced at 4 and at 8 ranks, both schemes -- are kept here; the bench.py launches are not repeated)
+    # (the multi-rank cases are transport and sharding logic, which is curve-independent and runs in full on BLS12-381: one of
+    #  them -- 4 ranks on slices, buckets cut into parts -- is kept here; the bench.py launches are not repeated)
     out = _run(["tests/test_gpu_marlin.py"],
                extra=["-k", "not golden and not two_ranks and not bench_gpus and not bench_line and not (full_size and 20) and not (sharded_prove_ranks and not "
-                            "(2-12-marlin-0 or 8-14-sonic-1 or 4-16-marlin-1))"])
+                            "4-16-marlin-1)"])
     assert " passed" in out
 
 

@@ -158,12 +158,13 @@ def test_a_golden_proof_under_level_2(gpu, checked):
 
 
 def test_soak_tool_short_run(gpu, tmp_path):
-    """tools/soak_sliced.py -- the 8-process scenario of the one unexplained failure -- for a few iterations at level 2 (<= 60 s)"""
+    """tools/soak_sliced.py -- the 8-process scenario of the one unexplained failure, and the same MSMs sharded by bucket range (the
+    accumulate kernel's cut buckets) -- for a few iterations at level 2 (<= 60 s)"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_sliced.py"), "--world", "8", "--iters", "12", "--check", "2",
-                        "--ntt-logs", "6", "13", "--out", str(tmp_path), "--port", "29877", "--timeout", "300"],
+                        "--sharded-c", "16", "--ntt-logs", "6", "13", "--out", str(tmp_path), "--port", "29877", "--timeout", "300"],
                        capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("SOAK ")][-1]
     import json
     tot = json.loads(line[5:])
-    assert tot["mismatches"] == 0 and tot["errors"] == 0 and tot["violations"] == 0 and tot["sliced_msms"] == 8 * 12 * 6 and tot["batches_checked"] >= 8 * 12 * 3, line
+    assert tot["mismatches"] == 0 and tot["errors"] == 0 and tot["violations"] == 0 and tot["sliced_msms"] == 8 * 12 * 6 and tot["bucket_range_sharded_msms"] == 8 * 12 * 3 and tot["batches_checked"] >= 8 * 12 * 4, line

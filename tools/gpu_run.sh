@@ -125,7 +125,7 @@ for R in "$@"; do
       IFS=: read -r IT DG SER <<< "${R#soak=}"
       S=$O/soak_${IT}_diag${DG:-0}${SER:+_serialized}; mkdir -p $S
       ( export MH_DIAG=${DG:-0}; [ -n "${SER:-}" ] && export AMD_SERIALIZE_KERNEL=3
-        timeout 3000 python tools/soak_sliced.py --world 8 --iters $IT --check 2 --out $S --timeout 2900 > $S/soak.log 2>&1; echo "soak rc=$?" >> $S/soak.log )
+        timeout 3000 python tools/soak_sliced.py --world 8 --iters $IT --check 2 --sharded-c ${SOAK_SHARDED_C:-16} --out $S --timeout 2900 > $S/soak.log 2>&1; echo "soak rc=$?" >> $S/soak.log )
       grep -E "^SOAK|soak rc|soak:" $S/soak.log | tail -12 ;;
     fresh=*)        # fresh=<launches>: the soak's scenario from a cold start, again and again (a process's FIRST batch runs on fresh allocations)
       NL=${R#fresh=}; S=$O/fresh_$NL; mkdir -p $S; : > $S/fresh.log

@@ -14,6 +14,10 @@ On the first mismatch every rank writes what it has to <out>/soak_rank<r>.json: 
 points, the reference's, whether the unsliced result reproduces, and the stage-by-stage text of the library's last checked batch
 (mh_check_report).  A violated invariant makes the call itself fail with MH_ECHECK naming the stage; that is recorded the same way.
 
+Round 6's accumulate kernel (virtual slots; in a bucket-range shard the long buckets are accumulated in parts and merged) gets its
+own leg: --sharded-c C builds a second window table of width C over the same points and, per iteration, runs the three MSMs sharded by
+BUCKET RANGE over the ranks (mh_msm_batch_sharded_dev: every rank's partial sums all-gathered and added) against the unsliced MSM.
+
   python tools/soak_sliced.py --world 8 --iters 900 --check 2 --out gpurun_out/soak     # ~5,400 sliced MSMs per run
   MH_DIAG=1 ... / MH_DIAG=2 ... / AMD_SERIALIZE_KERNEL=3 ...                            # the bisection configurations
 """
@@ -82,6 +86,11 @@ def worker(args):
     B = M.Bases.srs_powers(tau, n + 64)
     B.precompute(args.c)
     allb = B.download()
+    B2 = None
+    if args.sharded_c:
+        B2 = M.Bases(allb)
+        B2.precompute(args.sharded_c)
+    out["bucket_range_sharded_msms"] = 0
     n2 = n - 5
     len1, len2 = len(range(rank, n, world)), len(range(rank, n2, world))
     # the bases of this rank's three slices as contiguous sets WITHOUT a table: the variable-base path serves them
@@ -100,12 +109,19 @@ def worker(args):
             got = MD.msm_batch_sliced_dev(B, jobs, world)
             mine = MD.msm_batch_sliced_dev(B, jobs, world, combine=False)
             refs = [M.msm(refsets[0], l1), M.msm(refsets[1], l2), M.msm(refsets[2], l2)]
+            shd = M.msm_batch_sharded_dev([(B2, 0, d1, n), (B2, 37, d2, n2), (B2, 0, d2, n2)]) if B2 is not None else None
         except _lib.MarlinHipError as e:
             out["errors"].append({"iter": it, "error": str(e)})
             dump()
             break
         out["iters"] = it + 1
         out["sliced_msms"] += 6
+        if shd is not None:
+            out["bucket_range_sharded_msms"] += 3
+            bad_shd = [j for j in range(3) if aff(shd)[j] != aff(whole)[j]]
+            if bad_shd:
+                out["mismatches"].append({"iter": it, "bucket_range_sharded_differs_in_jobs": bad_shd, "sharded": hexpt(shd), "whole": hexpt(whole)})
+                dump()
         bad_sum = [j for j in range(3) if aff(got)[j] != aff(whole)[j]]
         bad_own = [j for j in range(3) if aff(mine)[j] != aff(refs)[j]]
         if bad_sum or bad_own:
@@ -139,6 +155,7 @@ def main():
     ap.add_argument("--check", type=int, default=2)
     ap.add_argument("--msm-log", type=int, default=15)
     ap.add_argument("--c", type=int, default=14)
+    ap.add_argument("--sharded-c", type=int, default=0, help="also run the MSMs sharded by bucket range over a second table of this window width (16: 16 partitions, cuts at 8 ranks)")
     ap.add_argument("--ntt-logs", type=int, nargs="*", default=[6, 7, 13, 20])
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "soak"))
     ap.add_argument("--port", type=int, default=29871)
@@ -163,14 +180,14 @@ def main():
         print("---- rank %d (exit %s)\n%s" % (r, p.returncode, so[-3000:]))
         rc = rc or (p.returncode or 0)
     # one summary line for the whole run
-    tot = {"world": args.world, "iters": 0, "sliced_msms": 0, "mismatches": 0, "errors": 0, "batches_checked": 0, "violations": 0}
+    tot = {"world": args.world, "iters": 0, "sliced_msms": 0, "bucket_range_sharded_msms": 0, "mismatches": 0, "errors": 0, "batches_checked": 0, "violations": 0}
     for r in range(args.world):
         try:
             d = json.load(open(os.path.join(args.out, "soak_rank%d.json" % r)))
         except Exception:
             rc = rc or 1
             continue
-        tot["iters"] = max(tot["iters"], d["iters"]); tot["sliced_msms"] += d["sliced_msms"]
+        tot["iters"] = max(tot["iters"], d["iters"]); tot["sliced_msms"] += d["sliced_msms"]; tot["bucket_range_sharded_msms"] += d.get("bucket_range_sharded_msms", 0)
         tot["mismatches"] += len(d["mismatches"]); tot["errors"] += len(d["errors"])
         tot["batches_checked"] += d["report"]["batches"]; tot["violations"] += d["report"]["violations"]
     tot["env"] = {k: os.environ.get(k) for k in ("MH_DIAG", "AMD_SERIALIZE_KERNEL")}
