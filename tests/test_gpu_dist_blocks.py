@@ -5,7 +5,9 @@ a gloo exchange:
   coefficients, the gathered M-layout blocks equal mh_ntt of the whole vector bit for bit; the inverse brings every rank's
   slice back (SURVEY.md 8e; src/ahp/prover.rs:351-366,532-535,655-688 are the transforms it distributes);
 * mh_msm_batch_sliced_dev -- the point-sharded MSM of cyclic coefficient slices against the ONE window table (table index
-  first + i * stride), partial points all-gathered and added: equals the MSM of the whole vector.
+  first + i * stride), partial points all-gathered and added: equals the MSM of the whole vector;
+* mh_msm_batch_sharded_dev -- the MSM sharded by bucket range (what every commitment of a multi-GPU proof is): long buckets
+  accumulated in parts, repeated pairs through the fix-up.
 """
 import os
 import subprocess
@@ -95,6 +97,23 @@ part = MD.msm_batch_sliced_dev(B, [(rank, e1, len(l1))], world, combine=False)
 parts = [None] * world
 dist.all_gather_object(parts, part[0])
 assert aff([MD.g1_sum(np.stack(parts))]) == aff(whole[:1])
+# ---- the same MSMs sharded by BUCKET RANGE (mh_msm_batch_sharded_dev; c = 16: 16 partitions for up to 8 ranks): the accumulate kernel
+# runs over virtual slots and cuts a rank's long buckets into parts (Ts = 20 entries here, the average bucket holds 16) ...
+allb = B.download()
+B2 = M.Bases(np.ascontiguousarray(allb))
+B2.precompute(16)
+shd = M.msm_batch_sharded_dev([(B2, 0, d1, n), (B2, 37, d2, n - 5), (B2, 0, d2, n - 5)])
+assert aff(shd) == aff(whole), "rank %%d: bucket-range-sharded MSM differs in jobs %%s" %% (rank, [j for j in range(3) if aff(shd)[j] != aff(whole)[j]])
+# ... and with repeated (base, scalar) pairs -- bases i and i + 4096 the same point with equal scalars meet in the same buckets: an
+# equal-x pair inside ONE PART marks the whole bucket for the fix-up, which recomputes it from its complete list
+pts = np.ascontiguousarray(allb[:n]).copy(); pts[4096:8192] = pts[:4096]
+sr = s1.copy(); sr[4096:8192] = sr[:4096]; sr[100:164] = sr[100]
+pts[100:164] = pts[100]
+Br = M.Bases(pts); Br.precompute(16)
+want_r = M.msm(M.Bases(pts), sr)                                # no table: the variable-base path
+dr = M.DeviceBuffer.from_numpy(sr)
+got_r = M.msm_batch_sharded_dev([(Br, 0, dr, n)])
+assert aff(got_r) == aff([want_r]), "rank %%d: bucket-range-sharded MSM with repeated pairs differs" %% rank
 print("rank %%d ok" %% rank)
 dist.barrier(); dist.destroy_process_group()
 '''
