@@ -81,9 +81,48 @@ struct HFp {
     return acc;
   }
   HFp pow_u64(uint64_t e) const { return pow(&e, 1); }
-  HFp inv() const {  // Fermat; 0 -> 0
+  HFp inv_fermat() const {  // 0 -> 0
     uint64_t e[N]; memcpy(e, P::MOD, sizeof(e)); e[0] -= 2;
     return pow(e, N);
+  }
+  // Inverse by the binary extended Euclidean algorithm on the stored integer (what ark-ff's `inverse` does; 0 -> 0): the Fermat
+  // power is ~580 multiplications -- 40 us for Fq on the prover's critical path at every commit round (one per batch_to_affine) and
+  // 13 us for each of Fr's ~10 per proof; this is ~1.4 x 381 shift / subtract steps.  The stored integer is a R, so the Euclidean
+  // inverse is a^-1 R^-1: two Montgomery multiplications by R^2 bring it to a^-1 R.
+  HFp inv() const {
+    if (is_zero()) return *this;
+    uint64_t u[N], w[N], b[N], c[N];
+    memcpy(u, v, sizeof(u)); memcpy(w, P::MOD, sizeof(w));
+    memset(b, 0, sizeof(b)); memset(c, 0, sizeof(c)); b[0] = 1;
+    auto is_one = [](const uint64_t* a) { uint64_t o = a[0] ^ 1; for (int i = 1; i < N; i++) o |= a[i]; return o == 0; };
+    // a >>= k and x = x / 2^k mod p in one pass each (0 < k < 64): x + m p is divisible by 2^k for m = -x p^-1 mod 2^k (P::INV = -p^-1 mod 2^64)
+    auto shift_pair = [](uint64_t* a, uint64_t* x, unsigned k) {
+      for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> k) | (a[i + 1] << (64 - k));
+      a[N - 1] >>= k;
+      const uint64_t m = (x[0] * P::INV) & ((1ull << k) - 1);
+      u128 t = (u128)m * P::MOD[0] + x[0];
+      uint64_t lo = (uint64_t)t, cy = (uint64_t)(t >> 64);
+      for (int i = 1; i < N; i++) {
+        t = (u128)m * P::MOD[i] + x[i] + cy;
+        const uint64_t nx = (uint64_t)t; cy = (uint64_t)(t >> 64);
+        x[i - 1] = (lo >> k) | (nx << (64 - k));
+        lo = nx;
+      }
+      x[N - 1] = (lo >> k) | (cy << (64 - k));
+    };
+    auto geq = [](const uint64_t* a, const uint64_t* d) { for (int i = N - 1; i >= 0; i--) { if (a[i] != d[i]) return a[i] > d[i]; } return true; };
+    auto sub = [](uint64_t* a, const uint64_t* d) { uint64_t bw = 0; for (int i = 0; i < N; i++) { u128 t = (u128)a[i] - d[i] - bw; a[i] = (uint64_t)t; bw = (uint64_t)(t >> 127); } return bw; };
+    auto sub_modp = [&](uint64_t* a, const uint64_t* d) {      // a = a - d mod p, both < p
+      if (sub(a, d)) { uint64_t cy = 0; for (int i = 0; i < N; i++) { u128 t = (u128)a[i] + P::MOD[i] + cy; a[i] = (uint64_t)t; cy = (uint64_t)(t >> 64); } }
+    };
+    while (!is_one(u) && !is_one(w)) {
+      while (!(u[0] & 1)) { const unsigned k = u[0] ? (unsigned)__builtin_ctzll(u[0]) : 63u; shift_pair(u, b, k); }
+      while (!(w[0] & 1)) { const unsigned k = w[0] ? (unsigned)__builtin_ctzll(w[0]) : 63u; shift_pair(w, c, k); }
+      if (geq(u, w)) { sub(u, w); sub_modp(b, c); } else { sub(w, u); sub_modp(c, b); }
+    }
+    HFp x, r2;
+    memcpy(x.v, is_one(u) ? b : c, sizeof(x.v)); memcpy(r2.v, P::R2, sizeof(r2.v));
+    return (x * r2) * r2;
   }
   // canonical integer (little-endian limbs) <-> Montgomery
   static HFp from_canonical(const uint64_t* c) { HFp a; memcpy(a.v, c, sizeof(a.v)); HFp r2; memcpy(r2.v, P::R2, sizeof(r2.v)); return a * r2; }
