@@ -781,7 +781,9 @@ struct FbRun {
     uint64_t* sums_h = (uint64_t*)ws.h_out.ptr;
     MH_HIP(hipMemcpyAsync(sums_h, ws.win.ptr, sums_n * 8, hipMemcpyDeviceToHost, s));
     MH_HIP(hipMemcpyAsync(sums_h + sums_n, ws.sums.ptr, 4, hipMemcpyDeviceToHost, s));
+    mh::host_tick("finish: before sync");
     MH_HIP(hipStreamSynchronize(s));
+    mh::host_tick("finish: synced (device done)");
     const u32 mx = *(const u32*)(sums_h + sums_n);
     skewed = mx > skew_limit;                      // the kernels returned at once: `out` is not a result
     if (skewed) return MH_OK;
@@ -810,6 +812,7 @@ struct FbRun {
     wait.add(fut);
     out[0] = combine(0);
     for (int k = 1; k < nj; k++) out[k] = pool ? fut[k].get() : combine(k);
+    mh::host_tick("finish: planes combined");
     return check_result(s, out);
   }
 

@@ -11,10 +11,26 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <chrono>
+#include <vector>
 #include <vector>
 #include "../../include/marlin_hip.h"
 
 namespace mh {
+// MH_TRACE=2: a host-side timeline WITHOUT synchronisation -- where the calling thread's time goes between the HIP calls of a proof
+// (the GPU is idle at every host round trip: a commit round's results, the Fiat-Shamir challenge, the next round's first launch).
+// host_tick(label) records a time stamp; host_ticks_flush() prints the differences on stderr.
+struct HostTicks { bool on = false; bool init = false; std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> t; };
+inline HostTicks& host_ticks() { static thread_local HostTicks h; if (!h.init) { const char* e = getenv("MH_TRACE"); h.on = e && atoi(e) == 2; h.init = true; } return h; }
+inline void host_tick(const char* label) { HostTicks& h = host_ticks(); if (h.on) h.t.emplace_back(label, std::chrono::steady_clock::now()); }
+inline void host_ticks_flush() {
+  HostTicks& h = host_ticks();
+  if (!h.on) return;
+  for (size_t i = 1; i < h.t.size(); i++)
+    fprintf(stderr, "[mh_host] %9.1f us  %s -> %s\n", std::chrono::duration<double, std::micro>(h.t[i].second - h.t[i - 1].second).count(), h.t[i - 1].first, h.t[i].first);
+  h.t.clear();
+}
+
 
 extern thread_local std::string g_err;
 

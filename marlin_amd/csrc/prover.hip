@@ -678,7 +678,9 @@ int marlin_commit(Context& c, ProverKey& pk, const std::vector<CommitReq>& reqs,
       if (reqs[i].hiding) fin[i] = fin[i].add(hid[i].get());
     }
     std::vector<HG1Affine> aff(fin.size());
+    mh::host_tick("commit: hiding parts added");
     hostff::batch_to_affine(fin.data(), fin.size(), aff.data());        // one inversion for the round's commitments
+    mh::host_tick("commit: to affine");
     for (size_t i = 0; i < reqs.size(); i++) { comms[i].comm = aff[i]; comms[i].has_shifted = false; }
     return MH_OK;
   }
@@ -1680,7 +1682,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     fs.initialize(init);                                  // lib.rs:161-163
   }
 
-  tr.mark("AHP::Prover::Init (z_A, z_B)");
+  tr.mark("AHP::Prover::Init (z_A, z_B)"); mh::host_tick("init issued");
   // ---------------- first round (prover.rs:309-409) -----------------------------------------------------------
   PTRY(ntt_device(c, pk.z.fr(), pk.xpoly.fr(), lgX, 1));              // x_poly = interpolate(formatted input)
   if (X <= 16) {                                                        // x_evals = domain_h.fft(x_poly): Horner per point
@@ -1712,7 +1714,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   const uint64_t mask_len = 3 * H;          // degree 3H + 2*zk_bound - 3
   PTRY(device_poly_rand(c, pk, zk, pk.mask.fr(), mask_len, S[0], (u32*)S[1]));
   if (g_job.poison == MH_OK) hipLaunchKernelGGL(rng::mask_fix_kernel, dim3(1), dim3(1), 0, c.stream, pk.mask.fr(), (u64)H, (u64)mask_len);
-  tr.mark("AHP::Prover::FirstRound (w, z_A, z_B, mask polys)");
+  tr.mark("AHP::Prover::FirstRound (w, z_A, z_B, mask polys)"); mh::host_tick("round 1 kernels issued");
   // Three of round 2's five forward 4H transforms need no challenge: z_a and z_b (prover.rs:467) and z = w v_X + x
   // (prover.rs:503-516, 534).  They are handed to the commitment's MSM batch as its side job (Context::side_job): issued on the
   // second stream behind the bucket accumulation, they run beside the bucket reduction -- one wave per SIMD, a third of the
@@ -1747,7 +1749,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     put_comm(b, c_w, pk.pc); put_comm(b, c_za, pk.pc); put_comm(b, c_zb, pk.pc); put_comm(b, c_mask, pk.pc);
     fs.absorb(b);                                                            // lib.rs:180
   }
-  tr.mark("Committing to first round polys");
+  tr.mark("Committing to first round polys"); mh::host_tick("round 1 committed + absorbed");
   // verifier_first_round (verifier.rs:44-79)
   auto v_h = [&](const HFr& x) { return x.pow_u64(H) - HFr::one(); };
   HFr alpha = fs.rand_fr();
@@ -1822,7 +1824,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   }
   PTRY(d2d(c, pk.g1.fr(), S[4] + 1, H - 1));
   const uint64_t g1_len = H - 1;
-  tr.mark("AHP::Prover::SecondRound");
+  tr.mark("AHP::Prover::SecondRound"); mh::host_tick("round 2 kernels issued");
   std::vector<fsh::Commitment> cm2; std::vector<PolyRand> rd2;
   CTRY(marlin_commit(c, pk, {{pk.t.fr(), H, false, 0, false}, {pk.g1.fr(), g1_len, true, H - 2, true},
                                {pk.h1.fr(), h1_len, false, 0, false}}, &zk, cm2, rd2));
@@ -1833,7 +1835,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     put_comm(b, c_t, pk.pc); put_comm(b, c_g1, pk.pc); put_comm(b, c_h1, pk.pc);
     fs.absorb(b);                                                               // lib.rs:201
   }
-  tr.mark("Committing to second round polys");
+  tr.mark("Committing to second round polys"); mh::host_tick("round 2 committed + absorbed");
   HFr beta = fs.rand_fr();
   while (v_h(beta).is_zero()) beta = fs.rand_fr();                              // verifier.rs:82-91
 
@@ -1903,7 +1905,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   }
   const uint64_t g2_len = K - 1;
   const uint64_t h2_len = K - 1;
-  tr.mark("AHP::Prover::ThirdRound");
+  tr.mark("AHP::Prover::ThirdRound"); mh::host_tick("round 3 kernels issued");
   std::vector<fsh::Commitment> cm3; std::vector<PolyRand> rd3;
   CTRY(marlin_commit(c, pk, {{pk.g2.fr(), g2_len, true, K - 2, false}, {pk.h2.fr(), h2_len, false, 0, false}}, &zk, cm3, rd3));
   fsh::Commitment &c_g2 = cm3[0], &c_h2 = cm3[1];
@@ -1912,7 +1914,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
     put_comm(b, c_g2, pk.pc); put_comm(b, c_h2, pk.pc);
     fs.absorb(b);                                                                // lib.rs:221
   }
-  tr.mark("Committing to third round polys");
+  tr.mark("Committing to third round polys"); mh::host_tick("round 3 committed + absorbed");
   HFr gamma = fs.rand_fr();                                                      // verifier.rs:94-100
 
   // ---------------- evaluations (lib.rs:272-287): g_1, g_2, t, z_b in label order ---------------------------
@@ -1958,7 +1960,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
                                        {pk.h2.fr(), h2_len, vK_gamma.neg()}}));
   }
 
-  tr.mark("Evaluating linear combinations over query set");
+  tr.mark("Evaluating linear combinations over query set"); mh::host_tick("evaluations + linear combinations issued");
   // ---------------- PC::open_combinations (lib.rs:292) -> batch_open -> MarlinKZG10::open ---------------------
   auto xi_pow = [&](unsigned e) { return xi.pow_u64(e); };
   auto sg = c.bases.find(pk.srs_g);
@@ -2181,7 +2183,7 @@ static int marlin_prove_impl(uint64_t pk_handle, const uint64_t* instance, const
   has_rv_gamma = false;
   }
 
-  tr.mark("PC::open_combinations");
+  tr.mark("PC::open_combinations"); mh::host_tick("openings done"); mh::host_ticks_flush();
   pk.last_polys = {{"w", {pk.w.fr(), w_len}}, {"z_a", {pk.za.fr(), za_len}}, {"z_b", {pk.zb.fr(), za_len}},
                    {"mask_poly", {pk.mask.fr(), mask_len}}, {"t", {pk.t.fr(), H}}, {"g_1", {pk.g1.fr(), g1_len}},
                    {"h_1", {pk.h1.fr(), h1_len}}, {"g_2", {pk.g2.fr(), g2_len}}, {"h_2", {pk.h2.fr(), h2_len}},
