@@ -29,10 +29,12 @@ def test_bn254_marlin_and_sonic_provers():
     parity, general R1CS, proofs up to 2^16 verified by the oracle (the 2^20 proofs of BASELINE.json configs[4] are byte-pinned by
     test_bn254_whole_golden_proofs_of_the_cpu_oracle and recomputed by test_bn254_sonic_2p20_whole_proof_pinned)."""
     # (the multi-rank cases are transport and sharding logic, which is curve-independent and runs in full on BLS12-381: one of
-    #  them -- 4 ranks on slices, buckets cut into parts -- is kept here; the bench.py launches are not repeated)
+    #  them -- 4 ranks on slices, buckets cut into parts -- is kept here; the bench.py launches, the switches' cross-check paths, the
+    #  caller's Fiat-Shamir / zk draws, the error paths and the skewed sharded MSMs -- host logic and curve-generic kernels -- are not repeated)
     out = _run(["tests/test_gpu_marlin.py"],
                extra=["-k", "not golden and not two_ranks and not bench_gpus and not bench_line and not (full_size and 20) and not (sharded_prove_ranks and not "
-                            "4-16-marlin-1)"])
+                            "4-16-marlin-1) and not alternative_paths and not skewed_digits and not exchange_callback and not callers_fiat_shamir "
+                            "and not zk_draws and not error_paths"])
     assert " passed" in out
 
 
