@@ -343,7 +343,6 @@ static int msm_set_attrs(Context& c) {
   MH_PSPLIT_WIDTHS(MH_PSPLIT_ATTR)
 #undef MH_PSPLIT_ATTR
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-  MH_HIP(hipFuncSetAttribute((const void*)msmfb::rsum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)msmfb::rsum_lds_bytes()));
   MH_HIP(hipFuncSetAttribute((const void*)msmfb::plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(msmfb::PLANE_THREADS * sizeof(msmfb::G1Xyzz30))));
   c.msm_attr_done = true;
@@ -557,8 +556,8 @@ struct FbRun {
       auto lanes = [&](u64 len) { u32 lg = 0; while (lg < 6 && (2ull << lg) * Lt <= len) lg++; return lg; };
       rs.lgJ = lanes(rs.C); rs.J = 1u << rs.lgJ; rs.Lr = rs.C >> rs.lgJ;
       rs.lgI = lanes(1ull << rs.lgM); rs.I = 1u << rs.lgI; rs.Lc = (rs.R_own + rs.I - 1) / rs.I;
-      rs.NTr = (u32)(((u64)rs.R_own * rs.J + 255) & ~255ull);            // whole blocks: a block is all rows or all columns of one job
-      rs.NT = rs.NTr + (u32)(((u64)rs.C * rs.I + 255) & ~255ull);
+      rs.NTr = (u32)(((u64)rs.R_own * rs.J + 63) & ~63ull);
+      rs.NT = rs.NTr + (u32)(((u64)rs.C * rs.I + 63) & ~63ull);
       rs.NS = rs.R_own + rs.C;
       rs.nplanes = rs.lgC + rs.lgM + 1;
       coef.assign(rs.nplanes, 0);
@@ -765,7 +764,7 @@ struct FbRun {
     F::G1Xyzz30* sums = (F::G1Xyzz30*)ws.seg.ptr;
     const u32* d_max = (const u32*)ws.sums.ptr;
     const u64 threads = (u64)nj * rs.NT;
-    hipLaunchKernelGGL(F::rsum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(F::RSUM_THREADS), F::rsum_lds_bytes(), s, (const F::G1Xyzz30*)ws.buckets.ptr, sums, nbt,
+    hipLaunchKernelGGL(F::rsum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const F::G1Xyzz30*)ws.buckets.ptr, sums, nbt,
                        (u32)nj, rs, own, d_max, skew_limit);
     hipLaunchKernelGGL(F::plane_kernel, dim3(rs.nplanes, (unsigned)nj), dim3(F::PLANE_THREADS), F::PLANE_THREADS * sizeof(F::G1Xyzz30), s,
                        (const F::G1Xyzz30*)sums, (G1Xyzz*)ws.win.ptr, rs, d_max, skew_limit);

@@ -749,39 +749,24 @@ __device__ __forceinline__ Fq30 f30_shfl_xor(const Fq30& a, u32 mask) {
 }
 
 // thread q of job w: q < NTr: lane g = q % J of row m = q / J adds columns g, g + J, ...; else lane g = (q - NTr) % I of column
-// c = (q - NTr) / I adds rows g, g + I, ...  NTr and NT are whole BLOCKS (multiples of 256), so a block is all rows or all columns of
-// one job: its trip count is uniform (threads past the last row / column carry the identity).  A group's lg G partial sums are
-// then added up by a TREE THROUGH LDS over the block's 256 / G groups at once (round 6; round 5: an xor butterfly inside the wave,
-// every lane executing every level -- half of the first level's additions, three quarters of the second's ... computed twice or
-// more): level l takes 256 >> (l + 1) threads, i.e. 2, 1, 1, ... waves instead of 4 each -- 6 wave-additions per block instead of
-// 20 at J = 32 --, the other waves wait at the barrier and cost the SIMD nothing.  ONE inlined copy of the group law serves both
-// phases (220 registers: two waves per SIMD; 53 KB of LDS per block).
-constexpr int RSUM_THREADS = 256;
-inline size_t rsum_lds_bytes() { return (size_t)RSUM_THREADS * sizeof(G1Xyzz30); }
-__global__ __launch_bounds__(RSUM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void rsum_kernel(
+// c = (q - NTr) / I adds rows g, g + I, ...  NTr and NT are whole waves, so a wave is all rows or all columns: its trip count
+// and its shuffles are uniform (threads past the last row / column carry the identity through them).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rsum_kernel(
     const G1Xyzz30* __restrict__ buckets, G1Xyzz30* __restrict__ sums, u32 nbt, u32 njobs, RsPlan p, Own own,
     const u32* __restrict__ largest, u32 skew_limit) {
-  extern __shared__ __attribute__((aligned(16))) u32 lds_rsum[];
-  G1Xyzz30* sh = reinterpret_cast<G1Xyzz30*>(lds_rsum);
-  const u32 tid = threadIdx.x;
-  const u32 t = blockIdx.x * blockDim.x + tid;
-  if (t >= njobs * p.NT) return;            // whole blocks only (NT is a multiple of 256)
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= njobs * p.NT) return;            // whole waves only (NT is a multiple of 64)
   if (*largest > skew_limit) return;        // a skewed batch left this path in the accumulate kernel: the buckets hold nothing
   const u32 w = t / p.NT, q = t % p.NT;
   const G1Xyzz30* B = buckets + (u64)w * nbt;
-  const bool row = q < p.NTr;               // block-uniform
+  const bool row = q < p.NTr;
   u32 grp, g, lgG, L, m, c, dm, dc;
   bool valid;
   if (row) { grp = q >> p.lgJ; g = q & (p.J - 1); lgG = p.lgJ; L = p.Lr; m = grp; c = g; dm = 0; dc = p.J; valid = grp < p.R_own; }
   else { const u32 q2 = q - p.NTr; grp = q2 >> p.lgI; g = q2 & (p.I - 1); lgG = p.lgI; L = p.Lc; m = g; c = grp; dm = p.I; dc = 0; valid = grp < p.C; }
-  const u32 grp0 = grp - (tid >> lgG);      // the block's first group (its first thread's q is a multiple of 256, and G divides 256)
-  G1Xyzz30* out = sums + (u64)w * p.NS + (row ? 0 : p.R_own);
-  const u32 ngrp_valid = row ? p.R_own : p.C;
   X30 acc = x30_identity();
   for (u32 step = 0; step < L + lgG; step++) {
     X30 b;
-    bool put = false;
-    u32 slot = 0, half = 0;
     if (step < L) {
       if (valid && m < p.R_own && c < p.C) {
         const u32 v = own.first + (m >> p.lgrpp) * own.stride;
@@ -790,25 +775,12 @@ __global__ __launch_bounds__(RSUM_THREADS) __attribute__((amdgpu_waves_per_eu(2,
       } else b = x30_identity();
       m += dm; c += dc;
     } else {
-      const u32 lvl = step - L;
-      if (lvl == 0) x30_store(sh + tid, acc);                       // every lane parks its partial sum
-      __syncthreads();                                              // (block-uniform: L and lg G are the block's)
-      half = 1u << (lgG - lvl - 1);                                 // additions per group at this level
-      if (tid < ((u32)RSUM_THREADS >> (lvl + 1))) {                 // thread -> (group, pair): 256 >> (l + 1) additions in the block
-        const u32 gi = tid >> (lgG - lvl - 1), j = tid & (half - 1);
-        slot = (gi << lgG) + j;
-        acc = x30_load(sh + slot);
-        b = x30_load(sh + slot + half);
-        put = true;
-      } else b = x30_identity();                                    // (a wave of these skips the addition as a whole)
+      const u32 mask = 1u << (step - L);
+      b.x = f30_shfl_xor(acc.x, mask); b.y = f30_shfl_xor(acc.y, mask); b.zz = f30_shfl_xor(acc.zz, mask); b.zzz = f30_shfl_xor(acc.zzz, mask);
     }
     x30_add_ilp_inl(acc, b);
-    if (put) {
-      if (half > 1) x30_store(sh + slot, acc);                      // read again after the next level's barrier
-      else if (grp0 + tid < ngrp_valid) x30_store(out + grp0 + tid, acc);      // last level: thread i holds the sum of the block's group i
-    }
   }
-  if (lgG == 0 && valid) x30_store(out + grp, acc);
+  if (valid && g == 0) x30_store(sums + (u64)w * p.NS + (row ? grp : p.R_own + grp), acc);
 }
 
 // tree sum of the block's first `nthreads` accumulators (a power of two) through LDS; the result is thread 0's `acc`

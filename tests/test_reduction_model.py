@@ -1,6 +1,6 @@
 """Integer model of the fixed-base bucket reduction of marlin_amd/csrc/msm_fb.cuh (rsum_kernel, plane_kernel) and of the plan /
 coefficients FbRun::prepare builds for it (capi.hip): with integers in place of bucket points, row / column sums by lane groups,
-(partial sums of a group added up by a tree over the block's groups, as through LDS), bit planes of the row and column indices and the host's coefficients must reproduce sum_b (b + 1) S_b over the OWNED buckets --
+bit planes of the row and column indices and the host's coefficients must reproduce sum_b (b + 1) S_b over the OWNED buckets --
 every window width, one GPU and bucket-range shards of 2 / 3 / 4 / 8 ranks, thin and full launches.  This is a model of the index
 arithmetic (the GPU tests check the kernels themselves against the oracle); it mirrors the kernels statement by statement."""
 import random
@@ -44,8 +44,8 @@ def plan(c, first, stride, nj, num_simds):
         return lg
     lgJ = lanes(C); J = 1 << lgJ; Lr = C >> lgJ
     lgI = lanes(1 << lgM); I = 1 << lgI; Lc = (R + I - 1) // I
-    NTr = (R * J + 255) & ~255
-    NT = NTr + ((C * I + 255) & ~255)
+    NTr = (R * J + 63) & ~63
+    NT = NTr + ((C * I + 63) & ~63)
     npl = lgC + lgM + 1
     coef = [0] * npl
     for p in range(lgC):
@@ -60,11 +60,11 @@ def plan(c, first, stride, nj, num_simds):
 def reduce_model(P, S):
     C, R, first, stride, lgrpp, lgC = P["C"], P["R"], P["first"], P["stride"], P["lgrpp"], P["lgC"]
     sums = [0] * (R + C)
-    for blk in range(P["NT"] // 256):                     # rsum_kernel, one block of 256 threads: all rows or all columns
-        acc = [0] * 256
+    for wave in range(P["NT"] // 64):
+        acc = [0] * 64
         lane = []
-        for tid in range(256):
-            q = blk * 256 + tid
+        for l in range(64):
+            q = wave * 64 + l
             if q < P["NTr"]:
                 grp, g, lgG, L = q >> P["lgJ"], q & (P["J"] - 1), P["lgJ"], P["Lr"]
                 lane.append([True, grp, g, grp, g, 0, P["J"], grp < R])
@@ -72,40 +72,21 @@ def reduce_model(P, S):
                 q2 = q - P["NTr"]
                 grp, g, lgG, L = q2 >> P["lgI"], q2 & (P["I"] - 1), P["lgI"], P["Lc"]
                 lane.append([False, grp, g, g, grp, P["I"], 0, grp < C])
-        assert len({(st[0]) for st in lane}) == 1          # the block is homogeneous: L, lgG of the last thread are the block's
-        row = lane[0][0]
-        grp0 = lane[0][1]
-        nvalid = R if row else C
-        base = 0 if row else R
-        sh = [0] * 256
-        for step in range(L + lgG):
+        for step in range(L + lgG):                       # L, lgG of the last lane: the wave is homogeneous
             if step < L:
-                for tid, st in enumerate(lane):
-                    _, grp, g, m, c, dm, dc, valid = st
+                for l, st in enumerate(lane):
+                    row, grp, g, m, c, dm, dc, valid = st
                     if valid and m < R and c < C:
                         v = first + (m >> lgrpp) * stride
                         r = (v << lgrpp) | (m & ((1 << lgrpp) - 1))
-                        acc[tid] += S[(r << lgC) | c]
+                        acc[l] += S[(r << lgC) | c]
                     st[3] += dm; st[4] += dc
             else:
-                lvl = step - L
-                if lvl == 0:
-                    sh = list(acc)
-                half = 1 << (lgG - lvl - 1)
-                new_sh = list(sh)
-                for tid in range(256 >> (lvl + 1)):
-                    gi, j = tid >> (lgG - lvl - 1), tid & (half - 1)
-                    slot = (gi << lgG) + j
-                    a = sh[slot] + sh[slot + half]
-                    if half > 1:
-                        new_sh[slot] = a
-                    elif grp0 + tid < nvalid:
-                        sums[base + grp0 + tid] = a
-                sh = new_sh
-        if lgG == 0:
-            for tid, st in enumerate(lane):
-                if st[7]:
-                    sums[base + st[1]] = acc[tid]
+                mask = 1 << (step - L)
+                acc = [acc[l] + acc[l ^ mask] for l in range(64)]
+        for l, st in enumerate(lane):
+            if st[7] and st[2] == 0:
+                sums[st[1] if st[0] else R + st[1]] = acc[l]
     planes = []
     for pl in range(P["npl"]):
         if pl < lgC:
@@ -126,5 +107,5 @@ def test_row_column_sums_and_bit_planes_reproduce_the_weighted_bucket_sum(c, sha
     rnd = random.Random(c * 1000 + shard[0] * 10 + nj)
     S = [rnd.randrange(1 << 24) for _ in range(P["nbt"])]
     want = sum((b + 1) * S[b] for v in range(P["first"], P["nparts"], P["stride"]) for b in range(v * P["nb"], (v + 1) * P["nb"]))
-    assert P["J"] * P["Lr"] == P["C"] and P["I"] * P["Lc"] >= P["R"] and P["NTr"] % 256 == 0 and P["NT"] % 256 == 0
+    assert P["J"] * P["Lr"] == P["C"] and P["I"] * P["Lc"] >= P["R"] and P["NTr"] % 64 == 0 and P["NT"] % 64 == 0
     assert reduce_model(P, S) == want
